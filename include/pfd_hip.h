@@ -1,0 +1,219 @@
+/*
+ * pfd_hip.h -- C ABI of libpfd_hip.so: the MI355X (gfx950) kernels behind the
+ * Prompt-Free-Diffusion denoising hot path (SeeCoder encode -> SD-v1.5 UNet DDIM
+ * loop -> AutoKL decode).
+ *
+ * The reference (SHI-Labs/Prompt-Free-Diffusion) has no FFI: its "operator API" is a
+ * Python class registry over stock torch ops.  This header is therefore the native
+ * boundary we define underneath that registry; every entry point names the reference
+ * op sequence (file:line under the reference tree) it replaces.  The Python host
+ * (prompt-free-diffusion_amd/lib/hip/binding.py) binds these with ctypes; see
+ * INTEGRATION.md for the stub a reference maintainer would add.
+ *
+ * Conventions
+ *   - all pointers are DEVICE pointers; activations/weights are IEEE fp16 ("f16"),
+ *     statistics, latents and schedule scalars are fp32; indices int32/int64 as stated
+ *   - activations are token-major / NHWC: element (b, y, x, c) of a [B,H,W,C] image
+ *     lives at ((b*H + y)*W + x)*ld + c, ld >= C (a row stride, in elements)
+ *   - no allocation, no host sync inside; all work is enqueued on `stream`
+ *     (a hipStream_t passed as void*); safe under hipGraph capture
+ *   - return 0 on success, negative PFD_E* on error (nothing is launched on error)
+ */
+#ifndef PFD_HIP_H
+#define PFD_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PFD_OK 0
+#define PFD_EINVAL (-1)   /* null pointer / non-positive size / misaligned stride   */
+#define PFD_ESHAPE (-2)   /* shape outside what the kernels are built for           */
+#define PFD_ELAUNCH (-3)  /* hipGetLastError() != hipSuccess after the launch       */
+
+#define PFD_ABI_VERSION 1
+
+typedef void* pfd_stream_t; /* hipStream_t */
+
+/* epilogue activations of pfd_gemm_f16 */
+#define PFD_ACT_NONE 0
+#define PFD_ACT_GELU 1  /* exact erf GELU: F.gelu attention.py:51, nn.GELU swin.py:84        */
+#define PFD_ACT_RELU 2  /* seecoder.py:65,214                                               */
+#define PFD_ACT_SILU 3  /* nn.SiLU openaimodel.py:2631, :218                                */
+#define PFD_ACT_GEGLU 4 /* x * gelu(gate), attention.py:49-51; W packed in 64-row blocks     */
+                        /* [32 rows of x | 32 rows of gate]; output has N/2 columns          */
+
+int pfd_abi_version(void);
+/* last hip error string observed by this library on the calling thread (never NULL) */
+const char* pfd_last_error(void);
+
+/* ------------------------------------------------------------------------------------
+ * Dense contraction on MFMA (v_mfma_f32_32x32x16_f16), fp32 accumulate.
+ *
+ *   ksize == 0 : C[m, n] = epi( sum_k A[m*lda + k] * W[n*ldw + k] )            (linear)
+ *   ksize  > 0 : implicit-GEMM convolution over an NHWC image A = [B,H,W,Cin] (row
+ *                stride lda): m = (b, oy, ox), k = (ky, kx, ci),
+ *                iy = oy*stride + ky - pad, ix likewise; out-of-range taps read 0;
+ *                with ups=1 the image is first nearest-2x upsampled (gather iy>>1).
+ *                W is [N][ksize*ksize*Cin] (tap-major, channel-minor), ldw its row stride.
+ *   epi(v) = act(v + bias[n or m] + rowvec[(m / rows_per_rv)*ldrv + n]) + R[m*ldr + n]
+ *
+ * Replaces: nn.Linear / 1x1 nn.Conv2d everywhere on the path (attention.py:169-176,
+ * 47-51, 60-67, 329-347; swin.py:88-90,171-173,322; seecoder.py:74-77,216-218,358;
+ * openaimodel.py:2629-2633,217-223,240); F.conv2d 3x3 s1/s2 (openaimodel.py:105,150,
+ * 203,229; autokl_modules.py:47-51,66-70,93-108; controlnet.py:165-181) together with
+ * the ops the reference runs around them: bias add, `h + emb_out` (openaimodel.py:272),
+ * `skip_connection(x) + h` (:274), `attn(...) + x` (attention.py:303-305),
+ * F.interpolate(scale 2, nearest) (openaimodel.py:114; autokl_modules.py:54) and
+ * GEGLU (attention.py:49-51).
+ *
+ * Requirements: K % 64 == 0 (linear) or Cin % 64 == 0 (conv); lda/ldw % 8 == 0;
+ * A, W 16-byte aligned.  M, N arbitrary (tails are masked).
+ * ---------------------------------------------------------------------------------- */
+typedef struct PfdGemmDesc {
+  const void* A;
+  const void* W;
+  const void* bias;   /* f16 [N] (or [M] if bias_per_row), may be NULL */
+  const void* rowvec; /* f16, may be NULL                               */
+  const void* R;      /* f16 residual, may be NULL                      */
+  void* C;            /* f16 [M, ldc]; N/2 columns when act==GEGLU       */
+  int64_t lda, ldw, ldr, ldc, ldrv;
+  int32_t M, N, K;
+  int32_t rows_per_rv;  /* >= 1 */
+  int32_t act;          /* PFD_ACT_*  */
+  int32_t bias_per_row; /* 0/1 */
+  /* implicit-conv geometry; ksize==0 -> plain GEMM and the rest is ignored */
+  int32_t ksize, stride, pad, ups;
+  int32_t B, H, Wd, Cin; /* input image (before the optional upsample) */
+  int32_t Ho, Wo;        /* output image; M must equal B*Ho*Wo          */
+} PfdGemmDesc;
+int pfd_gemm_f16(const PfdGemmDesc* d, pfd_stream_t stream);
+/* Same, with the block tile forced: tile = 10*TM + TN in {22, 21, 12, 11} meaning a
+ * (64*TM) x (64*TN) x 64 tile; 0 = the library's heuristic.  Tests and tuning only. */
+int pfd_gemm_f16_ex(const PfdGemmDesc* d, int32_t tile, pfd_stream_t stream);
+
+/* ------------------------------------------------------------------------------------
+ * Fused scaled-dot-product attention, online softmax in fp32 (never materialises the
+ * score matrix).  O[b,i,h,:] = softmax_j(scale * <Q[b,i,h,:], K[b,j,h,:]>) . V[b,j,h,:]
+ *   Q  element (b,i,h,d) at Q [b*q_bs + i*ldq + h*D + d]
+ *   K  element (b,j,h,d) at K [b*k_bs + j*ldk + h*D + d]
+ *   Vt element (b,j,h,d) at Vt[(h*D + d)*ldvt + b*vt_bs + j]     (V transposed: the
+ *      producer GEMM writes V^T = Wv . X^T directly, so no transpose pass exists)
+ *   O  element (b,i,h,d) at O [b*o_bs + i*ldo + h*D + d]
+ * Replaces CrossAttention.forward attention.py:178-201 (einsum, *scale, softmax,
+ * einsum and the two rearranges), xformers memory_efficient_attention :264, and
+ * nn.MultiheadAttention's core in seecoder.py:133,186.
+ * D in {40, 80, 96, 160}; ldq/ldk/ldo % 8 == 0, ldvt/vt_bs % 8 == 0; Nq, Nk arbitrary.
+ * ---------------------------------------------------------------------------------- */
+typedef struct PfdAttnDesc {
+  const void* Q;
+  const void* K;
+  const void* Vt;
+  void* O;
+  int64_t ldq, ldk, ldvt, ldo;
+  int64_t q_bs, k_bs, vt_bs, o_bs;
+  int32_t B, H, Nq, Nk, D;
+  float scale;
+} PfdAttnDesc;
+int pfd_attention_f16(const PfdAttnDesc* d, pfd_stream_t stream);
+
+/* ------------------------------------------------------------------------------------
+ * Swin (shifted-)window attention core for one image: pad to multiples of `ws`, cyclic
+ * roll by -shift, window partition, q*scale, QK^T + relative-position bias + shift mask
+ * (-100, not -inf), softmax, .V, window reverse, roll back, crop -- all as index math.
+ *   qkv   f16 [B*H*W, 3C]: LN(x) . Wqkv^T + b   (columns: q | k | v, head-major inside)
+ *   qkv_bias f16 [3C]: value of a zero-padded token's q|k|v (padding happens after
+ *            norm1 and before the qkv Linear, swin.py:266-273,186)
+ *   rpb   f16 [(2ws-1)^2, nH] relative_position_bias_table (swin.py:155-156,192-195)
+ *   out   f16 [B*H*W, C]  (input of WindowAttention.proj)
+ * Replaces swin.py:266-302 + 186-207 + the mask construction 421-440.
+ * head_dim must be 32, ws 12 (Swin-L, configs/model/swin.yaml:18-29).
+ * ---------------------------------------------------------------------------------- */
+typedef struct PfdSwinAttnDesc {
+  const void* qkv;
+  const void* qkv_bias;
+  const void* rpb;
+  void* out;
+  int32_t B, H, W, C, nH, ws, shift;
+  float scale;
+} PfdSwinAttnDesc;
+int pfd_swin_window_attention_f16(const PfdSwinAttnDesc* d, pfd_stream_t stream);
+
+/* ------------------------------------------------------------------------------------
+ * GroupNorm (+ optional SiLU) over NHWC, statistics in fp32.  The input may be the
+ * channel concatenation of two tensors (skip connections, pfd.py:356 / :519) which is
+ * never materialised: x2 may be NULL (C2 = 0).
+ *   y[b,p,c] = act( (x[b,p,c] - mean[b,g]) * rstd[b,g] * gamma[c] + beta[c] )
+ * ws: fp32 workspace of at least pfd_groupnorm_ws_bytes(B, C1+C2, HW) bytes.
+ * Replaces GroupNorm32 + SiLU (openaimodel.py:200-202,224-226,2732-2734; eps 1e-5),
+ * Normalize (attention.py:83-84, autokl_modules.py:38-39; eps 1e-6) + nonlinearity
+ * (autokl_modules.py:33-35), nn.GroupNorm(32, .) (seecoder.py:359,383).
+ * C1, C2 % 8 == 0; (C1+C2) % G == 0.
+ * ---------------------------------------------------------------------------------- */
+size_t pfd_groupnorm_ws_bytes(int32_t B, int32_t C, int32_t HW);
+int pfd_groupnorm_f16(const void* x1, int32_t C1, int64_t ldx1, const void* x2, int32_t C2,
+                      int64_t ldx2, const void* gamma, const void* beta, void* y, int64_t ldy,
+                      int32_t B, int32_t HW, int32_t G, float eps, int32_t act /*NONE|SILU*/,
+                      void* ws, size_t ws_bytes, pfd_stream_t stream);
+
+/* LayerNorm over the last dim of a [M, C] token matrix, fp32 statistics.
+ * gather4 != 0: PatchMerging gather -- row r=(b,oy,ox) of the normalised matrix is the
+ * concat [x(2oy,2ox) | x(2oy+1,2ox) | x(2oy,2ox+1) | x(2oy+1,2ox+1)] of a [B,H,W,C/4]
+ * image (zero beyond H/W when odd) (swin.py:334-348).
+ * Replaces nn.LayerNorm (attention.py:294-296, swin.py:241,247,323,600, seecoder.py:72,
+ * 79,113,163,219).  C % 8 == 0, C <= 8192. */
+int pfd_layernorm_f16(const void* x, int64_t ldx, const void* gamma, const void* beta, void* y,
+                      int64_t ldy, int32_t M, int32_t C, float eps, int32_t gather4, int32_t B,
+                      int32_t H, int32_t W, pfd_stream_t stream);
+
+/* Row softmax with pre-scale: y[r,:] = softmax(scale * x[r,:]) (fp32 math), [R, N] f16.
+ * Used by the VAE mid-block single-head attention (autokl_modules.py:186-197). */
+int pfd_softmax_rows_f16(const void* x, int64_t ldx, void* y, int64_t ldy, int32_t R, int32_t N,
+                         float scale, pfd_stream_t stream);
+
+/* ------------------------------------------------------------------------------------
+ * Boundary / elementwise kernels (HBM-bound)
+ * ---------------------------------------------------------------------------------- */
+/* NCHW (fp32 if src_f32 else f16) -> NHWC f16, y = x*mul + add.  `rep` > 1 writes the
+ * batch `rep` times back to back (CFG batch doubling torch.cat([x]*2), ddim.py:145). */
+int pfd_nchw_to_nhwc_f16(const void* x, int32_t src_f32, void* y, int32_t B, int32_t C, int32_t H,
+                         int32_t W, float mul, float add, int32_t rep, pfd_stream_t stream);
+/* NHWC f16 -> NCHW (fp32 if dst_f32 else f16), y = clamp(x*mul + add, lo, hi).
+ * With mul=.5, add=.5, lo=0, hi=1 this is AutoencoderKL.decode's tail (autokl.py:47,53). */
+int pfd_nhwc_to_nchw(const void* x, void* y, int32_t dst_f32, int32_t B, int32_t C, int32_t H,
+                     int32_t W, float mul, float add, float lo, float hi, pfd_stream_t stream);
+/* im2col for convolutions whose Cin is not a multiple of 64 (UNet stem 4ch, ControlNet
+ * hint encoder, VAE conv_in, Swin patch-embed 4x4/4): col[m, (ky*k+kx)*Cin + ci], zero
+ * padded to Kpad columns.  NHWC f16 in. */
+int pfd_im2col_f16(const void* x, int64_t ldx, void* col, int32_t B, int32_t H, int32_t W,
+                   int32_t Cin, int32_t ksize, int32_t stride, int32_t pad, int32_t Ho, int32_t Wo,
+                   int32_t Kpad, pfd_stream_t stream);
+/* sinusoidal timestep embedding, fp32 math, cos half first (diffusion_utils.py:131-151),
+ * cast to f16 (pfd.py:486).  t: int64 [B]; out f16 [B, dim]. */
+int pfd_timestep_embedding_f16(const int64_t* t, void* out, int32_t B, int32_t dim,
+                               float max_period, pfd_stream_t stream);
+/* Classifier-free-guidance combine + DDIM update, fp32 (ddim.py:150-151,159-171):
+ *   e = e_u + s*(e_c - e_u);  pred_x0 = (x - sqrt(1-a_t) e)/sqrt(a_t)
+ *   x_prev = sqrt(a_prev) pred_x0 + sqrt(1 - a_prev - sigma^2) e + sigma*noise
+ * eps: NHWC f16 [nb*B, h, w, C] (uncond batch first; nb=1 -> e = s*eps, ddim.py:142-143)
+ * x, x_prev, pred_x0: NCHW fp32 [B,C,h,w]; noise may be NULL (eta == 0).
+ * coef: device fp32 [5] = {a_t, a_prev, sigma_t, sqrt(1-a_t), guidance scale}.
+ * xin_next (may be NULL): NHWC f16 [nb*B,h,w,C] = x_prev duplicated nb times, i.e. the
+ * next step's UNet input (ddim.py:145 fused). */
+int pfd_cfg_ddim_step(const void* eps, int32_t nb, const float* x, const float* noise,
+                      const float* coef, float* x_prev, float* pred_x0, void* xin_next, int32_t B,
+                      int32_t C, int32_t h, int32_t w, pfd_stream_t stream);
+/* y = a + b (f16, fp32 add), n elements; b may be NULL (copy). */
+int pfd_add_f16(const void* a, const void* b, void* y, int64_t n, pfd_stream_t stream);
+/* y[r, c] = x[r, c] + v[c] for a [R, C] f16 matrix (level/positional embeddings,
+ * seecoder.py:402,515). */
+int pfd_add_rowvec_f16(const void* x, int64_t ldx, const void* v, void* y, int64_t ldy, int32_t R,
+                       int32_t C, pfd_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PFD_HIP_H */

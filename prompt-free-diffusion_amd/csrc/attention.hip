@@ -1,0 +1,227 @@
+// pfd_attention_f16: fused QK^T -> online softmax -> PV on v_mfma_f32_32x32x16_f16.
+//
+// The kernel works on the TRANSPOSED problem so that the softmax reduction axis is
+// (almost) lane-local and P never leaves registers:
+//     S^T[kv, q] = sum_d K[kv, d] Q[q, d]        A = K tile (LDS), B = Q (registers)
+//     O^T[d,  q] = sum_kv V^T[d, kv] P^T[kv, q]   A = V^T tile (LDS), B = P^T (registers)
+// A 32x32 S^T accumulator has col = q = lane&31 and rows kv = (r&3) + 8(r>>2) + 4(lane>>5):
+// one q column is split over lanes l and l^32, so the row max / row sum need exactly one
+// cross-lane exchange.  Registers 8b..8b+7 of that accumulator are, for 16-kv block b, the
+// 8 values an MFMA B operand wants -- in the k order pi(hi, j) = (j&3) + 8(j>>2) + 4hi.  MFMA
+// only needs A and B to agree on which k a (lane-group, j) slot means, so the V^T A operand
+// is read in the same pi order: two 8-byte LDS reads per fragment, no permutation of P.
+// V arrives already transposed from its producer GEMM (see pfd_hip.h), K row-major.
+//
+// Block = 4 waves x 32 query rows; KV tile = 64 keys; per tile per wave:
+// 2*DQK/16 + 4*DV/32 MFMAs (DQK = D rounded to 16, DV = D rounded to 32).
+#include "pfd_common.h"
+
+namespace {
+
+constexpr int KV_TILE = 64;
+constexpr int VT_LD = KV_TILE + 4;  // halfs; 136-B rows: conflict-free ds_read_b64 over 32 rows
+
+struct AttnParams {
+  const half_t* Q;
+  const half_t* K;
+  const half_t* Vt;
+  half_t* O;
+  long ldq, ldk, ldvt, ldo;
+  long q_bs, k_bs, vt_bs, o_bs;
+  int B, H, Nq, Nk, D;
+  float scale_log2;
+};
+
+template <int D>
+__global__ __launch_bounds__(256) void attention_kernel(const AttnParams p) {
+  constexpr int DQK = (D + 15) / 16 * 16;
+  constexpr int DV = (D + 31) / 32 * 32;
+  constexpr int K_LD = DQK + 8;  // halfs; (DQK+8)*2 B is an odd multiple of 16 B for D in {40,80,96,160}
+  constexpr int NS = DQK / 16;
+  constexpr int ND = DV / 32;
+  __shared__ __attribute__((aligned(16))) half_t Ks[KV_TILE * K_LD];
+  __shared__ __attribute__((aligned(16))) half_t Vts[DV * VT_LD];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l31 = lane & 31, hi = lane >> 5;
+  const int h = blockIdx.y, b = blockIdx.z;
+  const int q_row = blockIdx.x * 128 + wave * 32 + l31;
+
+  // zero the LDS padding once (columns D..DQK of K, rows D..DV of V^T)
+  for (int i = tid; i < KV_TILE * K_LD; i += 256) Ks[i] = (half_t)0.f;
+  for (int i = tid; i < DV * VT_LD; i += 256) Vts[i] = (half_t)0.f;
+
+  // Q fragments: B operand, col = q = lane&31, k = d
+  half8_t qf[NS];
+  {
+    const half_t* qp = p.Q + (long)b * p.q_bs + (long)q_row * p.ldq + h * D;
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+      const int d = s * 16 + hi * 8;
+      Pack16 t;
+      t.u = make_uint4(0, 0, 0, 0);
+      if (q_row < p.Nq && d < D) t.u = *reinterpret_cast<const uint4*>(qp + d);
+      qf[s] = t.h;
+    }
+  }
+
+  float16_t o_acc[ND];
+#pragma unroll
+  for (int i = 0; i < ND; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o_acc[i][r] = 0.f;
+  float m_run = -INFINITY, l_run = 0.f;
+
+  const half_t* kbase = p.K + (long)b * p.k_bs + h * D;
+  const half_t* vbase = p.Vt + (long)h * D * p.ldvt + (long)b * p.vt_bs;
+  constexpr int KCH = D / 8;  // 16-B chunks per K row
+
+  for (int kv0 = 0; kv0 < p.Nk; kv0 += KV_TILE) {
+    __syncthreads();  // previous tile fully consumed (also orders the zero fill on entry)
+    for (int c = tid; c < KV_TILE * KCH; c += 256) {
+      const int row = c / KCH, cc = c - row * KCH;
+      uint4 v = make_uint4(0, 0, 0, 0);
+      if (kv0 + row < p.Nk) v = *reinterpret_cast<const uint4*>(kbase + (long)(kv0 + row) * p.ldk + cc * 8);
+      *reinterpret_cast<uint4*>(Ks + row * K_LD + cc * 8) = v;
+    }
+    for (int c = tid; c < D * 8; c += 256) {
+      const int d = c >> 3, cc = c & 7;
+      const int kv = kv0 + cc * 8;
+      Pack16 v;
+      v.u = make_uint4(0, 0, 0, 0);
+      if (kv < p.Nk) {
+        v.u = *reinterpret_cast<const uint4*>(vbase + (long)d * p.ldvt + kv);
+        if (kv + 8 > p.Nk) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e)
+            if (kv + e >= p.Nk) v.e[e] = (half_t)0.f;
+        }
+      }
+      uint2* dst = reinterpret_cast<uint2*>(Vts + d * VT_LD + cc * 8);
+      dst[0] = make_uint2(v.u.x, v.u.y);
+      dst[1] = make_uint2(v.u.z, v.u.w);
+    }
+    __syncthreads();
+
+    // ---- S^T = K . Q^T for the two 32-key halves of the tile ----
+    float16_t st[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) st[u][r] = 0.f;
+      const half_t* kp = Ks + (u * 32 + l31) * K_LD + hi * 8;
+#pragma unroll
+      for (int s = 0; s < NS; ++s) {
+        const half8_t kf = *reinterpret_cast<const half8_t*>(kp + s * 16);
+        st[u] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[s], st[u], 0, 0, 0);
+      }
+    }
+    // ---- online softmax over this tile's 64 keys (log2 domain) ----
+    float mx = -INFINITY;
+    const bool tail = kv0 + KV_TILE > p.Nk;
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        float v = st[u][r] * p.scale_log2;
+        if (tail && kv0 + u * 32 + mfma32_row(r, hi) >= p.Nk) v = -INFINITY;
+        st[u][r] = v;
+        mx = fmaxf(mx, v);
+      }
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    const float m_new = fmaxf(m_run, mx);  // finite: every tile holds at least one valid key
+    const float alpha = exp2f(m_run - m_new);
+    float rs = 0.f;
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float e = exp2f(st[u][r] - m_new);
+        st[u][r] = e;
+        rs += e;
+      }
+    rs += __shfl_xor(rs, 32, 64);
+    l_run = l_run * alpha + rs;
+    m_run = m_new;
+#pragma unroll
+    for (int i = 0; i < ND; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) o_acc[i][r] *= alpha;
+
+    // ---- P^T to f16 B fragments; O^T += V^T . P^T ----
+    half8_t pf[2][2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+      for (int bb = 0; bb < 2; ++bb)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) pf[u][bb][j] = (half_t)st[u][bb * 8 + j];
+#pragma unroll
+    for (int i = 0; i < ND; ++i) {
+      const half_t* vp = Vts + (i * 32 + l31) * VT_LD + 4 * hi;
+#pragma unroll
+      for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int bb = 0; bb < 2; ++bb) {
+          const half4_t lo4 = *reinterpret_cast<const half4_t*>(vp + u * 32 + bb * 16);
+          const half4_t hi4 = *reinterpret_cast<const half4_t*>(vp + u * 32 + bb * 16 + 8);
+          half8_t vf;
+          vf[0] = lo4[0]; vf[1] = lo4[1]; vf[2] = lo4[2]; vf[3] = lo4[3];
+          vf[4] = hi4[0]; vf[5] = hi4[1]; vf[6] = hi4[2]; vf[7] = hi4[3];
+          o_acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf[u][bb], o_acc[i], 0, 0, 0);
+        }
+    }
+  }
+
+  // ---- epilogue: O[q, d] = O^T[d, q] / l ----
+  if (q_row < p.Nq) {
+    const float inv = 1.0f / l_run;
+    half_t* op = p.O + (long)b * p.o_bs + (long)q_row * p.ldo + h * D;
+#pragma unroll
+    for (int i = 0; i < ND; ++i)
+#pragma unroll
+      for (int rq = 0; rq < 4; ++rq) {
+        const int d0 = i * 32 + 8 * rq + 4 * hi;
+        if (d0 < D) {
+          half4_t o;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) o[e] = (half_t)(o_acc[i][rq * 4 + e] * inv);
+          *reinterpret_cast<half4_t*>(op + d0) = o;
+        }
+      }
+  }
+}
+
+template <int D>
+int launch(const AttnParams& p, hipStream_t s) {
+  dim3 grid((p.Nq + 127) / 128, p.H, p.B);
+  hipLaunchKernelGGL((attention_kernel<D>), grid, dim3(256), 0, s, p);
+  return pfd_check_launch("pfd_attention_f16");
+}
+
+}  // namespace
+
+extern "C" int pfd_attention_f16(const PfdAttnDesc* d, pfd_stream_t stream) {
+  if (!d || !d->Q || !d->K || !d->Vt || !d->O) return PFD_EINVAL;
+  if (d->B <= 0 || d->H <= 0 || d->Nq <= 0 || d->Nk <= 0) return PFD_EINVAL;
+  if ((d->ldq & 7) || (d->ldk & 7) || (d->ldo & 7) || (d->ldvt & 7) || (d->vt_bs & 7) || (d->q_bs & 7) ||
+      (d->k_bs & 7) || (d->o_bs & 7))
+    return PFD_EINVAL;
+  if ((reinterpret_cast<uintptr_t>(d->Q) & 15) || (reinterpret_cast<uintptr_t>(d->K) & 15) ||
+      (reinterpret_cast<uintptr_t>(d->Vt) & 15) || (reinterpret_cast<uintptr_t>(d->O) & 15))
+    return PFD_EINVAL;
+  AttnParams p;
+  p.Q = (const half_t*)d->Q; p.K = (const half_t*)d->K; p.Vt = (const half_t*)d->Vt; p.O = (half_t*)d->O;
+  p.ldq = d->ldq; p.ldk = d->ldk; p.ldvt = d->ldvt; p.ldo = d->ldo;
+  p.q_bs = d->q_bs; p.k_bs = d->k_bs; p.vt_bs = d->vt_bs; p.o_bs = d->o_bs;
+  p.B = d->B; p.H = d->H; p.Nq = d->Nq; p.Nk = d->Nk; p.D = d->D;
+  p.scale_log2 = d->scale * 1.4426950408889634f;
+  hipStream_t s = (hipStream_t)stream;
+  switch (d->D) {
+    case 40: return launch<40>(p, s);
+    case 80: return launch<80>(p, s);
+    case 96: return launch<96>(p, s);
+    case 160: return launch<160>(p, s);
+    default: return PFD_ESHAPE;
+  }
+}

@@ -1,0 +1,337 @@
+// pfd_gemm_f16: linear / 1x1 / 3x3 implicit-GEMM convolution on v_mfma_f32_32x32x16_f16.
+//
+// Tile: BM x BN x 64, BM = 64*TM, BN = 64*TN; 256 threads = 4 waves as 2(M) x 2(N); each wave
+// owns TM x TN MFMA tiles of 32x32 (fp32 accumulators live in the unified VGPR/AGPR file).
+// Operands are staged global -> registers -> LDS (two LDS buffers, one barrier per K step;
+// the next tile's global loads are in flight during the current tile's MFMAs).  Register
+// staging rather than LDS-DMA because the convolution's A operand is a gather with zero
+// fill at the image border.  LDS rows are 64 halfs + 8 pad = 144 B = 9 x 16 B: an odd
+// number of 16-B slots makes every ds_read_b128 lane group hit 16 distinct slots.
+// Epilogue: accumulators (+bias, +row vector, activation / GEGLU) go to an fp32 LDS image,
+// then every thread adds the residual and writes whole 16-B rows segments.
+//
+// HBM bytes per tile step: (BM + BN) * 64 * 2; MFMA flops: 2 * BM * BN * 64.
+#include "pfd_common.h"
+
+namespace {
+
+constexpr int BK = 64;
+constexpr int LDS_LD = BK + 8;  // halfs per LDS row
+
+struct GemmParams {
+  const half_t* A;
+  const half_t* W;
+  const half_t* bias;
+  const half_t* rowvec;
+  const half_t* R;
+  half_t* C;
+  long lda, ldw, ldr, ldc, ldrv;
+  int M, N, K;
+  int rows_per_rv, act, bias_per_row;
+  int ksize, stride, pad, ups;
+  int B, H, Wd, Cin, Ho, Wo;
+  int tiles_m, tiles_n;
+};
+
+template <int TM, int TN>
+struct Cfg {
+  static constexpr int BM = 64 * TM;
+  static constexpr int BN = 64 * TN;
+  static constexpr int A_CH = BM * 8 / 256;  // 16-B chunks per thread for the A tile
+  static constexpr int B_CH = BN * 8 / 256;
+  static constexpr int STAGE_HALFS = (BM + BN) * LDS_LD;
+  static constexpr int MAIN_BYTES = 2 * STAGE_HALFS * 2;
+  static constexpr int EPI_LD = BN + 4;  // floats per staged output row
+  static constexpr int EPI_BYTES = BM * EPI_LD * 4;
+  static constexpr int SMEM = MAIN_BYTES > EPI_BYTES ? MAIN_BYTES : EPI_BYTES;
+};
+
+template <int TM, int TN, bool CONV>
+__global__ __launch_bounds__(256) void gemm_conv_kernel(const GemmParams p) {
+  using C_ = Cfg<TM, TN>;
+  constexpr int BM = C_::BM, BN = C_::BN;
+  __shared__ __attribute__((aligned(16))) char smem[C_::SMEM];
+  half_t* lds = reinterpret_cast<half_t*>(smem);
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int l31 = lane & 31, hi = lane >> 5;
+
+  const int nblk = p.tiles_m * p.tiles_n;
+  const int t = xcd_remap(blockIdx.x, nblk);
+  const int tile_m = t / p.tiles_n;
+  const int tile_n = t - tile_m * p.tiles_n;
+  const int m0 = tile_m * BM;
+  const int n0 = tile_n * BN;
+
+  // ---- per-thread staging geometry (rows are fixed over the K loop) ----
+  const int cc = tid & 7;    // 16-B chunk inside the 128-B K slab
+  const int row0 = tid >> 3; // 0..31; chunk i covers row0 + 32*i
+  bool a_ok[C_::A_CH];
+  long a_off[C_::A_CH];                                   // plain GEMM: element offset of the row
+  int a_b[C_::A_CH], a_y[C_::A_CH], a_x[C_::A_CH];        // conv: output coordinates
+#pragma unroll
+  for (int i = 0; i < C_::A_CH; ++i) {
+    const int m = m0 + row0 + 32 * i;
+    a_ok[i] = m < p.M;
+    if (CONV) {
+      const int hw = p.Ho * p.Wo;
+      const int b = m / hw;
+      const int rem = m - b * hw;
+      const int oy = rem / p.Wo;
+      a_b[i] = b;
+      a_y[i] = oy * p.stride - p.pad;
+      a_x[i] = (rem - oy * p.Wo) * p.stride - p.pad;
+      a_off[i] = 0;
+    } else {
+      a_off[i] = (long)m * p.lda + cc * 8;
+      a_b[i] = a_y[i] = a_x[i] = 0;
+    }
+  }
+  bool b_ok[C_::B_CH];
+  long b_off[C_::B_CH];
+#pragma unroll
+  for (int i = 0; i < C_::B_CH; ++i) {
+    const int n = n0 + row0 + 32 * i;
+    b_ok[i] = n < p.N;
+    b_off[i] = (long)n * p.ldw + cc * 8;
+  }
+
+  uint4 ra[C_::A_CH], rb[C_::B_CH];
+  const int Hin = p.ups ? 2 * p.H : p.H;
+  const int Win = p.ups ? 2 * p.Wd : p.Wd;
+
+  auto load_tile = [&](int kt) {
+    const int k0 = kt * BK;
+    if (CONV) {
+      const int tap = k0 / p.Cin;
+      const int ci0 = k0 - tap * p.Cin;
+      const int ky = tap / p.ksize;
+      const int kx = tap - ky * p.ksize;
+#pragma unroll
+      for (int i = 0; i < C_::A_CH; ++i) {
+        int iy = a_y[i] + ky, ix = a_x[i] + kx;
+        const bool ok = a_ok[i] && iy >= 0 && iy < Hin && ix >= 0 && ix < Win;
+        if (p.ups) {
+          iy >>= 1;
+          ix >>= 1;
+        }
+        const long off = (((long)a_b[i] * p.H + iy) * p.Wd + ix) * p.lda + ci0 + cc * 8;
+        ra[i] = ok ? *reinterpret_cast<const uint4*>(p.A + off) : make_uint4(0, 0, 0, 0);
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < C_::A_CH; ++i)
+        ra[i] = a_ok[i] ? *reinterpret_cast<const uint4*>(p.A + a_off[i] + k0)
+                        : make_uint4(0, 0, 0, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < C_::B_CH; ++i)
+      rb[i] = b_ok[i] ? *reinterpret_cast<const uint4*>(p.W + b_off[i] + k0)
+                      : make_uint4(0, 0, 0, 0);
+  };
+  auto store_tile = [&](int buf) {
+    half_t* As = lds + buf * C_::STAGE_HALFS;
+    half_t* Bs = As + BM * LDS_LD;
+#pragma unroll
+    for (int i = 0; i < C_::A_CH; ++i)
+      *reinterpret_cast<uint4*>(As + (row0 + 32 * i) * LDS_LD + cc * 8) = ra[i];
+#pragma unroll
+    for (int i = 0; i < C_::B_CH; ++i)
+      *reinterpret_cast<uint4*>(Bs + (row0 + 32 * i) * LDS_LD + cc * 8) = rb[i];
+  };
+
+  float16_t acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int nk = p.K / BK;
+  load_tile(0);
+  store_tile(0);
+  __syncthreads();
+
+  for (int kt = 0; kt < nk; ++kt) {
+    const int buf = kt & 1;
+    if (kt + 1 < nk) load_tile(kt + 1);
+    const half_t* As = lds + buf * C_::STAGE_HALFS + (wm * 32 * TM + l31) * LDS_LD + hi * 8;
+    const half_t* Bs = lds + buf * C_::STAGE_HALFS + BM * LDS_LD + (wn * 32 * TN + l31) * LDS_LD + hi * 8;
+#pragma unroll
+    for (int s = 0; s < BK / 16; ++s) {
+      half8_t af[TM], bf[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+        af[i] = *reinterpret_cast<const half8_t*>(As + i * 32 * LDS_LD + s * 16);
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+        bf[j] = *reinterpret_cast<const half8_t*>(Bs + j * 32 * LDS_LD + s * 16);
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[i], bf[j], acc[i][j], 0, 0, 0);
+    }
+    if (kt + 1 < nk) store_tile(buf ^ 1);
+    __syncthreads();
+  }
+
+  // ---- epilogue phase 1: registers -> fp32 LDS image (bias, row vector, activation) ----
+  float* Cs = reinterpret_cast<float*>(smem);
+  const bool geglu = p.act == PFD_ACT_GEGLU;
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int nl = wn * 32 * TN + j * 32 + l31;
+      const int n = n0 + nl;
+      float bcol = 0.f;
+      if (p.bias && !p.bias_per_row && n < p.N) bcol = (float)p.bias[n];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int ml = wm * 32 * TM + i * 32 + mfma32_row(r, hi);
+        const int m = m0 + ml;
+        float v = acc[i][j][r] + bcol;
+        if (m < p.M && n < p.N) {
+          if (p.bias && p.bias_per_row) v += (float)p.bias[m];
+          if (p.rowvec) v += (float)p.rowvec[(long)(m / p.rows_per_rv) * p.ldrv + n];
+        }
+        if (p.act == PFD_ACT_GELU) v = pfd_gelu(v);
+        else if (p.act == PFD_ACT_RELU) v = fmaxf(v, 0.f);
+        else if (p.act == PFD_ACT_SILU) v = pfd_silu(v);
+        acc[i][j][r] = v;
+      }
+    }
+  }
+  if (geglu) {
+    if constexpr (TN == 2) {
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int ml = wm * 32 * TM + i * 32 + mfma32_row(r, hi);
+          Cs[ml * C_::EPI_LD + wn * 32 + l31] = acc[i][0][r] * pfd_gelu(acc[i][1][r]);
+        }
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int ml = wm * 32 * TM + i * 32 + mfma32_row(r, hi);
+          Cs[ml * C_::EPI_LD + wn * 32 * TN + j * 32 + l31] = acc[i][j][r];
+        }
+  }
+  __syncthreads();
+
+  // ---- epilogue phase 2: + residual, 16-B row segments to HBM ----
+  const int bn_out = geglu ? BN / 2 : BN;
+  const int n_out0 = geglu ? n0 / 2 : n0;
+  const int N_out = geglu ? p.N / 2 : p.N;
+  const int cpr = bn_out / 8;  // chunks per row
+  const bool vec_ok = ((p.ldc & 7) == 0) && (p.R == nullptr || (p.ldr & 7) == 0) &&
+                      ((reinterpret_cast<uintptr_t>(p.C) & 15) == 0) &&
+                      (p.R == nullptr || (reinterpret_cast<uintptr_t>(p.R) & 15) == 0);
+  for (int c = tid; c < BM * cpr; c += 256) {
+    const int ml = c / cpr;
+    const int nc = (c - ml * cpr) * 8;
+    const int m = m0 + ml;
+    const int n = n_out0 + nc;
+    if (m >= p.M || n >= N_out) continue;
+    const float4_t v0 = *reinterpret_cast<const float4_t*>(Cs + ml * C_::EPI_LD + nc);
+    const float4_t v1 = *reinterpret_cast<const float4_t*>(Cs + ml * C_::EPI_LD + nc + 4);
+    float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+    if (vec_ok && n + 8 <= N_out) {
+      if (p.R) {
+        Pack16 r;
+        r.u = *reinterpret_cast<const uint4*>(p.R + (long)m * p.ldr + n);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] += (float)r.e[e];
+      }
+      Pack16 o;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) o.e[e] = (half_t)v[e];
+      *reinterpret_cast<uint4*>(p.C + (long)m * p.ldc + n) = o.u;
+    } else {
+      for (int e = 0; e < 8 && n + e < N_out; ++e) {
+        float x = v[e];
+        if (p.R) x += (float)p.R[(long)m * p.ldr + n + e];
+        p.C[(long)m * p.ldc + n + e] = (half_t)x;
+      }
+    }
+  }
+}
+
+template <int TM, int TN>
+int launch(const GemmParams& p0, hipStream_t s) {
+  GemmParams p = p0;
+  using C_ = Cfg<TM, TN>;
+  p.tiles_m = (p.M + C_::BM - 1) / C_::BM;
+  p.tiles_n = (p.N + C_::BN - 1) / C_::BN;
+  const int grid = p.tiles_m * p.tiles_n;
+  if (p.ksize > 0)
+    hipLaunchKernelGGL((gemm_conv_kernel<TM, TN, true>), dim3(grid), dim3(256), 0, s, p);
+  else
+    hipLaunchKernelGGL((gemm_conv_kernel<TM, TN, false>), dim3(grid), dim3(256), 0, s, p);
+  return pfd_check_launch("pfd_gemm_f16");
+}
+
+}  // namespace
+
+extern "C" int pfd_gemm_f16_ex(const PfdGemmDesc* d, int32_t tile, pfd_stream_t stream) {
+  if (!d || !d->A || !d->W || !d->C) return PFD_EINVAL;
+  if (d->M <= 0 || d->N <= 0 || d->K <= 0) return PFD_EINVAL;
+  if ((d->lda & 7) || (d->ldw & 7)) return PFD_EINVAL;
+  if ((reinterpret_cast<uintptr_t>(d->A) & 15) || (reinterpret_cast<uintptr_t>(d->W) & 15)) return PFD_EINVAL;
+  if (d->K % BK) return PFD_ESHAPE;
+  if (d->rowvec && d->rows_per_rv < 1) return PFD_EINVAL;
+  GemmParams p;
+  p.A = (const half_t*)d->A;
+  p.W = (const half_t*)d->W;
+  p.bias = (const half_t*)d->bias;
+  p.rowvec = (const half_t*)d->rowvec;
+  p.R = (const half_t*)d->R;
+  p.C = (half_t*)d->C;
+  p.lda = d->lda; p.ldw = d->ldw; p.ldr = d->ldr; p.ldc = d->ldc; p.ldrv = d->ldrv;
+  p.M = d->M; p.N = d->N; p.K = d->K;
+  p.rows_per_rv = d->rows_per_rv > 0 ? d->rows_per_rv : 1;
+  p.act = d->act; p.bias_per_row = d->bias_per_row;
+  p.ksize = d->ksize; p.stride = d->stride; p.pad = d->pad; p.ups = d->ups;
+  p.B = d->B; p.H = d->H; p.Wd = d->Wd; p.Cin = d->Cin; p.Ho = d->Ho; p.Wo = d->Wo;
+  p.tiles_m = p.tiles_n = 0;
+  if (p.ksize > 0) {
+    if (p.Cin % BK) return PFD_ESHAPE;
+    if (p.K != p.ksize * p.ksize * p.Cin) return PFD_EINVAL;
+    if ((long)p.B * p.Ho * p.Wo != p.M) return PFD_EINVAL;
+    if (p.stride < 1) return PFD_EINVAL;
+  }
+  if (p.act < PFD_ACT_NONE || p.act > PFD_ACT_GEGLU) return PFD_EINVAL;
+  hipStream_t s = (hipStream_t)stream;
+  if (p.act == PFD_ACT_GEGLU) {
+    if (p.N % 128) return PFD_ESHAPE;
+    return launch<2, 2>(p, s);
+  }
+  switch (tile) {  // explicit tile (tests / tuning); 0 = heuristic below
+    case 0: break;
+    case 22: return launch<2, 2>(p, s);
+    case 21: return launch<2, 1>(p, s);
+    case 12: return launch<1, 2>(p, s);
+    case 11: return launch<1, 1>(p, s);
+    default: return PFD_EINVAL;
+  }
+  // Tile choice: fill the 256 CUs first, then prefer the larger (higher-intensity) tile.
+  auto blocks = [&](int bm, int bn) { return (long)((p.M + bm - 1) / bm) * ((p.N + bn - 1) / bn); };
+  auto waste = [&](int bn) { return (double)(((p.N + bn - 1) / bn) * bn) / p.N; };
+  if (blocks(128, 128) >= 512 && waste(128) <= 1.13) return launch<2, 2>(p, s);
+  if (blocks(128, 64) >= 384 && p.M >= 128) return launch<2, 1>(p, s);
+  if (p.N > 64 && blocks(64, 128) >= 384 && waste(128) <= 1.13) return launch<1, 2>(p, s);
+  return launch<1, 1>(p, s);
+}
+
+extern "C" int pfd_gemm_f16(const PfdGemmDesc* d, pfd_stream_t stream) { return pfd_gemm_f16_ex(d, 0, stream); }

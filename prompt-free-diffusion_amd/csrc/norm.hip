@@ -1,0 +1,345 @@
+// HBM-bound normalisation kernels: GroupNorm(+SiLU) over NHWC (optionally over the virtual
+// channel-concat of two tensors), LayerNorm (optionally over the PatchMerging gather) and a
+// scaled row softmax.  All statistics in fp32; every global access is a 16-byte vector.
+//
+// GroupNorm algorithmic HBM bytes per element: 2 (stats read) + 2 (apply read) + 2 (write).
+#include "pfd_common.h"
+
+namespace {
+
+constexpr int GN_MAX_CHUNKS = 256;
+constexpr int GN_MAX_G = 64;
+
+struct GnSrc {
+  const half_t* x1;
+  const half_t* x2;
+  long ld1, ld2;
+  int C1, C2;
+};
+
+__device__ __forceinline__ uint4 gn_load(const GnSrc& s, long row, int v) {
+  const int c = v * 8;
+  if (c < s.C1) return *reinterpret_cast<const uint4*>(s.x1 + row * s.ld1 + c);
+  return *reinterpret_cast<const uint4*>(s.x2 + row * s.ld2 + (c - s.C1));
+}
+
+// Thread (v, rt): owns 8 channels v*8.. (two vec slots when C > 2048) and rows rt, rt+RT, ...
+// of its chunk, so a wave's loads sweep contiguous memory when ld == C.
+__global__ __launch_bounds__(256) void gn_stats_kernel(GnSrc s, int HW, int G, int rows_per_chunk,
+                                                       float* __restrict__ partial) {
+  __shared__ float red[256 * 16];
+  __shared__ float chan[4096 * 2];
+  const int C = s.C1 + s.C2;
+  const int nvec = C / 8;
+  const int b = blockIdx.y, chunk = blockIdx.x;
+  const int tid = threadIdx.x;
+  const int VT = nvec < 256 ? nvec : 256;
+  const int RT = 256 / VT;
+  const int v0 = tid % VT, rt = tid / VT;
+  const int r_beg = chunk * rows_per_chunk;
+  const int r_end = min(HW, r_beg + rows_per_chunk);
+  const int nslot = (nvec + 255) / 256;  // 1 or 2
+  for (int slot = 0; slot < nslot; ++slot) {
+    const int v = v0 + slot * 256;
+    float sm[8], sq[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) sm[e] = sq[e] = 0.f;
+    if (rt < RT && v < nvec) {
+      for (int r = r_beg + rt; r < r_end; r += RT) {
+        Pack16 p;
+        p.u = gn_load(s, (long)b * HW + r, v);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float x = (float)p.e[e];
+          sm[e] += x;
+          sq[e] += x * x;
+        }
+      }
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      red[tid * 16 + e] = sm[e];
+      red[tid * 16 + 8 + e] = sq[e];
+    }
+    __syncthreads();
+    if (rt == 0 && v < nvec) {
+      for (int e = 0; e < 8; ++e) {
+        float a = 0.f, q = 0.f;
+        for (int k = 0; k < RT; ++k) {
+          a += red[(k * VT + v0) * 16 + e];
+          q += red[(k * VT + v0) * 16 + 8 + e];
+        }
+        chan[(v * 8 + e) * 2] = a;
+        chan[(v * 8 + e) * 2 + 1] = q;
+      }
+    }
+    __syncthreads();
+  }
+  const int cpg = C / G;
+  if (tid < G) {
+    float a = 0.f, q = 0.f;
+    for (int c = tid * cpg; c < (tid + 1) * cpg; ++c) {
+      a += chan[c * 2];
+      q += chan[c * 2 + 1];
+    }
+    float* out = partial + (((long)b * gridDim.x + chunk) * G + tid) * 2;
+    out[0] = a;
+    out[1] = q;
+  }
+}
+
+__global__ void gn_finalize_kernel(const float* __restrict__ partial, int nchunks, int G, float count,
+                                   float eps, float* __restrict__ stats) {
+  const int b = blockIdx.x, g = threadIdx.x;
+  if (g >= G) return;
+  float a = 0.f, q = 0.f;
+  for (int k = 0; k < nchunks; ++k) {
+    const float* p = partial + (((long)b * nchunks + k) * G + g) * 2;
+    a += p[0];
+    q += p[1];
+  }
+  const float mean = a / count;
+  const float var = fmaxf(q / count - mean * mean, 0.f);
+  stats[((long)b * G + g) * 2] = mean;
+  stats[((long)b * G + g) * 2 + 1] = rsqrtf(var + eps);
+}
+
+__global__ __launch_bounds__(256) void gn_apply_kernel(GnSrc s, const half_t* __restrict__ gamma,
+                                                       const half_t* __restrict__ beta,
+                                                       const float* __restrict__ stats, half_t* __restrict__ y,
+                                                       long ldy, int HW, int G, int rows_per_chunk, int act) {
+  __shared__ float sc[4096], sh[4096];
+  const int C = s.C1 + s.C2;
+  const int nvec = C / 8;
+  const int cpg = C / G;
+  const int b = blockIdx.y, chunk = blockIdx.x, tid = threadIdx.x;
+  for (int c = tid; c < C; c += 256) {
+    const int g = c / cpg;
+    const float mean = stats[((long)b * G + g) * 2];
+    const float rstd = stats[((long)b * G + g) * 2 + 1];
+    const float w = rstd * (float)gamma[c];
+    sc[c] = w;
+    sh[c] = (float)beta[c] - mean * w;
+  }
+  __syncthreads();
+  const int VT = nvec < 256 ? nvec : 256;
+  const int RT = 256 / VT;
+  const int v0 = tid % VT, rt = tid / VT;
+  if (rt >= RT) return;
+  const int r_beg = chunk * rows_per_chunk;
+  const int r_end = min(HW, r_beg + rows_per_chunk);
+  for (int v = v0; v < nvec; v += 256) {
+    float w[8], o[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      w[e] = sc[v * 8 + e];
+      o[e] = sh[v * 8 + e];
+    }
+    for (int r = r_beg + rt; r < r_end; r += RT) {
+      const long row = (long)b * HW + r;
+      Pack16 p, q;
+      p.u = gn_load(s, row, v);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        float t = (float)p.e[e] * w[e] + o[e];
+        if (act == PFD_ACT_SILU) t = pfd_silu(t);
+        q.e[e] = (half_t)t;
+      }
+      *reinterpret_cast<uint4*>(y + row * ldy + v * 8) = q.u;
+    }
+  }
+}
+
+// ---- LayerNorm: one wave per row, the row lives in registers (<= 8 vecs of 8 per lane) ----
+constexpr int LN_MAXV = 8;
+
+__global__ __launch_bounds__(256) void layernorm_kernel(const half_t* __restrict__ x, long ldx,
+                                                        const half_t* __restrict__ gamma,
+                                                        const half_t* __restrict__ beta, half_t* __restrict__ y,
+                                                        long ldy, int M, int C, float eps, int gather4, int B,
+                                                        int H, int W) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= M) return;
+  const int nvec = C / 8;
+  int gb = 0, gy = 0, gx = 0, Cq = 0;
+  if (gather4) {
+    const int Ho = (H + 1) / 2, Wo = (W + 1) / 2;
+    gb = row / (Ho * Wo);
+    const int rem = row - gb * Ho * Wo;
+    gy = rem / Wo;
+    gx = rem - gy * Wo;
+    Cq = C / 4;
+  }
+  float vals[LN_MAXV][8];
+  float sum = 0.f;
+#pragma unroll
+  for (int k = 0; k < LN_MAXV; ++k) {
+    const int v = lane + 64 * k;
+    Pack16 p;
+    p.u = make_uint4(0, 0, 0, 0);
+    if (v < nvec) {
+      if (gather4) {
+        const int c = v * 8;
+        const int part = c / Cq;
+        const int iy = 2 * gy + (part & 1), ix = 2 * gx + (part >> 1);
+        if (iy < H && ix < W)
+          p.u = *reinterpret_cast<const uint4*>(x + (((long)gb * H + iy) * W + ix) * ldx + (c - part * Cq));
+      } else {
+        p.u = *reinterpret_cast<const uint4*>(x + (long)row * ldx + v * 8);
+      }
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      vals[k][e] = (float)p.e[e];
+      sum += vals[k][e];
+    }
+  }
+  const float mean = wave_sum(sum) / (float)C;
+  float sq = 0.f;
+#pragma unroll
+  for (int k = 0; k < LN_MAXV; ++k) {
+    if (lane + 64 * k < nvec) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float d = vals[k][e] - mean;
+        sq += d * d;
+      }
+    }
+  }
+  const float rstd = rsqrtf(wave_sum(sq) / (float)C + eps);
+#pragma unroll
+  for (int k = 0; k < LN_MAXV; ++k) {
+    const int v = lane + 64 * k;
+    if (v < nvec) {
+      Pack16 g, bt, o;
+      g.u = *reinterpret_cast<const uint4*>(gamma + v * 8);
+      bt.u = *reinterpret_cast<const uint4*>(beta + v * 8);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) o.e[e] = (half_t)((vals[k][e] - mean) * rstd * (float)g.e[e] + (float)bt.e[e]);
+      *reinterpret_cast<uint4*>(y + (long)row * ldy + v * 8) = o.u;
+    }
+  }
+}
+
+// ---- scaled row softmax: one block per row ----
+constexpr int SM_MAXV = 8;  // N <= 256*8*8 = 16384
+
+__global__ __launch_bounds__(256) void softmax_rows_kernel(const half_t* __restrict__ x, long ldx,
+                                                           half_t* __restrict__ y, long ldy, int N, float scale) {
+  __shared__ float red[8];
+  const int row = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int nvec = N / 8;
+  float vals[SM_MAXV][8];
+  float mx = -INFINITY;
+#pragma unroll
+  for (int k = 0; k < SM_MAXV; ++k) {
+    const int v = tid + 256 * k;
+    if (v < nvec) {
+      Pack16 p;
+      p.u = *reinterpret_cast<const uint4*>(x + (long)row * ldx + v * 8);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        vals[k][e] = (float)p.e[e] * scale;
+        mx = fmaxf(mx, vals[k][e]);
+      }
+    }
+  }
+  mx = wave_max(mx);
+  if (lane == 0) red[wave] = mx;
+  __syncthreads();
+  mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  float sum = 0.f;
+#pragma unroll
+  for (int k = 0; k < SM_MAXV; ++k) {
+    if (tid + 256 * k < nvec) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        vals[k][e] = __expf(vals[k][e] - mx);
+        sum += vals[k][e];
+      }
+    }
+  }
+  sum = wave_sum(sum);
+  if (lane == 0) red[4 + wave] = sum;
+  __syncthreads();
+  const float inv = 1.f / (red[4] + red[5] + red[6] + red[7]);
+#pragma unroll
+  for (int k = 0; k < SM_MAXV; ++k) {
+    const int v = tid + 256 * k;
+    if (v < nvec) {
+      Pack16 o;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) o.e[e] = (half_t)(vals[k][e] * inv);
+      *reinterpret_cast<uint4*>(y + (long)row * ldy + v * 8) = o.u;
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" size_t pfd_groupnorm_ws_bytes(int32_t B, int32_t C, int32_t HW) {
+  (void)C;
+  (void)HW;
+  return (size_t)B * (GN_MAX_CHUNKS + 1) * GN_MAX_G * 2 * sizeof(float);
+}
+
+extern "C" int pfd_groupnorm_f16(const void* x1, int32_t C1, int64_t ldx1, const void* x2, int32_t C2,
+                                 int64_t ldx2, const void* gamma, const void* beta, void* y, int64_t ldy,
+                                 int32_t B, int32_t HW, int32_t G, float eps, int32_t act, void* ws,
+                                 size_t ws_bytes, pfd_stream_t stream) {
+  if (!x1 || !gamma || !beta || !y || !ws) return PFD_EINVAL;
+  if (C2 > 0 && !x2) return PFD_EINVAL;
+  if (C2 < 0 || C1 <= 0 || B <= 0 || HW <= 0 || G <= 0 || G > GN_MAX_G) return PFD_EINVAL;
+  const int C = C1 + C2;
+  if ((C1 & 7) || (C2 & 7) || (C % G) || C > 4096) return PFD_ESHAPE;
+  if ((ldx1 & 7) || (ldx2 & 7) || (ldy & 7)) return PFD_EINVAL;
+  if (act != PFD_ACT_NONE && act != PFD_ACT_SILU) return PFD_EINVAL;
+  if (ws_bytes < pfd_groupnorm_ws_bytes(B, C, HW)) return PFD_EINVAL;
+  hipStream_t s = (hipStream_t)stream;
+  GnSrc src{(const half_t*)x1, (const half_t*)x2, ldx1, ldx2, C1, C2};
+  const int nvec = C / 8;
+  const int RT = nvec < 256 ? 256 / nvec : 1;
+  // aim for ~1024 blocks over the chip, at least 4 row sweeps per block
+  int nchunks = (1024 + B - 1) / B;
+  const int max_by_rows = (HW + RT * 4 - 1) / (RT * 4);
+  if (nchunks > max_by_rows) nchunks = max_by_rows;
+  if (nchunks > GN_MAX_CHUNKS) nchunks = GN_MAX_CHUNKS;
+  if (nchunks < 1) nchunks = 1;
+  const int rpc = (HW + nchunks - 1) / nchunks;
+  nchunks = (HW + rpc - 1) / rpc;
+  float* partial = (float*)ws;
+  float* stats = partial + (size_t)B * GN_MAX_CHUNKS * GN_MAX_G * 2;
+  hipLaunchKernelGGL(gn_stats_kernel, dim3(nchunks, B), dim3(256), 0, s, src, HW, G, rpc, partial);
+  hipLaunchKernelGGL(gn_finalize_kernel, dim3(B), dim3(64), 0, s, partial, nchunks, G,
+                     (float)HW * (float)(C / G), eps, stats);
+  hipLaunchKernelGGL(gn_apply_kernel, dim3(nchunks, B), dim3(256), 0, s, src, (const half_t*)gamma,
+                     (const half_t*)beta, stats, (half_t*)y, (long)ldy, HW, G, rpc, act);
+  return pfd_check_launch("pfd_groupnorm_f16");
+}
+
+extern "C" int pfd_layernorm_f16(const void* x, int64_t ldx, const void* gamma, const void* beta, void* y,
+                                 int64_t ldy, int32_t M, int32_t C, float eps, int32_t gather4, int32_t B,
+                                 int32_t H, int32_t W, pfd_stream_t stream) {
+  if (!x || !gamma || !beta || !y || M <= 0 || C <= 0) return PFD_EINVAL;
+  if ((C & 7) || C > 64 * 8 * LN_MAXV) return PFD_ESHAPE;
+  if ((ldx & 7) || (ldy & 7)) return PFD_EINVAL;
+  if (gather4) {
+    if ((C % 32) || B <= 0 || H <= 0 || W <= 0) return PFD_EINVAL;
+    if ((long)B * ((H + 1) / 2) * ((W + 1) / 2) != M) return PFD_EINVAL;
+  }
+  hipLaunchKernelGGL(layernorm_kernel, dim3((M + 3) / 4), dim3(256), 0, (hipStream_t)stream,
+                     (const half_t*)x, (long)ldx, (const half_t*)gamma, (const half_t*)beta, (half_t*)y,
+                     (long)ldy, M, C, eps, gather4, B, H, W);
+  return pfd_check_launch("pfd_layernorm_f16");
+}
+
+extern "C" int pfd_softmax_rows_f16(const void* x, int64_t ldx, void* y, int64_t ldy, int32_t R, int32_t N,
+                                    float scale, pfd_stream_t stream) {
+  if (!x || !y || R <= 0 || N <= 0) return PFD_EINVAL;
+  if ((N & 7) || N > 256 * 8 * SM_MAXV) return PFD_ESHAPE;
+  if ((ldx & 7) || (ldy & 7)) return PFD_EINVAL;
+  hipLaunchKernelGGL(softmax_rows_kernel, dim3(R), dim3(256), 0, (hipStream_t)stream, (const half_t*)x,
+                     (long)ldx, (half_t*)y, (long)ldy, N, scale);
+  return pfd_check_launch("pfd_softmax_rows_f16");
+}

@@ -1,0 +1,649 @@
+// Torch-free self test + micro benchmark of libpfd_hip.so (runs in seconds on a GPU box).
+// Every kernel is checked against a straightforward fp64/fp32 CPU loop over the SAME fp16
+// inputs.  This is test infrastructure: nothing here is linked into the product library.
+//   build/selftest            -> correctness (exit code = number of failed cases)
+//   build/selftest --bench    -> also time the UNet-shaped problems and print TFLOP/s
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <algorithm>
+#include <functional>
+#include <random>
+#include <string>
+#include <vector>
+
+#include "pfd_hip.h"
+
+typedef _Float16 h16;
+
+#define HIP_OK(x)                                                                 \
+  do {                                                                            \
+    hipError_t e_ = (x);                                                          \
+    if (e_ != hipSuccess) {                                                       \
+      fprintf(stderr, "HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); \
+      exit(99);                                                                   \
+    }                                                                             \
+  } while (0)
+
+static std::mt19937 rng(1234);
+static int g_fail = 0, g_total = 0;
+
+static std::vector<h16> rand_h(size_t n, float scale = 1.f) {
+  std::uniform_real_distribution<float> d(-1.f, 1.f);
+  std::vector<h16> v(n);
+  for (auto& x : v) x = (h16)(d(rng) * scale);
+  return v;
+}
+static std::vector<float> rand_f(size_t n, float scale = 1.f) {
+  std::uniform_real_distribution<float> d(-1.f, 1.f);
+  std::vector<float> v(n);
+  for (auto& x : v) x = d(rng) * scale;
+  return v;
+}
+template <class T>
+struct Dev {
+  T* p = nullptr;
+  size_t n = 0;
+  Dev() {}
+  explicit Dev(size_t n_) : n(n_) { HIP_OK(hipMalloc(&p, std::max<size_t>(n, 1) * sizeof(T))); HIP_OK(hipMemset(p, 0, std::max<size_t>(n,1) * sizeof(T))); }
+  explicit Dev(const std::vector<T>& h) : n(h.size()) {
+    HIP_OK(hipMalloc(&p, std::max<size_t>(n, 1) * sizeof(T)));
+    HIP_OK(hipMemcpy(p, h.data(), n * sizeof(T), hipMemcpyHostToDevice));
+  }
+  ~Dev() { if (p) hipFree(p); }
+  std::vector<T> get() const {
+    std::vector<T> h(n);
+    HIP_OK(hipDeviceSynchronize());
+    HIP_OK(hipMemcpy(h.data(), p, n * sizeof(T), hipMemcpyDeviceToHost));
+    return h;
+  }
+  Dev(const Dev&) = delete;
+  Dev& operator=(const Dev&) = delete;
+};
+
+template <class T>
+static void report(const std::string& name, const std::vector<T>& got, const std::vector<double>& ref,
+                   double atol, double rtol) {
+  double worst = 0, maxabs = 0;
+  size_t bad = 0, worst_i = 0;
+  for (size_t i = 0; i < ref.size(); ++i) {
+    const double g = (double)got[i];
+    const double d = fabs(g - ref[i]);
+    const double lim = atol + rtol * fabs(ref[i]);
+    if (!(d <= lim) || !std::isfinite(g)) ++bad;
+    if (d / lim > worst || !std::isfinite(g)) { worst = std::isfinite(g) ? d / lim : 1e30; worst_i = i; }
+    maxabs = std::max(maxabs, d);
+  }
+  ++g_total;
+  if (bad) {
+    ++g_fail;
+    printf("FAIL %-58s bad=%zu/%zu max|d|=%.4g worst@%zu got=%.5g ref=%.5g\n", name.c_str(), bad, ref.size(),
+           maxabs, worst_i, (double)got[worst_i], ref[worst_i]);
+  } else {
+    printf("ok   %-58s max|d|=%.3g\n", name.c_str(), maxabs);
+  }
+  fflush(stdout);
+}
+
+static double act_ref(double v, int act) {
+  switch (act) {
+    case PFD_ACT_GELU: return 0.5 * v * (1.0 + erf(v / sqrt(2.0)));
+    case PFD_ACT_RELU: return v > 0 ? v : 0;
+    case PFD_ACT_SILU: return v / (1.0 + exp(-v));
+    default: return v;
+  }
+}
+
+
+
+// ------------------------------------------------------------------ GEMM / conv
+struct GemmCase {
+  int M, N, K;
+  int act = 0;
+  bool bias = true, res = false, rowvec = false, bias_row = false;
+  int tile = 0;
+  int extra_ld = 0;  // added to every leading dimension
+  int ksize = 0, stride = 1, pad = 0, ups = 0, B = 0, H = 0, W = 0, Cin = 0;
+};
+
+static void run_gemm_case(const GemmCase& c) {
+  const bool conv = c.ksize > 0;
+  int M = c.M, K = c.K, Ho = 0, Wo = 0;
+  if (conv) {
+    const int Hin = c.ups ? 2 * c.H : c.H, Win = c.ups ? 2 * c.W : c.W;
+    Ho = (Hin + 2 * c.pad - c.ksize) / c.stride + 1;
+    Wo = (Win + 2 * c.pad - c.ksize) / c.stride + 1;
+    M = c.B * Ho * Wo;
+    K = c.ksize * c.ksize * c.Cin;
+  }
+  const int N = c.N;
+  const long lda = (conv ? c.Cin : K) + c.extra_ld, ldw = K + c.extra_ld;
+  const int Nout = c.act == PFD_ACT_GEGLU ? N / 2 : N;
+  const long ldc = Nout + c.extra_ld, ldr = Nout + c.extra_ld, ldrv = N + c.extra_ld;
+  const long a_rows = conv ? (long)c.B * c.H * c.W : M;
+  const float ws = 1.0f / sqrtf((float)K);
+  auto A = rand_h(a_rows * lda), W = rand_h((size_t)N * ldw, ws * 1.7f);
+  auto bias = rand_h(c.bias_row ? M : N, 0.5f);
+  const int rows_per_rv = conv ? Ho * Wo : 64;
+  const int n_rv = (M + rows_per_rv - 1) / rows_per_rv;
+  auto rv = rand_h((size_t)n_rv * ldrv, 0.5f);
+  auto R = rand_h((size_t)M * ldr, 1.0f);
+  Dev<h16> dA(A), dW(W), dB(bias), dRV(rv), dR(R), dC((size_t)M * ldc);
+  PfdGemmDesc d;
+  memset(&d, 0, sizeof(d));
+  d.A = dA.p; d.W = dW.p; d.bias = c.bias ? dB.p : nullptr; d.rowvec = c.rowvec ? dRV.p : nullptr;
+  d.R = c.res ? dR.p : nullptr; d.C = dC.p;
+  d.lda = lda; d.ldw = ldw; d.ldr = ldr; d.ldc = ldc; d.ldrv = ldrv;
+  d.M = M; d.N = N; d.K = K; d.rows_per_rv = rows_per_rv; d.act = c.act; d.bias_per_row = c.bias_row;
+  d.ksize = c.ksize; d.stride = c.stride; d.pad = c.pad; d.ups = c.ups;
+  d.B = c.B; d.H = c.H; d.Wd = c.W; d.Cin = c.Cin; d.Ho = Ho; d.Wo = Wo;
+  const int rc = pfd_gemm_f16_ex(&d, c.tile, nullptr);
+  char name[256];
+  snprintf(name, sizeof(name), "gemm M%d N%d K%d act%d b%d r%d rv%d br%d tile%d ld+%d %s", M, N, K, c.act,
+           c.bias, c.res, c.rowvec, c.bias_row, c.tile, c.extra_ld,
+           conv ? (std::string("conv k") + std::to_string(c.ksize) + " s" + std::to_string(c.stride) + " p" +
+                   std::to_string(c.pad) + " u" + std::to_string(c.ups))
+                      .c_str()
+                : "");
+  if (rc != 0) {
+    ++g_total; ++g_fail;
+    printf("FAIL %-58s rc=%d (%s)\n", name, rc, pfd_last_error());
+    return;
+  }
+  auto got = dC.get();
+  // CPU reference
+  std::vector<double> pre((size_t)M * N);
+  for (int m = 0; m < M; ++m) {
+    int b = 0, oy = 0, ox = 0;
+    if (conv) { b = m / (Ho * Wo); oy = (m % (Ho * Wo)) / Wo; ox = m % Wo; }
+    for (int n = 0; n < N; ++n) {
+      double s = 0;
+      if (!conv) {
+        for (int k = 0; k < K; ++k) s += (double)A[m * lda + k] * (double)W[n * ldw + k];
+      } else {
+        const int Hin = c.ups ? 2 * c.H : c.H, Win = c.ups ? 2 * c.W : c.W;
+        for (int ky = 0; ky < c.ksize; ++ky)
+          for (int kx = 0; kx < c.ksize; ++kx) {
+            int iy = oy * c.stride + ky - c.pad, ix = ox * c.stride + kx - c.pad;
+            if (iy < 0 || iy >= Hin || ix < 0 || ix >= Win) continue;
+            if (c.ups) { iy /= 2; ix /= 2; }
+            const h16* ap = &A[(((long)b * c.H + iy) * c.W + ix) * lda];
+            const h16* wp = &W[n * ldw + (ky * c.ksize + kx) * c.Cin];
+            for (int ci = 0; ci < c.Cin; ++ci) s += (double)ap[ci] * (double)wp[ci];
+          }
+      }
+      if (c.bias) s += (double)bias[c.bias_row ? m : n];
+      if (c.rowvec) s += (double)rv[(m / rows_per_rv) * ldrv + n];
+      pre[(size_t)m * N + n] = s;
+    }
+  }
+  std::vector<double> ref((size_t)M * ldc, 0.0);
+  std::vector<h16> gotc((size_t)M * ldc, (h16)0);
+  for (int m = 0; m < M; ++m)
+    for (int n = 0; n < Nout; ++n) {
+      double v;
+      if (c.act == PFD_ACT_GEGLU) {
+        const int blk = n / 32, j = n % 32;
+        const double x = pre[(size_t)m * N + blk * 64 + j], g = pre[(size_t)m * N + blk * 64 + 32 + j];
+        v = x * act_ref(g, PFD_ACT_GELU);
+      } else {
+        v = act_ref(pre[(size_t)m * N + n], c.act);
+      }
+      if (c.res) v += (double)R[m * ldr + n];
+      ref[(size_t)m * ldc + n] = v;
+      gotc[(size_t)m * ldc + n] = got[(size_t)m * ldc + n];
+    }
+  // the pad columns (ld+extra) must stay untouched (zero)
+  for (int m = 0; m < M; ++m)
+    for (long n = Nout; n < ldc; ++n) gotc[(size_t)m * ldc + n] = got[(size_t)m * ldc + n];
+  report(name, gotc, ref, 4e-3, 3e-3);
+}
+
+// ------------------------------------------------------------------ attention
+static void run_attn_case(int B, int H, int Nq, int Nk, int D, bool fused_layout) {
+  const int C = H * D;
+  const float scale = 1.0f / sqrtf((float)D);
+  // fused_layout: Q and K are column slices of one [B*N, 2C] matrix (self-attention producer layout)
+  const long ldq = fused_layout ? 2 * C : C, ldk = ldq, ldo = C;
+  const int Nkp = (Nk + 7) / 8 * 8;
+  const long ldvt = (long)B * Nkp;
+  auto Qh = rand_h((size_t)B * Nq * ldq, 1.5f), Kh = rand_h((size_t)B * Nk * ldk, 1.5f), Vt = rand_h((size_t)C * ldvt, 1.0f);
+  Dev<h16> dQ(Qh), dK(Kh), dV(Vt), dO((size_t)B * Nq * ldo);
+  PfdAttnDesc d;
+  memset(&d, 0, sizeof(d));
+  d.Q = dQ.p; d.K = fused_layout ? dK.p + C : dK.p; d.Vt = dV.p; d.O = dO.p;
+  d.ldq = ldq; d.ldk = ldk; d.ldvt = ldvt; d.ldo = ldo;
+  d.q_bs = (long)Nq * ldq; d.k_bs = (long)Nk * ldk; d.vt_bs = Nkp; d.o_bs = (long)Nq * ldo;
+  d.B = B; d.H = H; d.Nq = Nq; d.Nk = Nk; d.D = D; d.scale = scale;
+  const int rc = pfd_attention_f16(&d, nullptr);
+  char name[128];
+  snprintf(name, sizeof(name), "attention B%d H%d Nq%d Nk%d D%d fused%d", B, H, Nq, Nk, D, (int)fused_layout);
+  if (rc != 0) { ++g_total; ++g_fail; printf("FAIL %-58s rc=%d (%s)\n", name, rc, pfd_last_error()); return; }
+  auto got = dO.get();
+  std::vector<double> ref(got.size(), 0.0);
+  const int koff = fused_layout ? C : 0;
+  std::vector<double> s(Nk);
+  for (int b = 0; b < B; ++b)
+    for (int h = 0; h < H; ++h)
+      for (int i = 0; i < Nq; ++i) {
+        double mx = -1e300;
+        for (int j = 0; j < Nk; ++j) {
+          double a = 0;
+          for (int e = 0; e < D; ++e)
+            a += (double)Qh[(size_t)b * Nq * ldq + i * ldq + h * D + e] * (double)Kh[(size_t)b * Nk * ldk + j * ldk + koff + h * D + e];
+          s[j] = a * scale;
+          mx = std::max(mx, s[j]);
+        }
+        double sum = 0;
+        for (int j = 0; j < Nk; ++j) { s[j] = exp(s[j] - mx); sum += s[j]; }
+        for (int e = 0; e < D; ++e) {
+          double o = 0;
+          for (int j = 0; j < Nk; ++j) o += s[j] * (double)Vt[(size_t)(h * D + e) * ldvt + b * Nkp + j];
+          ref[(size_t)b * Nq * ldo + i * ldo + h * D + e] = o / sum;
+        }
+      }
+  report(name, got, ref, 3e-3, 5e-3);
+}
+
+// ------------------------------------------------------------------ swin window attention
+static void run_swin_case(int B, int H, int W, int nH, int shift) {
+  const int C = nH * 32, ws = 12, NT = 144;
+  const float scale = 1.0f / sqrtf(32.f);
+  auto qkv = rand_h((size_t)B * H * W * 3 * C, 1.5f), qb = rand_h(3 * C, 0.5f), rpb = rand_h(529 * nH, 1.0f);
+  Dev<h16> dq(qkv), db(qb), dr(rpb), dout((size_t)B * H * W * C);
+  PfdSwinAttnDesc d;
+  memset(&d, 0, sizeof(d));
+  d.qkv = dq.p; d.qkv_bias = db.p; d.rpb = dr.p; d.out = dout.p;
+  d.B = B; d.H = H; d.W = W; d.C = C; d.nH = nH; d.ws = ws; d.shift = shift; d.scale = scale;
+  const int rc = pfd_swin_window_attention_f16(&d, nullptr);
+  char name[128];
+  snprintf(name, sizeof(name), "swin_attn B%d H%d W%d nH%d shift%d", B, H, W, nH, shift);
+  if (rc != 0) { ++g_total; ++g_fail; printf("FAIL %-58s rc=%d (%s)\n", name, rc, pfd_last_error()); return; }
+  auto got = dout.get();
+  std::vector<double> ref(got.size(), 0.0);
+  const int Hp = (H + ws - 1) / ws * ws, Wp = (W + ws - 1) / ws * ws;
+  // reference algorithm, literally: pad -> roll(-shift) -> partition -> attention -> reverse -> roll(+shift) -> crop
+  auto src = [&](int b, int y, int x, int col) -> double {  // padded qkv
+    if (y < H && x < W) return (double)qkv[((size_t)(b * H + y) * W + x) * 3 * C + col];
+    return (double)qb[col];
+  };
+  std::vector<int> img_mask((size_t)Hp * Wp, 0);
+  if (shift > 0) {
+    int hs[4] = {0, Hp - ws, Hp - shift, Hp}, wsl[4] = {0, Wp - ws, Wp - shift, Wp}, cnt = 0;
+    for (int a = 0; a < 3; ++a)
+      for (int c2 = 0; c2 < 3; ++c2) {
+        for (int y = hs[a]; y < hs[a + 1]; ++y)
+          for (int x = wsl[c2]; x < wsl[c2 + 1]; ++x) img_mask[(size_t)y * Wp + x] = cnt;
+        ++cnt;
+      }
+  }
+  std::vector<double> sc(NT);
+  for (int b = 0; b < B; ++b)
+    for (int wy = 0; wy < Hp / ws; ++wy)
+      for (int wx = 0; wx < Wp / ws; ++wx)
+        for (int h = 0; h < nH; ++h)
+          for (int i = 0; i < NT; ++i) {
+            const int iy = i / ws, ix = i % ws;
+            const int piy = wy * ws + iy, pix = wx * ws + ix;           // rolled frame
+            const int oy = (piy + shift) % Hp, ox = (pix + shift) % Wp;  // original padded frame
+            double mx = -1e300;
+            for (int j = 0; j < NT; ++j) {
+              const int jy = j / ws, jx = j % ws;
+              const int pjy = wy * ws + jy, pjx = wx * ws + jx;
+              const int ky = (pjy + shift) % Hp, kx = (pjx + shift) % Wp;
+              double a = 0;
+              for (int e = 0; e < 32; ++e)
+                a += src(b, oy, ox, h * 32 + e) * scale * src(b, ky, kx, C + h * 32 + e);
+              a += (double)rpb[((iy - jy + ws - 1) * (2 * ws - 1) + (ix - jx + ws - 1)) * nH + h];
+              if (shift > 0 && img_mask[(size_t)piy * Wp + pix] != img_mask[(size_t)pjy * Wp + pjx]) a += -100.0;
+              sc[j] = a;
+              mx = std::max(mx, a);
+            }
+            double sum = 0;
+            for (int j = 0; j < NT; ++j) { sc[j] = exp(sc[j] - mx); sum += sc[j]; }
+            if (oy < H && ox < W)
+              for (int e = 0; e < 32; ++e) {
+                double o = 0;
+                for (int j = 0; j < NT; ++j) {
+                  const int jy = j / ws, jx = j % ws;
+                  const int ky = (wy * ws + jy + shift) % Hp, kx = (wx * ws + jx + shift) % Wp;
+                  o += sc[j] * src(b, ky, kx, 2 * C + h * 32 + e);
+                }
+                ref[((size_t)(b * H + oy) * W + ox) * C + h * 32 + e] = o / sum;
+              }
+          }
+  report(name, got, ref, 3e-3, 5e-3);
+}
+
+// ------------------------------------------------------------------ norms
+static void run_gn_case(int B, int HW, int C1, int C2, int G, int act, float eps) {
+  const int C = C1 + C2;
+  auto x1 = rand_h((size_t)B * HW * C1, 2.f), x2 = rand_h((size_t)B * HW * std::max(C2, 8), 1.f);
+  for (auto& v : x1) v = (h16)((float)v + 0.7f);
+  auto gm = rand_h(C, 1.f), bt = rand_h(C, 0.5f);
+  Dev<h16> d1(x1), d2(x2), dg(gm), db(bt), dy((size_t)B * HW * C);
+  const size_t wsb = pfd_groupnorm_ws_bytes(B, C, HW);
+  Dev<char> dws(wsb);
+  const int rc = pfd_groupnorm_f16(d1.p, C1, C1, C2 ? d2.p : nullptr, C2, C2, dg.p, db.p, dy.p, C, B, HW, G, eps, act,
+                                   dws.p, wsb, nullptr);
+  char name[128];
+  snprintf(name, sizeof(name), "groupnorm B%d HW%d C%d+%d G%d act%d", B, HW, C1, C2, G, act);
+  if (rc != 0) { ++g_total; ++g_fail; printf("FAIL %-58s rc=%d (%s)\n", name, rc, pfd_last_error()); return; }
+  auto got = dy.get();
+  std::vector<double> ref(got.size());
+  const int cpg = C / G;
+  auto X = [&](int b, int p, int c) -> double {
+    return c < C1 ? (double)x1[((size_t)b * HW + p) * C1 + c] : (double)x2[((size_t)b * HW + p) * C2 + (c - C1)];
+  };
+  for (int b = 0; b < B; ++b)
+    for (int g = 0; g < G; ++g) {
+      double s = 0, q = 0;
+      for (int p = 0; p < HW; ++p)
+        for (int c = g * cpg; c < (g + 1) * cpg; ++c) { const double v = X(b, p, c); s += v; q += v * v; }
+      const double n = (double)HW * cpg, mean = s / n, var = q / n - mean * mean, rstd = 1.0 / sqrt(var + eps);
+      for (int p = 0; p < HW; ++p)
+        for (int c = g * cpg; c < (g + 1) * cpg; ++c) {
+          double v = (X(b, p, c) - mean) * rstd * (double)gm[c] + (double)bt[c];
+          ref[((size_t)b * HW + p) * C + c] = act_ref(v, act);
+        }
+    }
+  report(name, got, ref, 4e-3, 3e-3);
+}
+
+static void run_ln_case(int M, int C, int gather4, int B, int H, int W) {
+  const int Cq = C / 4;
+  auto x = rand_h(gather4 ? (size_t)B * H * W * Cq : (size_t)M * C, 2.f);
+  for (auto& v : x) v = (h16)((float)v - 0.4f);
+  auto gm = rand_h(C, 1.f), bt = rand_h(C, 0.5f);
+  Dev<h16> dx(x), dg(gm), db(bt), dy((size_t)M * C);
+  const int rc = pfd_layernorm_f16(dx.p, gather4 ? Cq : C, dg.p, db.p, dy.p, C, M, C, 1e-5f, gather4, B, H, W, nullptr);
+  char name[128];
+  snprintf(name, sizeof(name), "layernorm M%d C%d gather%d", M, C, gather4);
+  if (rc != 0) { ++g_total; ++g_fail; printf("FAIL %-58s rc=%d (%s)\n", name, rc, pfd_last_error()); return; }
+  auto got = dy.get();
+  std::vector<double> ref(got.size());
+  const int Ho = (H + 1) / 2, Wo = (W + 1) / 2;
+  for (int m = 0; m < M; ++m) {
+    std::vector<double> row(C);
+    for (int c = 0; c < C; ++c) {
+      if (!gather4) row[c] = (double)x[(size_t)m * C + c];
+      else {
+        const int b = m / (Ho * Wo), oy = (m % (Ho * Wo)) / Wo, ox = m % Wo, part = c / Cq;
+        const int iy = 2 * oy + (part & 1), ix = 2 * ox + (part >> 1);
+        row[c] = (iy < H && ix < W) ? (double)x[(((size_t)b * H + iy) * W + ix) * Cq + c % Cq] : 0.0;
+      }
+    }
+    double s = 0; for (double v : row) s += v;
+    const double mean = s / C;
+    double q = 0; for (double v : row) q += (v - mean) * (v - mean);
+    const double rstd = 1.0 / sqrt(q / C + 1e-5);
+    for (int c = 0; c < C; ++c) ref[(size_t)m * C + c] = (row[c] - mean) * rstd * (double)gm[c] + (double)bt[c];
+  }
+  report(name, got, ref, 4e-3, 3e-3);
+}
+
+static void run_softmax_case(int R, int N, float scale) {
+  auto x = rand_h((size_t)R * N, 8.f);
+  Dev<h16> dx(x), dy((size_t)R * N);
+  const int rc = pfd_softmax_rows_f16(dx.p, N, dy.p, N, R, N, scale, nullptr);
+  char name[128];
+  snprintf(name, sizeof(name), "softmax_rows R%d N%d", R, N);
+  if (rc != 0) { ++g_total; ++g_fail; printf("FAIL %-58s rc=%d\n", name, rc); return; }
+  auto got = dy.get();
+  std::vector<double> ref(got.size());
+  for (int r = 0; r < R; ++r) {
+    double mx = -1e300, s = 0;
+    for (int j = 0; j < N; ++j) mx = std::max(mx, (double)x[(size_t)r * N + j] * scale);
+    for (int j = 0; j < N; ++j) s += exp((double)x[(size_t)r * N + j] * scale - mx);
+    for (int j = 0; j < N; ++j) ref[(size_t)r * N + j] = exp((double)x[(size_t)r * N + j] * scale - mx) / s;
+  }
+  report(name, got, ref, 1e-4, 5e-3);
+}
+
+// ------------------------------------------------------------------ elementwise
+static void run_elementwise() {
+  {  // layout conversions
+    const int B = 2, C = 4, H = 9, W = 7, rep = 2;
+    auto x = rand_f((size_t)B * C * H * W, 3.f);
+    Dev<float> dx(x);
+    Dev<h16> dy((size_t)rep * B * C * H * W);
+    int rc = pfd_nchw_to_nhwc_f16(dx.p, 1, dy.p, B, C, H, W, 0.5f, 0.25f, rep, nullptr);
+    auto got = dy.get();
+    std::vector<double> ref(got.size());
+    for (int r = 0; r < rep; ++r)
+      for (int b = 0; b < B; ++b) for (int c = 0; c < C; ++c) for (int y = 0; y < H; ++y) for (int xx = 0; xx < W; ++xx)
+        ref[(size_t)r * B * C * H * W + (((size_t)b * H + y) * W + xx) * C + c] = x[(((size_t)b * C + c) * H + y) * W + xx] * 0.5 + 0.25;
+    report(std::string("nchw_to_nhwc f32 rep2 rc=") + std::to_string(rc), got, ref, 2e-3, 2e-3);
+    auto xh = rand_h((size_t)B * H * W * 70, 2.f);
+    Dev<h16> dxh(xh);
+    Dev<float> dyf((size_t)B * 70 * H * W);
+    rc = pfd_nhwc_to_nchw(dxh.p, dyf.p, 1, B, 70, H, W, 0.5f, 0.5f, 0.f, 1.f, nullptr);
+    auto gotf = dyf.get();
+    std::vector<double> reff(gotf.size());
+    for (int b = 0; b < B; ++b) for (int c = 0; c < 70; ++c) for (int p = 0; p < H * W; ++p)
+      reff[((size_t)b * 70 + c) * H * W + p] = std::min(1.0, std::max(0.0, (double)xh[((size_t)b * H * W + p) * 70 + c] * 0.5 + 0.5));
+    report(std::string("nhwc_to_nchw f32 clamp rc=") + std::to_string(rc), gotf, reff, 1e-6, 1e-6);
+  }
+  {  // im2col
+    const int B = 2, H = 6, W = 5, Cin = 4, ks = 3, st = 1, pad = 1, Ho = 6, Wo = 5, Kpad = 64;
+    auto x = rand_h((size_t)B * H * W * Cin);
+    Dev<h16> dx(x), dc((size_t)B * Ho * Wo * Kpad);
+    int rc = pfd_im2col_f16(dx.p, Cin, dc.p, B, H, W, Cin, ks, st, pad, Ho, Wo, Kpad, nullptr);
+    auto got = dc.get();
+    std::vector<double> ref(got.size(), 0.0);
+    for (int b = 0; b < B; ++b) for (int oy = 0; oy < Ho; ++oy) for (int ox = 0; ox < Wo; ++ox)
+      for (int ky = 0; ky < ks; ++ky) for (int kx = 0; kx < ks; ++kx) for (int ci = 0; ci < Cin; ++ci) {
+        const int iy = oy * st + ky - pad, ix = ox * st + kx - pad;
+        if (iy < 0 || iy >= H || ix < 0 || ix >= W) continue;
+        ref[(((size_t)b * Ho + oy) * Wo + ox) * Kpad + (ky * ks + kx) * Cin + ci] = (double)x[(((size_t)b * H + iy) * W + ix) * Cin + ci];
+      }
+    report(std::string("im2col k3 rc=") + std::to_string(rc), got, ref, 0, 0);
+  }
+  {  // timestep embedding
+    const int B = 3, dim = 320;
+    std::vector<int64_t> t = {1, 481, 981};
+    Dev<int64_t> dt(t);
+    Dev<h16> de((size_t)B * dim);
+    int rc = pfd_timestep_embedding_f16(dt.p, de.p, B, dim, 10000.f, nullptr);
+    auto got = de.get();
+    std::vector<double> ref(got.size());
+    for (int b = 0; b < B; ++b) for (int j = 0; j < dim; ++j) {
+      const int f = j % 160;
+      const double fr = exp(-log(10000.0) * f / 160.0);
+      ref[b * dim + j] = j < 160 ? cos(t[b] * fr) : sin(t[b] * fr);
+    }
+    report(std::string("timestep_embedding rc=") + std::to_string(rc), got, ref, 2e-3, 1e-3);
+  }
+  {  // cfg + ddim
+    const int B = 2, C = 4, h = 5, w = 6;
+    const size_t n = (size_t)B * C * h * w;
+    auto eps = rand_h(2 * n, 1.5f);
+    auto x = rand_f(n, 2.f), nz = rand_f(n, 1.f);
+    std::vector<float> coef = {0.45f, 0.52f, 0.1f, sqrtf(1 - 0.45f), 2.0f};
+    Dev<h16> de(eps), dxin(2 * n);
+    Dev<float> dx(x), dn(nz), dc(coef), dxp(n), dp0(n);
+    int rc = pfd_cfg_ddim_step(de.p, 2, dx.p, dn.p, dc.p, dxp.p, dp0.p, dxin.p, B, C, h, w, nullptr);
+    auto gxp = dxp.get(), gp0 = dp0.get();
+    auto gxin = dxin.get();
+    std::vector<double> rxp(n), rp0(n), rxin(2 * n);
+    for (int b = 0; b < B; ++b) for (int c = 0; c < C; ++c) for (int y = 0; y < h; ++y) for (int xx = 0; xx < w; ++xx) {
+      const size_t i = (((size_t)b * C + c) * h + y) * w + xx, ei = (((size_t)b * h + y) * w + xx) * C + c;
+      const double eu = (double)eps[ei], ec = (double)eps[n + ei], e = eu + 2.0 * (ec - eu);
+      const double p0 = (x[i] - sqrt(1 - 0.45) * e) / sqrt(0.45);
+      const double xp = sqrt(0.52) * p0 + sqrt(1 - 0.52 - 0.01) * e + 0.1 * nz[i];
+      rxp[i] = xp; rp0[i] = p0; rxin[ei] = xp; rxin[n + ei] = xp;
+    }
+    report(std::string("cfg_ddim x_prev rc=") + std::to_string(rc), gxp, rxp, 2e-5, 2e-5);
+    report("cfg_ddim pred_x0", gp0, rp0, 2e-5, 2e-5);
+    report("cfg_ddim xin_next", gxin, rxin, 3e-3, 2e-3);
+  }
+  {  // add, add_rowvec
+    const long n = 1003;
+    auto a = rand_h(n + 5), b = rand_h(n + 5);
+    Dev<h16> da(a), db(b), dy(n + 5);
+    int rc = pfd_add_f16(da.p, db.p, dy.p, n, nullptr);
+    auto got = dy.get();
+    std::vector<double> ref(n + 5, 0.0);
+    for (long i = 0; i < n; ++i) ref[i] = (double)a[i] + (double)b[i];
+    report(std::string("add_f16 rc=") + std::to_string(rc), got, ref, 1e-3, 1e-3);
+    const int R = 37, C = 96;
+    auto x = rand_h((size_t)R * C), v = rand_h(C);
+    Dev<h16> dx(x), dv(v), dz((size_t)R * C);
+    rc = pfd_add_rowvec_f16(dx.p, C, dv.p, dz.p, C, R, C, nullptr);
+    auto gz = dz.get();
+    std::vector<double> rz(gz.size());
+    for (int r = 0; r < R; ++r) for (int c = 0; c < C; ++c) rz[r * C + c] = (double)x[r * C + c] + (double)v[c];
+    report(std::string("add_rowvec rc=") + std::to_string(rc), gz, rz, 1e-3, 1e-3);
+  }
+}
+
+// ------------------------------------------------------------------ bench
+static float time_ms(const std::function<void()>& f, int iters) {
+  hipEvent_t a, b;
+  HIP_OK(hipEventCreate(&a)); HIP_OK(hipEventCreate(&b));
+  for (int i = 0; i < 3; ++i) f();
+  HIP_OK(hipEventRecord(a, 0));
+  for (int i = 0; i < iters; ++i) f();
+  HIP_OK(hipEventRecord(b, 0));
+  HIP_OK(hipEventSynchronize(b));
+  float ms = 0;
+  HIP_OK(hipEventElapsedTime(&ms, a, b));
+  return ms / iters;
+}
+
+static void bench_gemm(const char* label, int M, int N, int K, int ksize, int B, int H, int Cin, int tile) {
+  const bool conv = ksize > 0;
+  if (conv) { M = B * H * H; K = ksize * ksize * Cin; }
+  auto A = rand_h(conv ? (size_t)B * H * H * Cin : (size_t)M * K), W = rand_h((size_t)N * K, 0.05f), bias = rand_h(N);
+  Dev<h16> dA(A), dW(W), dB(bias), dC((size_t)M * N);
+  PfdGemmDesc d;
+  memset(&d, 0, sizeof(d));
+  d.A = dA.p; d.W = dW.p; d.bias = dB.p; d.C = dC.p;
+  d.lda = conv ? Cin : K; d.ldw = K; d.ldc = N; d.M = M; d.N = N; d.K = K; d.rows_per_rv = 1;
+  d.ksize = ksize; d.stride = 1; d.pad = ksize / 2; d.B = B; d.H = H; d.Wd = H; d.Cin = Cin; d.Ho = H; d.Wo = H;
+  int rc = 0;
+  const float ms = time_ms([&] { rc |= pfd_gemm_f16_ex(&d, tile, nullptr); }, 20);
+  const double tf = 2.0 * M * N * K / (ms * 1e-3) / 1e12;
+  printf("bench %-34s M%-6d N%-5d K%-6d tile%-2d rc=%d %8.3f ms %8.1f TFLOP/s\n", label, M, N, K, tile, rc, ms, tf);
+  fflush(stdout);
+}
+
+static void bench_attn(const char* label, int B, int H, int Nq, int Nk, int D) {
+  const int C = H * D, Nkp = (Nk + 7) / 8 * 8;
+  auto Q = rand_h((size_t)B * Nq * C), K = rand_h((size_t)B * Nk * C), Vt = rand_h((size_t)C * B * Nkp);
+  Dev<h16> dQ(Q), dK(K), dV(Vt), dO((size_t)B * Nq * C);
+  PfdAttnDesc d;
+  memset(&d, 0, sizeof(d));
+  d.Q = dQ.p; d.K = dK.p; d.Vt = dV.p; d.O = dO.p;
+  d.ldq = C; d.ldk = C; d.ldvt = (long)B * Nkp; d.ldo = C;
+  d.q_bs = (long)Nq * C; d.k_bs = (long)Nk * C; d.vt_bs = Nkp; d.o_bs = (long)Nq * C;
+  d.B = B; d.H = H; d.Nq = Nq; d.Nk = Nk; d.D = D; d.scale = 1.f / sqrtf((float)D);
+  int rc = 0;
+  const float ms = time_ms([&] { rc |= pfd_attention_f16(&d, nullptr); }, 20);
+  const double tf = 4.0 * B * H * (double)Nq * Nk * D / (ms * 1e-3) / 1e12;
+  printf("bench %-34s B%d H%d Nq%d Nk%d D%d rc=%d %8.3f ms %8.1f TFLOP/s\n", label, B, H, Nq, Nk, D, rc, ms, tf);
+  fflush(stdout);
+}
+
+static void bench_gn(const char* label, int B, int HW, int C) {
+  auto x = rand_h((size_t)B * HW * C), g = rand_h(C), bt = rand_h(C);
+  Dev<h16> dx(x), dg(g), db(bt), dy((size_t)B * HW * C);
+  const size_t wsb = pfd_groupnorm_ws_bytes(B, C, HW);
+  Dev<char> dws(wsb);
+  int rc = 0;
+  const float ms = time_ms([&] { rc |= pfd_groupnorm_f16(dx.p, C, C, nullptr, 0, 0, dg.p, db.p, dy.p, C, B, HW, 32, 1e-5f, PFD_ACT_SILU, dws.p, wsb, nullptr); }, 20);
+  const double gbs = 6.0 * B * HW * C / (ms * 1e-3) / 1e9;
+  printf("bench %-34s B%d HW%d C%d rc=%d %8.3f ms %8.1f GB/s (6 B/elem)\n", label, B, HW, C, rc, ms, gbs);
+  fflush(stdout);
+}
+
+int main(int argc, char** argv) {
+  const bool bench = argc > 1 && !strcmp(argv[1], "--bench");
+  const bool only_bench = argc > 1 && !strcmp(argv[1], "--only-bench");
+  hipDeviceProp_t prop;
+  HIP_OK(hipGetDeviceProperties(&prop, 0));
+  printf("device: %s  CUs=%d  abi=%d\n", prop.name, prop.multiProcessorCount, pfd_abi_version());
+
+  if (!only_bench) {
+    const int tiles[] = {22, 21, 12, 11};
+    for (int t : tiles) {
+      run_gemm_case({256, 256, 128, 0, true, false, false, false, t});
+      run_gemm_case({301, 203 - 3, 192, PFD_ACT_GELU, true, true, true, false, t});
+      run_gemm_case({77, 72, 64, PFD_ACT_SILU, true, true, false, true, t, 8});
+    }
+    run_gemm_case({130, 4, 128, 0, true, true, false, false, 0});          // N = 4 (UNet head)
+    run_gemm_case({64, 37, 64, PFD_ACT_RELU, false, false, false, false, 0});  // odd N -> scalar stores
+    run_gemm_case({200, 256, 128, PFD_ACT_GEGLU, true, true, false, false, 0});
+    run_gemm_case({512, 1280, 320, 0, true, false, true, false, 0});
+    for (int t : tiles) {
+      GemmCase c{0, 96, 0, 0, true, true, true, false, t, 0, 3, 1, 1, 0, 2, 9, 7, 64};
+      run_gemm_case(c);
+    }
+    run_gemm_case({0, 128, 0, PFD_ACT_SILU, true, false, false, false, 0, 0, 3, 2, 1, 0, 2, 10, 8, 64});  // stride 2
+    run_gemm_case({0, 64, 0, 0, true, true, false, false, 0, 0, 3, 1, 1, 1, 1, 5, 6, 128});             // upsample
+    run_gemm_case({0, 64, 0, 0, true, false, false, false, 0, 8, 3, 2, 0, 0, 1, 9, 9, 64});             // pad 0, stride 2, ld+8
+    run_gemm_case({0, 80, 0, 0, true, false, false, false, 0, 0, 1, 1, 0, 0, 2, 6, 6, 128});            // 1x1 as conv
+
+    run_attn_case(2, 2, 128, 128, 40, true);
+    run_attn_case(1, 2, 200, 148, 40, false);
+    run_attn_case(2, 2, 64, 64, 80, true);
+    run_attn_case(1, 2, 144, 256, 96, false);
+    run_attn_case(1, 3, 148, 148, 96, false);
+    run_attn_case(2, 2, 64, 148, 160, false);
+    run_attn_case(1, 1, 256, 320, 160, true);
+
+    run_swin_case(1, 14, 17, 2, 0);
+    run_swin_case(1, 14, 17, 2, 6);
+    run_swin_case(2, 24, 24, 1, 6);
+    run_swin_case(1, 8, 8, 3, 6);
+
+    run_gn_case(2, 64, 320, 0, 32, PFD_ACT_SILU, 1e-5f);
+    run_gn_case(2, 100, 64, 32, 32, PFD_ACT_NONE, 1e-6f);   // groups straddle the concat seam
+    run_gn_case(1, 50, 1280, 1280, 32, PFD_ACT_SILU, 1e-5f);  // two vec slots per thread
+    run_gn_case(2, 1024, 128, 0, 32, PFD_ACT_SILU, 1e-6f);
+    run_gn_case(1, 16, 1920, 0, 32, PFD_ACT_SILU, 1e-5f);
+
+    run_ln_case(37, 320, 0, 0, 0, 0);
+    run_ln_case(10, 1280, 0, 0, 0, 0);
+    run_ln_case(5, 3072, 0, 0, 0, 0);
+    run_ln_case(2 * 4 * 3, 4 * 96, 1, 2, 7, 5);
+    run_softmax_case(5, 4096, 0.044f);
+    run_softmax_case(3, 1152, 0.1f);
+    run_elementwise();
+    printf("SELFTEST %d/%d passed, %d failed\n", g_total - g_fail, g_total, g_fail);
+  }
+
+  if (bench || only_bench) {
+    // UNet-shaped problems at C2 (UNet batch 8)
+    for (int t : {22, 21, 12, 11}) {
+      bench_gemm("conv3x3 320->320 @64^2", 0, 320, 0, 3, 8, 64, 320, t);
+    }
+    for (int t : {22, 21}) {
+      bench_gemm("conv3x3 640->640 @32^2", 0, 640, 0, 3, 8, 32, 640, t);
+      bench_gemm("conv3x3 1280->1280 @16^2", 0, 1280, 0, 3, 8, 16, 1280, t);
+    }
+    for (int t : {22, 21, 12, 11}) bench_gemm("conv3x3 1280->1280 @8^2", 0, 1280, 0, 3, 8, 8, 1280, t);
+    bench_gemm("conv3x3 2560->1280 @16^2", 0, 1280, 0, 3, 8, 16, 2560, 0);
+    bench_gemm("conv3x3 960->320 @64^2", 0, 320, 0, 3, 8, 64, 960, 0);
+    bench_gemm("linear qk 320->640 @64^2", 32768, 640, 320, 0, 0, 0, 0, 0);
+    bench_gemm("linear geglu-in 320->2560", 32768, 2560, 320, 0, 0, 0, 0, 0);
+    bench_gemm("linear ff-out 1280->320", 32768, 320, 1280, 0, 0, 0, 0, 0);
+    bench_gemm("linear 640->5120 @32^2", 8192, 5120, 640, 0, 0, 0, 0, 0);
+    bench_gemm("linear 1280->10240 @16^2", 2048, 10240, 1280, 0, 0, 0, 0, 0);
+    bench_gemm("vae conv3x3 128->128 @512^2 (B1)", 0, 128, 0, 3, 1, 512, 128, 0);
+    bench_gemm("vae conv3x3 512->512 @64^2 (B4)", 0, 512, 0, 3, 4, 64, 512, 0);
+    bench_gemm("square 4096^3", 4096, 4096, 4096, 0, 0, 0, 0, 22);
+    bench_attn("self-attn 64^2 d40", 8, 8, 4096, 4096, 40);
+    bench_attn("self-attn 32^2 d80", 8, 8, 1024, 1024, 80);
+    bench_attn("self-attn 16^2 d160", 8, 8, 256, 256, 160);
+    bench_attn("cross-attn 64^2 d40", 8, 8, 4096, 148, 40);
+    bench_attn("seecoder cross d96", 1, 8, 144, 4096, 96);
+    bench_gn("groupnorm+silu 320 @64^2", 8, 4096, 320);
+    bench_gn("groupnorm+silu 1280 @16^2", 8, 256, 1280);
+    bench_gn("groupnorm+silu 128 @512^2", 4, 262144, 128);
+  }
+  return g_fail;
+}
