@@ -213,6 +213,11 @@ int pfd_add_f16(const void* a, const void* b, void* y, int64_t n, pfd_stream_t s
 int pfd_add_rowvec_f16(const void* x, int64_t ldx, const void* v, void* y, int64_t ldy, int32_t R,
                        int32_t C, pfd_stream_t stream);
 
+/* y = act(x) elementwise (act in NONE|GELU|RELU|SILU), n f16 elements.  The SiLU in front
+ * of every ResBlock emb_layers Linear (openaimodel.py:217-218) applied once to the shared
+ * time embedding, and nonlinearity() on its own (autokl_modules.py:33-35). */
+int pfd_act_f16(const void* x, void* y, int64_t n, int32_t act, pfd_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -163,6 +163,27 @@ __global__ void add_rowvec_kernel(const half_t* __restrict__ x, long ldx, const 
   }
 }
 
+__global__ void act_kernel(const half_t* __restrict__ x, half_t* __restrict__ y, long n, int act) {
+  const long nv = n / 8;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < nv; i += (long)gridDim.x * blockDim.x) {
+    Pack16 p, o;
+    p.u = reinterpret_cast<const uint4*>(x)[i];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const float v = (float)p.e[e];
+      o.e[e] = (half_t)(act == PFD_ACT_SILU ? pfd_silu(v) : act == PFD_ACT_GELU ? pfd_gelu(v)
+                        : act == PFD_ACT_RELU ? fmaxf(v, 0.f) : v);
+    }
+    reinterpret_cast<uint4*>(y)[i] = o.u;
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (n & 7)) {
+    const long i = nv * 8 + threadIdx.x;
+    const float v = (float)x[i];
+    y[i] = (half_t)(act == PFD_ACT_SILU ? pfd_silu(v) : act == PFD_ACT_GELU ? pfd_gelu(v)
+                    : act == PFD_ACT_RELU ? fmaxf(v, 0.f) : v);
+  }
+}
+
 inline int grid_for(long n, int block) {
   long g = (n + block - 1) / block;
   if (g > 4096) g = 4096;
@@ -241,4 +262,13 @@ extern "C" int pfd_add_rowvec_f16(const void* x, int64_t ldx, const void* v, voi
   hipLaunchKernelGGL(add_rowvec_kernel, dim3(grid_for(n, 256)), dim3(256), 0, (hipStream_t)stream,
                      (const half_t*)x, (long)ldx, (const half_t*)v, (half_t*)y, (long)ldy, R, C);
   return pfd_check_launch("pfd_add_rowvec_f16");
+}
+
+extern "C" int pfd_act_f16(const void* x, void* y, int64_t n, int32_t act, pfd_stream_t stream) {
+  if (!x || !y || n <= 0) return PFD_EINVAL;
+  if (act < PFD_ACT_NONE || act > PFD_ACT_SILU) return PFD_EINVAL;
+  if ((reinterpret_cast<uintptr_t>(x) & 15) || (reinterpret_cast<uintptr_t>(y) & 15)) return PFD_EINVAL;
+  hipLaunchKernelGGL(act_kernel, dim3(grid_for(n / 8 + 1, 256)), dim3(256), 0, (hipStream_t)stream,
+                     (const half_t*)x, (half_t*)y, (long)n, act);
+  return pfd_check_launch("pfd_act_f16");
 }

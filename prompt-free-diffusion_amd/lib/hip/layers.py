@@ -1,0 +1,202 @@
+"""Leaf layers of the HIP product path.
+
+Each class subclasses the torch parameter holder of the same name so that `state_dict()` keys,
+shapes and default initialisation are those of the reference checkpoints (1902
+keys for pfd_with_control), but none of them ever runs a torch compute op: `.hip(...)` works
+on fp16 NHWC / token-major tensors through libpfd_hip.so, and `.forward(...)` is the reference
+calling convention (NCHW / any float dtype) wrapped around `.hip`.
+
+Canonical parameters stay the `nn.Parameter`s; kernel-layout fp16 copies are cached per layer
+and rebuilt whenever the canonical tensor changes identity, version, dtype or device
+(`load_state_dict`, `.half()`, `.to()`, in-place edits) -- app.py hot-swaps weights per
+request (app.py:139-177, 217-222).
+"""
+import torch
+import torch.nn as nn
+
+from . import ops
+from .ops import ACT_GEGLU, ACT_GELU, ACT_NONE, ACT_RELU, ACT_SILU  # noqa: F401
+
+
+def _round_up(v, m):
+    return (v + m - 1) // m * m
+
+
+def _sig(*ps):
+    return tuple((p.data_ptr(), p._version, p.dtype, p.device) if p is not None else None for p in ps)
+
+
+def _dev16(t):
+    if not t.is_cuda:
+        raise RuntimeError("parameters must be on the GPU before the HIP path runs (call net.to('cuda')); "
+                           "there is no CPU fallback")
+    return t.detach().to(torch.float16)
+
+
+def pack_matrix(w2d, kpad_to=64):
+    """[N, K] -> dense fp16 [N, round_up(K, 64)] (zero padded K)."""
+    w = _dev16(w2d)
+    N, K = w.shape
+    Kp = _round_up(K, kpad_to)
+    if Kp != K:
+        wp = torch.zeros((N, Kp), dtype=torch.float16, device=w.device)
+        wp[:, :K] = w
+        return wp
+    return w.contiguous()
+
+
+def pack_conv_weight(w4d):
+    """[Cout, Cin, kh, kw] -> [Cout, kh*kw*Cin] (tap-major, channel-minor), K padded to 64."""
+    w = _dev16(w4d)
+    Cout = w.shape[0]
+    return pack_matrix(w.permute(0, 2, 3, 1).reshape(Cout, -1))
+
+
+def pack_vec(b):
+    return None if b is None else _dev16(b).contiguous()
+
+
+class _Packed:
+    """mixin: self._packed(name, builder, *params) -> cached kernel-layout tensors"""
+
+    def _packed(self, name, builder, *params):
+        cache = self.__dict__.setdefault("_pk_cache", {})
+        sig = _sig(*params)
+        ent = cache.get(name)
+        if ent is None or ent[0] != sig:
+            with torch.no_grad():
+                ent = (sig, builder())
+            cache[name] = ent
+        return ent[1]
+
+
+def _io_wrap_nchw(mod, x, fn):
+    """reference calling convention for image layers: NCHW in -> NCHW out in x.dtype"""
+    y = fn(ops.to_nhwc(x))
+    return ops.to_nchw(y, x.dtype if x.dtype in (torch.float16, torch.float32) else torch.float32)
+
+
+class Conv2d(nn.Conv2d, _Packed):
+    """nn.Conv2d parameter holder; kxk (stride 1|2) as implicit GEMM, narrow Cin via im2col."""
+
+    def _pk(self):
+        return self._packed("w", lambda: (pack_conv_weight(self.weight), pack_vec(self.bias)), self.weight, self.bias)
+
+    def hip(self, x, *, ups=False, rowvec=None, res=None, act=ACT_NONE, out=None, out_hw=None):
+        w, b = self._pk()
+        k, s, p = self.kernel_size[0], self.stride[0], self.padding[0]
+        cin = self.in_channels
+        if cin % 64 == 0:
+            if k == 1 and s == 1 and not ups:
+                B, H, W_, _ = x.shape
+                o2 = None if out is None else out.view(-1, out.shape[-1])
+                r2 = None if res is None else res.reshape(-1, res.shape[-1])
+                y = ops.gemm(x.reshape(-1, cin), w, bias=b, rowvec=rowvec, rows_per_rv=H * W_, res=r2, act=act,
+                             out=o2)
+                return y.view(B, H, W_, self.out_channels)
+            return ops.conv(x, w, k, stride=s, pad=p, ups=ups, bias=b, rowvec=rowvec, res=res, act=act, out=out,
+                            out_hw=out_hw)
+        if ups:
+            raise NotImplementedError("narrow-channel conv with fused upsample")
+        r2 = None if res is None else res.reshape(-1, res.shape[-1])
+        ho, wo = out_hw if out_hw is not None else (None, None)
+        return ops.conv_narrow(x, w, k, stride=s, pad=p, bias=b, rowvec=rowvec, res=r2, act=act, ho=ho, wo=wo)
+
+    def forward(self, x):
+        return _io_wrap_nchw(self, x, self.hip)
+
+
+class Linear(nn.Linear, _Packed):
+    def _pk(self):
+        return self._packed("w", lambda: (pack_matrix(self.weight), pack_vec(self.bias)), self.weight, self.bias)
+
+    def hip(self, x, *, act=ACT_NONE, res=None, rowvec=None, rows_per_rv=1, out=None):
+        """x: [..., K] fp16 token-major -> [..., N]"""
+        w, b = self._pk()
+        K = self.in_features
+        x2 = x.reshape(-1, K) if x.dim() != 2 else x
+        if w.shape[1] != K:  # K was padded (e.g. PPE 80 -> 128): pad the activation once
+            xp = torch.zeros((x2.shape[0], w.shape[1]), dtype=torch.float16, device=x2.device)
+            xp[:, :K] = x2
+            x2 = xp
+        r2 = None if res is None else (res.reshape(-1, res.shape[-1]) if res.dim() != 2 else res)
+        y = ops.gemm(x2, w, bias=b, act=act, res=r2, rowvec=rowvec, rows_per_rv=rows_per_rv, out=out)
+        return y if x.dim() == 2 else y.view(*x.shape[:-1], y.shape[-1])
+
+    def hip_t(self, x2d, out=None):
+        """transposed product: returns W @ x^T (+ bias per row) as [N, M] -- the V^T operand of
+        pfd_attention_f16 written directly by the GEMM."""
+        w, b = self._pk()
+        return ops.gemm(w, x2d, bias=b, bias_per_row=True, out=out, k=self.in_features)
+
+    def forward(self, x):
+        if not x.is_cuda:
+            raise RuntimeError("HIP path: input must be on the GPU (no CPU fallback)")
+        return self.hip(x.to(torch.float16)).to(x.dtype)
+
+
+class GroupNorm(nn.GroupNorm, _Packed):
+    def _pk(self):
+        return self._packed("w", lambda: (pack_vec(self.weight), pack_vec(self.bias)), self.weight, self.bias)
+
+    def hip(self, x, x2=None, silu=False):
+        g, b = self._pk()
+        return ops.groupnorm(x, g, b, self.num_groups, self.eps, x2=x2, silu=silu)
+
+    def forward(self, x):
+        return _io_wrap_nchw(self, x, self.hip)
+
+
+class LayerNorm(nn.LayerNorm, _Packed):
+    def _pk(self):
+        return self._packed("w", lambda: (pack_vec(self.weight), pack_vec(self.bias)), self.weight, self.bias)
+
+    def hip(self, x, out=None):
+        g, b = self._pk()
+        return ops.layernorm(x, g, b, self.eps, out=out)
+
+    def forward(self, x):
+        if not x.is_cuda:
+            raise RuntimeError("HIP path: input must be on the GPU (no CPU fallback)")
+        return self.hip(x.to(torch.float16).contiguous()).to(x.dtype)
+
+
+class MultiheadAttention(nn.MultiheadAttention, _Packed):
+    """nn.MultiheadAttention parameter holder (packed in_proj_weight [3C, C], seq-first API in
+    the reference).  `.hip` takes batch-free token matrices: q_in [Nq, C], k_in [Nk, C],
+    v_in [Nk, C] for ONE image and returns out_proj(attn) [Nq, C] (+ res)."""
+
+    def _pk(self):
+        def build():
+            Cd = self.embed_dim
+            w = _dev16(self.in_proj_weight)
+            b = _dev16(self.in_proj_bias)
+            return dict(wq=w[:Cd].contiguous(), wk=w[Cd:2 * Cd].contiguous(), wv=w[2 * Cd:].contiguous(),
+                        bq=b[:Cd].contiguous(), bk=b[Cd:2 * Cd].contiguous(), bv=b[2 * Cd:].contiguous(),
+                        wo=pack_matrix(self.out_proj.weight), bo=pack_vec(self.out_proj.bias))
+        return self._packed("w", build, self.in_proj_weight, self.in_proj_bias, self.out_proj.weight,
+                            self.out_proj.bias)
+
+    def hip(self, q_in, k_in, v_in, res=None):
+        p = self._pk()
+        Cd, H = self.embed_dim, self.num_heads
+        D = Cd // H
+        Nq, Nk = q_in.shape[0], k_in.shape[0]
+        q = ops.gemm(q_in, p["wq"], bias=p["bq"])
+        k = ops.gemm(k_in, p["wk"], bias=p["bk"])
+        Nk8 = _round_up(Nk, 8)
+        vt = torch.empty((Cd, Nk8), dtype=torch.float16, device=q.device)
+        ops.gemm(p["wv"], v_in, bias=p["bv"], bias_per_row=True, out=vt[:, :Nk])
+        o = ops.attention(q, k, vt, 1, H, Nq, Nk, D, D ** -0.5, ldq=Cd, ldk=Cd, ldvt=Nk8, q_bs=0, k_bs=0, vt_bs=0)
+        return ops.gemm(o, p["wo"], bias=p["bo"], res=res)
+
+    def hip_seq1(self, x, res=None):
+        """sequence length 1 (softmax over a single key == 1): out_proj(v_proj(x))."""
+        p = self._pk()
+        v = ops.gemm(x, p["wv"], bias=p["bv"])
+        return ops.gemm(v, p["wo"], bias=p["bo"], res=res)
+
+
+class Embedding(nn.Embedding, _Packed):
+    def hip_weight(self):
+        return self._packed("w", lambda: pack_vec(self.weight), self.weight)

@@ -1,0 +1,315 @@
+"""Tensor-level wrappers over the C ABI (binding.py): torch is used here for device memory and
+the current HIP stream only -- every arithmetic op below is a hand-written gfx950 kernel.
+
+Layout convention of the whole product path: activations are fp16, token-major / NHWC
+(`[B, H, W, C]` or `[M, C]`, channel stride 1, row stride `ld`).  NCHW exists only at the
+reference API boundary (ops.to_nhwc / ops.to_nchw).
+"""
+import ctypes as C
+
+import torch
+
+from . import binding as _b
+from .binding import ACT_GEGLU, ACT_GELU, ACT_NONE, ACT_RELU, ACT_SILU  # noqa: F401
+
+_byref = C.byref
+
+
+def _lib():
+    return _b.load()
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _ptr(t):
+    return t.data_ptr() if t is not None else None
+
+
+def _chk16(t, what):
+    if t.dtype != torch.float16:
+        raise TypeError(f"{what}: expected float16, got {t.dtype}")
+    if not t.is_cuda:
+        raise RuntimeError(f"{what}: tensor is on {t.device}; the HIP path has no CPU fallback")
+    if t.stride(-1) != 1:
+        raise ValueError(f"{what}: innermost stride must be 1")
+
+
+def _rows(t):
+    """(rows, cols, ld) of a tensor viewed as a row-major matrix with unit column stride."""
+    cols = t.shape[-1]
+    if t.dim() == 1:
+        return 1, cols, cols
+    ld = t.stride(-2)
+    rows = t.numel() // cols
+    # all leading dims must be collapsible onto the row stride
+    exp = ld
+    for d in range(t.dim() - 2, -1, -1):
+        if t.shape[d] != 1 and t.stride(d) != exp:
+            raise ValueError(f"tensor of shape {tuple(t.shape)} strides {t.stride()} is not a strided matrix")
+        exp *= t.shape[d]
+    return rows, cols, ld
+
+
+# ----------------------------------------------------------------------------------------------
+# GEMM / convolution
+# ----------------------------------------------------------------------------------------------
+def gemm(a, w, *, bias=None, rowvec=None, rows_per_rv=1, res=None, act=ACT_NONE, out=None,
+         bias_per_row=False, n=None, k=None, tile=0):
+    """out[M, N] = epi(a[M, K] @ w[N, K]^T); see pfd_gemm_f16 in include/pfd_hip.h."""
+    _chk16(a, "gemm A")
+    _chk16(w, "gemm W")
+    M, Ka, lda = _rows(a)
+    Nw, Kw, ldw = _rows(w)
+    N = Nw if n is None else n
+    K = min(Ka, Kw) if k is None else k
+    n_out = N // 2 if act == ACT_GEGLU else N
+    if out is None:
+        out = torch.empty((M, n_out), dtype=torch.float16, device=a.device)
+    _, _, ldc = _rows(out)
+    d = _b.PfdGemmDesc()
+    d.A, d.W, d.C = a.data_ptr(), w.data_ptr(), out.data_ptr()
+    d.bias, d.rowvec, d.R = _ptr(bias), _ptr(rowvec), _ptr(res)
+    d.lda, d.ldw, d.ldc = lda, ldw, ldc
+    d.ldr = _rows(res)[2] if res is not None else 0
+    d.ldrv = _rows(rowvec)[2] if rowvec is not None else 0
+    d.M, d.N, d.K = M, N, K
+    d.rows_per_rv, d.act, d.bias_per_row = rows_per_rv, act, 1 if bias_per_row else 0
+    d.ksize = 0
+    lib = _lib()
+    rc = lib.pfd_gemm_f16_ex(_byref(d), tile, _stream()) if tile else lib.pfd_gemm_f16(_byref(d), _stream())
+    _b.check(rc, f"pfd_gemm_f16 M{M} N{N} K{K}")
+    return out
+
+
+def conv(x, w, ksize, *, stride=1, pad=None, ups=False, bias=None, rowvec=None, res=None, act=ACT_NONE,
+         out=None, tile=0, out_hw=None):
+    """Implicit-GEMM convolution of an NHWC image x[B,H,W,Cin] (Cin % 64 == 0) with packed
+    weights w[N, ksize*ksize*Cin]; returns [B,Ho,Wo,N].  rowvec: [B, N] per-sample vector."""
+    _chk16(x, "conv x")
+    _chk16(w, "conv W")
+    B, H, W_, Cin = x.shape
+    if x.stride(2) != x.stride(3) * Cin and x.stride(2) < Cin:
+        raise ValueError("conv: bad pixel stride")
+    lda = x.stride(2)
+    if x.stride(1) != lda * W_ or (B > 1 and x.stride(0) != lda * W_ * H):
+        raise ValueError("conv: image must be dense over (B, H, W)")
+    if pad is None:
+        pad = ksize // 2
+    Hin, Win = (2 * H, 2 * W_) if ups else (H, W_)
+    Ho = (Hin + 2 * pad - ksize) // stride + 1
+    Wo = (Win + 2 * pad - ksize) // stride + 1
+    if out_hw is not None:  # asymmetric (bottom/right) zero padding: taps past the image read 0
+        Ho, Wo = out_hw
+    N, K, ldw = _rows(w)
+    if K != ksize * ksize * Cin:
+        raise ValueError(f"conv: packed weight K {K} != {ksize}*{ksize}*{Cin}")
+    M = B * Ho * Wo
+    if out is None:
+        out = torch.empty((B, Ho, Wo, N), dtype=torch.float16, device=x.device)
+    d = _b.PfdGemmDesc()
+    d.A, d.W, d.C = x.data_ptr(), w.data_ptr(), out.data_ptr()
+    d.bias, d.rowvec, d.R = _ptr(bias), _ptr(rowvec), _ptr(res)
+    d.lda, d.ldw, d.ldc = lda, ldw, _rows(out)[2]
+    d.ldr = _rows(res)[2] if res is not None else 0
+    d.ldrv = _rows(rowvec)[2] if rowvec is not None else 0
+    d.M, d.N, d.K = M, N, K
+    d.rows_per_rv, d.act, d.bias_per_row = Ho * Wo, act, 0
+    d.ksize, d.stride, d.pad, d.ups = ksize, stride, pad, 1 if ups else 0
+    d.B, d.H, d.Wd, d.Cin, d.Ho, d.Wo = B, H, W_, Cin, Ho, Wo
+    lib = _lib()
+    rc = lib.pfd_gemm_f16_ex(_byref(d), tile, _stream()) if tile else lib.pfd_gemm_f16(_byref(d), _stream())
+    _b.check(rc, f"pfd_gemm_f16(conv) M{M} N{N} K{K}")
+    return out
+
+
+def im2col(x, ksize, stride, pad, kpad, ho=None, wo=None):
+    """[B,H,W,Cin] -> [B*Ho*Wo, kpad] patch matrix (zero padded) for narrow-channel convs."""
+    _chk16(x, "im2col x")
+    B, H, W_, Cin = x.shape
+    Ho = (H + 2 * pad - ksize) // stride + 1 if ho is None else ho
+    Wo = (W_ + 2 * pad - ksize) // stride + 1 if wo is None else wo
+    col = torch.empty((B * Ho * Wo, kpad), dtype=torch.float16, device=x.device)
+    rc = _lib().pfd_im2col_f16(x.data_ptr(), x.stride(2), col.data_ptr(), B, H, W_, Cin, ksize, stride, pad,
+                               Ho, Wo, kpad, _stream())
+    _b.check(rc, "pfd_im2col_f16")
+    return col, Ho, Wo
+
+
+def conv_narrow(x, w, ksize, *, stride=1, pad=None, bias=None, rowvec=None, res=None, act=ACT_NONE,
+                ho=None, wo=None):
+    """Convolution whose Cin is not a multiple of 64: im2col + GEMM.  w: [N, kpad] packed."""
+    if pad is None:
+        pad = ksize // 2
+    B = x.shape[0]
+    col, Ho, Wo = im2col(x, ksize, stride, pad, w.shape[1], ho, wo)
+    N = w.shape[0]
+    out = gemm(col, w, bias=bias, rowvec=rowvec, rows_per_rv=Ho * Wo, res=res, act=act)
+    return out.view(B, Ho, Wo, N)
+
+
+# ----------------------------------------------------------------------------------------------
+# attention
+# ----------------------------------------------------------------------------------------------
+def attention(q, k, vt, B, H, Nq, Nk, D, scale, *, ldq, ldk, ldvt, q_bs, k_bs, vt_bs, out=None):
+    """Fused attention; see pfd_attention_f16.  q/k/vt may be views into wider buffers."""
+    if out is None:
+        out = torch.empty((B * Nq, H * D), dtype=torch.float16, device=q.device)
+    d = _b.PfdAttnDesc()
+    d.Q, d.K, d.Vt, d.O = q.data_ptr(), k.data_ptr(), vt.data_ptr(), out.data_ptr()
+    d.ldq, d.ldk, d.ldvt, d.ldo = ldq, ldk, ldvt, out.stride(-2)
+    d.q_bs, d.k_bs, d.vt_bs, d.o_bs = q_bs, k_bs, vt_bs, Nq * out.stride(-2)
+    d.B, d.H, d.Nq, d.Nk, d.D = B, H, Nq, Nk, D
+    d.scale = scale
+    _b.check(_lib().pfd_attention_f16(_byref(d), _stream()), f"pfd_attention_f16 B{B} H{H} Nq{Nq} Nk{Nk} D{D}")
+    return out
+
+
+def swin_window_attention(qkv, qkv_bias, rpb, B, H, W_, Cdim, nH, ws, shift, scale):
+    _chk16(qkv, "swin qkv")
+    out = torch.empty((B * H * W_, Cdim), dtype=torch.float16, device=qkv.device)
+    d = _b.PfdSwinAttnDesc()
+    d.qkv, d.qkv_bias, d.rpb, d.out = qkv.data_ptr(), qkv_bias.data_ptr(), rpb.data_ptr(), out.data_ptr()
+    d.B, d.H, d.W, d.C, d.nH, d.ws, d.shift = B, H, W_, Cdim, nH, ws, shift
+    d.scale = scale
+    _b.check(_lib().pfd_swin_window_attention_f16(_byref(d), _stream()), "pfd_swin_window_attention_f16")
+    return out
+
+
+# ----------------------------------------------------------------------------------------------
+# normalisation
+# ----------------------------------------------------------------------------------------------
+def groupnorm(x, gamma, beta, groups, eps, *, x2=None, silu=False, out=None):
+    """GroupNorm(+SiLU) of NHWC x[B,H,W,C1] (optionally virtually concatenated with x2[B,H,W,C2])."""
+    _chk16(x, "groupnorm x")
+    B = x.shape[0]
+    C1 = x.shape[-1]
+    HW = x.numel() // (B * C1)
+    C2 = 0 if x2 is None else x2.shape[-1]
+    if out is None:
+        out = torch.empty(tuple(x.shape[:-1]) + (C1 + C2,), dtype=torch.float16, device=x.device)
+    lib = _lib()
+    wsb = lib.pfd_groupnorm_ws_bytes(B, C1 + C2, HW)
+    ws = torch.empty(wsb, dtype=torch.uint8, device=x.device)
+    rc = lib.pfd_groupnorm_f16(x.data_ptr(), C1, x.stride(-2), _ptr(x2), C2, 0 if x2 is None else x2.stride(-2),
+                               gamma.data_ptr(), beta.data_ptr(), out.data_ptr(), out.stride(-2), B, HW, groups,
+                               eps, ACT_SILU if silu else ACT_NONE, ws.data_ptr(), wsb, _stream())
+    _b.check(rc, f"pfd_groupnorm_f16 B{B} HW{HW} C{C1}+{C2}")
+    return out
+
+
+def layernorm(x, gamma, beta, eps=1e-5, out=None):
+    _chk16(x, "layernorm x")
+    M, Cdim, ldx = _rows(x)
+    if out is None:
+        out = torch.empty(x.shape, dtype=torch.float16, device=x.device)
+    rc = _lib().pfd_layernorm_f16(x.data_ptr(), ldx, gamma.data_ptr(), beta.data_ptr(), out.data_ptr(),
+                                  _rows(out)[2], M, Cdim, eps, 0, 0, 0, 0, _stream())
+    _b.check(rc, f"pfd_layernorm_f16 M{M} C{Cdim}")
+    return out
+
+
+def layernorm_patch_merge(x, gamma, beta, eps=1e-5):
+    """PatchMerging gather + LayerNorm(4C): x[B,H,W,C] -> [B*ceil(H/2)*ceil(W/2), 4C]."""
+    _chk16(x, "layernorm_patch_merge x")
+    B, H, W_, Cq = x.shape
+    Ho, Wo = (H + 1) // 2, (W_ + 1) // 2
+    out = torch.empty((B * Ho * Wo, 4 * Cq), dtype=torch.float16, device=x.device)
+    rc = _lib().pfd_layernorm_f16(x.data_ptr(), x.stride(2), gamma.data_ptr(), beta.data_ptr(), out.data_ptr(),
+                                  4 * Cq, B * Ho * Wo, 4 * Cq, eps, 1, B, H, W_, _stream())
+    _b.check(rc, "pfd_layernorm_f16(gather4)")
+    return out
+
+
+def softmax_rows(x, scale, out=None):
+    _chk16(x, "softmax x")
+    R, N, ldx = _rows(x)
+    if out is None:
+        out = torch.empty((R, N), dtype=torch.float16, device=x.device)
+    _b.check(_lib().pfd_softmax_rows_f16(x.data_ptr(), ldx, out.data_ptr(), _rows(out)[2], R, N, scale, _stream()),
+             "pfd_softmax_rows_f16")
+    return out
+
+
+# ----------------------------------------------------------------------------------------------
+# boundary / elementwise
+# ----------------------------------------------------------------------------------------------
+def to_nhwc(x, mul=1.0, add=0.0, rep=1):
+    """NCHW fp32|fp16 -> NHWC fp16 (x*mul+add), batch repeated `rep` times."""
+    if not x.is_cuda:
+        raise RuntimeError("to_nhwc: input must live on the GPU; the HIP path has no CPU fallback")
+    if x.dtype not in (torch.float32, torch.float16):
+        x = x.float()
+    x = x.contiguous()
+    B, Cc, H, W_ = x.shape
+    out = torch.empty((rep * B, H, W_, Cc), dtype=torch.float16, device=x.device)
+    rc = _lib().pfd_nchw_to_nhwc_f16(x.data_ptr(), 1 if x.dtype == torch.float32 else 0, out.data_ptr(), B, Cc, H,
+                                     W_, mul, add, rep, _stream())
+    _b.check(rc, "pfd_nchw_to_nhwc_f16")
+    return out
+
+
+def to_nchw(x, dtype=torch.float16, mul=1.0, add=0.0, lo=-65504.0, hi=65504.0):
+    """NHWC fp16 (dense) -> NCHW fp32|fp16, y = clamp(x*mul+add, lo, hi)."""
+    _chk16(x, "to_nchw x")
+    B, H, W_, Cc = x.shape
+    if not x.is_contiguous():
+        raise ValueError("to_nchw: dense NHWC expected")
+    out = torch.empty((B, Cc, H, W_), dtype=torch.float32 if dtype == torch.float32 else torch.float16,
+                      device=x.device)
+    rc = _lib().pfd_nhwc_to_nchw(x.data_ptr(), out.data_ptr(), 1 if dtype == torch.float32 else 0, B, Cc, H, W_,
+                                 mul, add, lo, hi, _stream())
+    _b.check(rc, "pfd_nhwc_to_nchw")
+    return out if out.dtype == dtype else out.to(dtype)
+
+
+def timestep_embedding(t, dim, max_period=10000.0):
+    t = t.to(torch.int64).contiguous()
+    out = torch.empty((t.shape[0], dim), dtype=torch.float16, device=t.device)
+    _b.check(_lib().pfd_timestep_embedding_f16(t.data_ptr(), out.data_ptr(), t.shape[0], dim, max_period, _stream()),
+             "pfd_timestep_embedding_f16")
+    return out
+
+
+def cfg_ddim_step(eps, nb, x, coef, *, noise=None, want_next=True):
+    """Fused CFG combine + DDIM update.  eps NHWC f16 [nb*B,h,w,C]; x NCHW fp32 [B,C,h,w];
+    coef fp32[5] device.  Returns (x_prev fp32 NCHW, pred_x0 fp32 NCHW, xin_next f16 NHWC|None)."""
+    B, Cc, h, w = x.shape
+    x_prev = torch.empty_like(x)
+    pred_x0 = torch.empty_like(x)
+    xin = torch.empty((nb * B, h, w, Cc), dtype=torch.float16, device=x.device) if want_next else None
+    rc = _lib().pfd_cfg_ddim_step(eps.data_ptr(), nb, x.data_ptr(), _ptr(noise), coef.data_ptr(), x_prev.data_ptr(),
+                                  pred_x0.data_ptr(), _ptr(xin), B, Cc, h, w, _stream())
+    _b.check(rc, "pfd_cfg_ddim_step")
+    return x_prev, pred_x0, xin
+
+
+def add(a, b, out=None):
+    _chk16(a, "add a")
+    if not (a.is_contiguous() and b.is_contiguous()):
+        raise ValueError("add: dense tensors expected")
+    if out is None:
+        out = torch.empty_like(a)
+    _b.check(_lib().pfd_add_f16(a.data_ptr(), b.data_ptr(), out.data_ptr(), a.numel(), _stream()), "pfd_add_f16")
+    return out
+
+
+def add_rowvec(x, v, out=None):
+    _chk16(x, "add_rowvec x")
+    R, Cc, ldx = _rows(x)
+    if out is None:
+        out = torch.empty(x.shape, dtype=torch.float16, device=x.device)
+    _b.check(_lib().pfd_add_rowvec_f16(x.data_ptr(), ldx, v.data_ptr(), out.data_ptr(), _rows(out)[2], R, Cc,
+                                       _stream()), "pfd_add_rowvec_f16")
+    return out
+
+
+def activation(x, act, out=None):
+    _chk16(x, "activation x")
+    if not x.is_contiguous():
+        raise ValueError("activation: dense tensor expected")
+    if out is None:
+        out = torch.empty_like(x)
+    _b.check(_lib().pfd_act_f16(x.data_ptr(), out.data_ptr(), x.numel(), act, _stream()), "pfd_act_f16")
+    return out

@@ -1,0 +1,226 @@
+"""UNet transformer blocks on the HIP path.
+
+Same module tree / state-dict keys / constructor kwargs as the live classes of the reference's
+lib/model_zoo/attention.py (CrossAttention :159-201, GEGLU :44-51, FeedForward :54-71,
+BasicTransformerBlock :277-306, SpatialTransformer :309-371), but the forward is token-major
+fp16 end to end on hand-written gfx950 kernels:
+
+  GN(eps 1e-6) -> 1x1 conv (GEMM) -> [LN -> fused QK GEMM + V^T GEMM -> flash attention ->
+  out-proj GEMM (+bias +residual)] -> [LN -> Q GEMM -> flash attention over cached context K/V^T
+  -> out-proj (+residual)] -> [LN -> GEGLU GEMM (x*gelu(gate) in the epilogue) -> GEMM (+residual)]
+  -> 1x1 conv (+bias + block input)
+
+No `b c h w <-> b (hw) c` rearranges exist (attention.py:361,368): NHWC *is* token-major.
+The score matrix is never materialised (attention.py:188-199 does, 2.1 GB per layer at C2).
+"""
+import torch
+import torch.nn as nn
+
+from ..hip import layers as L
+from ..hip import ops
+
+
+def exists(v):
+    return v is not None
+
+
+def default(v, d):
+    return v if v is not None else (d() if callable(d) else d)
+
+
+def Normalize(in_channels):
+    return L.GroupNorm(num_groups=32, num_channels=in_channels, eps=1e-6, affine=True)
+
+
+class ContextKV:
+    """Per-request cache of the step-invariant cross-attention operands: for every
+    CrossAttention layer that consumes `context` [B, Nk, Cctx], K = to_k(context) and
+    V^T = to_v(context)^T are computed once (SURVEY §8a saving (ii)) instead of once per DDIM
+    step.  Context rows are zero-padded to a multiple of 8 tokens so every V^T row is 16-byte
+    aligned (pfd_attention_f16 contract)."""
+
+    def __init__(self, context):
+        if not context.is_cuda:
+            raise RuntimeError("HIP path: context must be on the GPU (no CPU fallback)")
+        B, Nk, Cd = context.shape
+        self.B, self.Nk, self.Cd = B, Nk, Cd
+        self.Nkp = (Nk + 7) // 8 * 8
+        ctx = torch.zeros((B, self.Nkp, Cd), dtype=torch.float16, device=context.device)
+        ctx[:, :Nk] = context.to(torch.float16)
+        self.ctx2d = ctx.view(B * self.Nkp, Cd)
+        self._kv = {}
+
+    def get(self, attn):
+        ent = self._kv.get(id(attn))
+        if ent is None:
+            k = attn.to_k.hip(self.ctx2d)          # [B*Nkp, inner]
+            vt = attn.to_v.hip_t(self.ctx2d)       # [inner, B*Nkp]
+            ent = self._kv[id(attn)] = (k, vt)
+        return ent
+
+
+def as_context_kv(context):
+    if context is None or isinstance(context, ContextKV):
+        return context
+    if isinstance(context, (list, tuple)):
+        context = context[0]
+    return ContextKV(context)
+
+
+class GEGLU(nn.Module, L._Packed):
+    """proj: Linear(dim_in, 2*dim_out); y = x * gelu(gate).  The packed weight interleaves x/gate
+    rows in blocks of 32 so both halves of an output column sit in one GEMM tile."""
+
+    def __init__(self, dim_in, dim_out):
+        super().__init__()
+        self.proj = L.Linear(dim_in, dim_out * 2)
+        self.dim_out = dim_out
+
+    def _pk(self):
+        def build():
+            n = self.dim_out
+            w = L._dev16(self.proj.weight)
+            b = L._dev16(self.proj.bias)
+            wi = torch.stack([w[:n].view(n // 32, 32, -1), w[n:].view(n // 32, 32, -1)], 1).reshape(2 * n, -1)
+            bi = torch.stack([b[:n].view(n // 32, 32), b[n:].view(n // 32, 32)], 1).reshape(2 * n)
+            return wi.contiguous(), bi.contiguous()
+        return self._packed("geglu", build, self.proj.weight, self.proj.bias)
+
+    def hip(self, x2d):
+        w, b = self._pk()
+        return ops.gemm(x2d, w, bias=b, act=ops.ACT_GEGLU)
+
+    def forward(self, x):
+        y = self.hip(x.to(torch.float16).reshape(-1, x.shape[-1]))
+        return y.view(*x.shape[:-1], self.dim_out).to(x.dtype)
+
+
+class FeedForward(nn.Module):
+    def __init__(self, dim, dim_out=None, mult=4, glu=False, dropout=0.):
+        super().__init__()
+        inner_dim = int(dim * mult)
+        dim_out = default(dim_out, dim)
+        self.glu = glu
+        project_in = GEGLU(dim, inner_dim) if glu else nn.Sequential(L.Linear(dim, inner_dim), nn.GELU())
+        self.net = nn.Sequential(project_in, nn.Dropout(dropout), L.Linear(inner_dim, dim_out))
+
+    def hip(self, x2d, res=None):
+        h = self.net[0].hip(x2d) if self.glu else self.net[0][0].hip(x2d, act=ops.ACT_GELU)
+        return self.net[2].hip(h, res=res)
+
+    def forward(self, x):
+        y = self.hip(x.to(torch.float16).reshape(-1, x.shape[-1]))
+        return y.view(*x.shape[:-1], y.shape[-1]).to(x.dtype)
+
+
+class CrossAttention(nn.Module, L._Packed):
+    def __init__(self, query_dim, context_dim=None, heads=8, dim_head=64, dropout=0.):
+        super().__init__()
+        inner_dim = dim_head * heads
+        context_dim = default(context_dim, query_dim)
+        self.scale = dim_head ** -0.5
+        self.heads = heads
+        self.dim_head = dim_head
+        self.inner_dim = inner_dim
+        self.to_q = L.Linear(query_dim, inner_dim, bias=False)
+        self.to_k = L.Linear(context_dim, inner_dim, bias=False)
+        self.to_v = L.Linear(context_dim, inner_dim, bias=False)
+        self.to_out = nn.Sequential(L.Linear(inner_dim, query_dim), nn.Dropout(dropout))
+
+    def _pk_qk(self):
+        return self._packed(
+            "qk", lambda: torch.cat([L._dev16(self.to_q.weight), L._dev16(self.to_k.weight)], 0).contiguous(),
+            self.to_q.weight, self.to_k.weight)
+
+    def hip(self, x, B, N, context=None, res=None):
+        """x: [B*N, query_dim] tokens (already normalised); context: None (self-attention) or a
+        ContextKV; res: residual added by the out-projection epilogue.  -> [B*N, query_dim]"""
+        Cd, H, D = self.inner_dim, self.heads, self.dim_head
+        if context is None:
+            qk = ops.gemm(x, self._pk_qk())                 # [M, 2*inner]: q | k
+            vt = self.to_v.hip_t(x)                          # [inner, M]
+            o = ops.attention(qk, qk[:, Cd:], vt, B, H, N, N, D, self.scale, ldq=2 * Cd, ldk=2 * Cd,
+                              ldvt=B * N, q_bs=N * 2 * Cd, k_bs=N * 2 * Cd, vt_bs=N)
+        else:
+            q = self.to_q.hip(x)
+            k, vt = context.get(self)
+            if context.B != B:
+                raise ValueError(f"context batch {context.B} != activation batch {B}")
+            o = ops.attention(q, k, vt, B, H, N, context.Nk, D, self.scale, ldq=Cd, ldk=Cd,
+                              ldvt=B * context.Nkp, q_bs=N * Cd, k_bs=context.Nkp * Cd, vt_bs=context.Nkp)
+        return self.to_out[0].hip(o, res=res)
+
+    def forward(self, x, context=None, mask=None):
+        assert mask is None, "mask is not supported on the HIP path"
+        B, N, _ = x.shape
+        ctx = None if context is None else as_context_kv(context)
+        y = self.hip(x.to(torch.float16).reshape(B * N, -1), B, N, ctx)
+        return y.view(B, N, -1).to(x.dtype)
+
+
+class BasicTransformerBlock(nn.Module):
+    def __init__(self, dim, n_heads, d_head, dropout=0., context_dim=None, gated_ff=True, checkpoint=True,
+                 disable_self_attn=False):
+        super().__init__()
+        self.disable_self_attn = disable_self_attn
+        self.attn1 = CrossAttention(query_dim=dim, heads=n_heads, dim_head=d_head, dropout=dropout,
+                                    context_dim=context_dim if disable_self_attn else None)
+        self.ff = FeedForward(dim, dropout=dropout, glu=gated_ff)
+        self.attn2 = CrossAttention(query_dim=dim, context_dim=context_dim, heads=n_heads, dim_head=d_head,
+                                    dropout=dropout)
+        self.norm1 = L.LayerNorm(dim)
+        self.norm2 = L.LayerNorm(dim)
+        self.norm3 = L.LayerNorm(dim)
+        self.checkpoint = checkpoint  # inference only: never used
+
+    def hip(self, x, B, N, context):
+        x = self.attn1.hip(self.norm1.hip(x), B, N, context if self.disable_self_attn else None, res=x)
+        x = self.attn2.hip(self.norm2.hip(x), B, N, context, res=x)
+        x = self.ff.hip(self.norm3.hip(x), res=x)
+        return x
+
+    def forward(self, x, context=None):
+        B, N, _ = x.shape
+        y = self.hip(x.to(torch.float16).reshape(B * N, -1).contiguous(), B, N, as_context_kv(context))
+        return y.view(B, N, -1).to(x.dtype)
+
+
+class SpatialTransformer(nn.Module):
+    def __init__(self, in_channels, n_heads, d_head, depth=1, dropout=0., context_dim=None,
+                 disable_self_attn=False, use_linear=False, use_checkpoint=True):
+        super().__init__()
+        if exists(context_dim) and not isinstance(context_dim, (list, tuple)):
+            context_dim = [context_dim]
+        elif context_dim is None:
+            context_dim = [None] * depth
+        self.in_channels = in_channels
+        inner_dim = n_heads * d_head
+        self.norm = Normalize(in_channels)
+        self.use_linear = use_linear
+        if use_linear:
+            self.proj_in = L.Linear(in_channels, inner_dim)
+        else:
+            self.proj_in = L.Conv2d(in_channels, inner_dim, kernel_size=1, stride=1, padding=0)
+        self.transformer_blocks = nn.ModuleList([
+            BasicTransformerBlock(inner_dim, n_heads, d_head, dropout=dropout, context_dim=context_dim[d],
+                                  disable_self_attn=disable_self_attn, checkpoint=use_checkpoint)
+            for d in range(depth)])
+        if use_linear:
+            self.proj_out = L.Linear(in_channels, inner_dim)
+        else:
+            self.proj_out = L.Conv2d(inner_dim, in_channels, kernel_size=1, stride=1, padding=0)
+        for p in self.proj_out.parameters():  # zero-initialised in the reference (attention.py:343-347)
+            p.detach().zero_()
+
+    def hip(self, x, context=None):
+        """x: NHWC fp16 [B,H,W,C]; context: ContextKV | None"""
+        B, H, W_, Cc = x.shape
+        N = H * W_
+        h = self.proj_in.hip(self.norm.hip(x)).view(B * N, -1)
+        for blk in self.transformer_blocks:
+            h = blk.hip(h, B, N, context)
+        return self.proj_out.hip(h.view(B, H, W_, -1), res=x)
+
+    def forward(self, x, context=None):
+        y = self.hip(ops.to_nhwc(x), as_context_kv(context))
+        return ops.to_nchw(y, x.dtype)

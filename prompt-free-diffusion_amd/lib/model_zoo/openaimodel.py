@@ -1,0 +1,343 @@
+"""SD-v1.5 UNet (split time_embed / data_blocks / context_blocks form) on the HIP path.
+
+Mirrors the live part of the reference's lib/model_zoo/openaimodel.py: `UNetModel2D_Next`
+(:2575-2812, registered as 'openai_unet_2d_next'), `ResBlock` (:162-274), `Downsample`
+(:133-159), `Upsample` (:89-117), `TimestepEmbedSequential` (:72-86) -- same constructor
+kwargs, same module tree and state-dict keys, same `i_order/m_order/o_order` lists that
+`PromptFreeDiffusion.apply_model` walks (pfd.py:328-363).  The legacy UNets in that file
+(:277-2570, :2814-2975) are not instantiated by any shipped config and are out of scope.
+
+What differs is everything numerical: activations are NHWC fp16; GroupNorm+SiLU is one fused
+kernel that reads the skip-connection concat virtually (two source pointers, no torch.cat,
+pfd.py:356); convolutions are MFMA implicit GEMMs with bias, the per-sample time-embedding
+vector (`h + emb_out`, :272), the residual (`skip_connection(x) + h`, :274) and nearest-2x
+upsampling (:114) fused into their prologue/epilogue.
+"""
+import copy
+from functools import partial
+
+import torch
+import torch.nn as nn
+
+from ..hip import layers as L
+from ..hip import ops
+from .attention import SpatialTransformer, as_context_kv
+from .common.get_model import register
+
+symbol = 'openai'
+
+
+def normalization(channels):
+    """GroupNorm32(32, C), eps 1e-5 (reference diffusion_utils.py:175-191)"""
+    return L.GroupNorm(32, channels)
+
+
+def timestep_embedding(timesteps, dim, max_period=10000, repeat_only=False):
+    """[N] int -> [N, dim] fp16 sinusoidal embedding (cos half first), fp32 math on device."""
+    if repeat_only:
+        return timesteps[:, None].to(torch.float16).repeat(1, dim)
+    return ops.timestep_embedding(timesteps, dim, float(max_period))
+
+
+class TimestepBlock(nn.Module):
+    """marker: forward takes (x, emb)"""
+
+
+class TimestepEmbedSequential(nn.Sequential, TimestepBlock):
+    """Children get the time embedding / the context according to their kind."""
+
+    def hip(self, x, semb, context=None, x2=None):
+        for layer in self:
+            if isinstance(layer, ResBlock):
+                x, x2 = layer.hip(x, semb, x2=x2), None
+            elif isinstance(layer, SpatialTransformer):
+                x = layer.hip(x, context)
+            elif isinstance(layer, nn.Sequential):  # UNet head: GN -> SiLU -> conv
+                x = layer[2].hip(layer[0].hip(x, silu=True))
+            elif isinstance(layer, nn.SiLU):
+                x = ops.activation(x, ops.ACT_SILU)
+            else:
+                x = layer.hip(x)
+        return x
+
+    def forward(self, x, emb, context=None):
+        semb = ops.activation(emb.to(torch.float16).contiguous(), ops.ACT_SILU) if emb is not None else None
+        y = self.hip(ops.to_nhwc(x), semb, as_context_kv(context))
+        return ops.to_nchw(y, x.dtype)
+
+
+class Upsample(nn.Module):
+    """nearest 2x then (optionally) conv3x3 -- the gather is inside the conv's A-operand load"""
+
+    def __init__(self, channels, use_conv, dims=2, out_channels=None, padding=1):
+        super().__init__()
+        assert dims == 2
+        self.channels = channels
+        self.out_channels = out_channels or channels
+        self.use_conv = use_conv
+        if use_conv:
+            self.conv = L.Conv2d(self.channels, self.out_channels, 3, padding=padding)
+
+    def hip(self, x):
+        assert x.shape[-1] == self.channels
+        if not self.use_conv:
+            raise NotImplementedError("Upsample without conv is not on the hot path")
+        return self.conv.hip(x, ups=True)
+
+    def forward(self, x):
+        return ops.to_nchw(self.hip(ops.to_nhwc(x)), x.dtype)
+
+
+class Downsample(nn.Module):
+    def __init__(self, channels, use_conv, dims=2, out_channels=None, padding=1):
+        super().__init__()
+        assert dims == 2 and use_conv, "only the strided-conv form is on the hot path"
+        self.channels = channels
+        self.out_channels = out_channels or channels
+        self.use_conv = use_conv
+        self.op = L.Conv2d(self.channels, self.out_channels, 3, stride=2, padding=padding)
+
+    def hip(self, x):
+        assert x.shape[-1] == self.channels
+        return self.op.hip(x)
+
+    def forward(self, x):
+        return ops.to_nchw(self.hip(ops.to_nhwc(x)), x.dtype)
+
+
+class ResBlock(TimestepBlock):
+    def __init__(self, channels, emb_channels, dropout, out_channels=None, use_conv=False,
+                 use_scale_shift_norm=False, dims=2, use_checkpoint=False, up=False, down=False):
+        super().__init__()
+        assert dims == 2 and not use_scale_shift_norm and not up and not down, \
+            "configuration outside the SD-v1.5 / ControlNet hot path"
+        self.channels = channels
+        self.emb_channels = emb_channels
+        self.dropout = dropout
+        self.out_channels = out_channels or channels
+        self.use_conv = use_conv
+        self.use_checkpoint = use_checkpoint
+        self.use_scale_shift_norm = use_scale_shift_norm
+        self.updown = False
+        self.in_layers = nn.Sequential(
+            normalization(channels), nn.SiLU(), L.Conv2d(channels, self.out_channels, 3, padding=1))
+        self.h_upd = self.x_upd = nn.Identity()
+        self.emb_layers = nn.Sequential(nn.SiLU(), L.Linear(emb_channels, self.out_channels))
+        out_conv = L.Conv2d(self.out_channels, self.out_channels, 3, padding=1)
+        for p in out_conv.parameters():  # zero_module in the reference (:228-230)
+            p.detach().zero_()
+        self.out_layers = nn.Sequential(
+            normalization(self.out_channels), nn.SiLU(), nn.Dropout(p=dropout), out_conv)
+        if self.out_channels == channels:
+            self.skip_connection = nn.Identity()
+        elif use_conv:
+            self.skip_connection = L.Conv2d(channels, self.out_channels, 3, padding=1)
+        else:
+            self.skip_connection = L.Conv2d(channels, self.out_channels, 1)
+
+    def hip(self, x, semb, x2=None):
+        """x (and optional x2, the skip tensor of a virtual channel concat [x | x2]): NHWC fp16;
+        semb: SiLU(time embedding) [B, emb_channels] fp16."""
+        C1 = x.shape[-1]
+        C2 = 0 if x2 is None else x2.shape[-1]
+        assert C1 + C2 == self.channels
+        hn = self.in_layers[0].hip(x, x2, silu=True)                      # [B,H,W,C1+C2]
+        e = self.emb_layers[1].hip(semb)                                   # [B, Cout]
+        h = self.in_layers[2].hip(hn, rowvec=e)                            # conv + bias + emb
+        h = self.out_layers[0].hip(h, silu=True)
+        skip = self.skip_connection
+        if isinstance(skip, nn.Identity):
+            assert x2 is None
+            sk = x
+        elif skip.kernel_size[0] == 1:
+            w, b = skip._pk()
+            B, H, W_, _ = x.shape
+            sk = ops.gemm(x.view(-1, C1), w[:, :C1], bias=b, k=C1)
+            if x2 is not None:
+                sk = ops.gemm(x2.view(-1, C2), w[:, C1:], res=sk, k=C2, out=sk)
+            sk = sk.view(B, H, W_, -1)
+        else:
+            assert x2 is None
+            sk = skip.hip(x)
+        return self.out_layers[3].hip(h, res=sk)
+
+    def forward(self, x, emb):
+        semb = ops.activation(emb.to(torch.float16).contiguous(), ops.ACT_SILU)
+        return ops.to_nchw(self.hip(ops.to_nhwc(x), semb), x.dtype)
+
+
+@register('openai_unet_2d_next')
+class UNetModel2D_Next(nn.Module):
+    def __init__(self, in_channels, model_channels, out_channels, num_res_blocks, attention_resolutions,
+                 context_dim, dropout=0, channel_mult=(1, 2, 4, 8), conv_resample=True, use_checkpoint=False,
+                 num_heads=8, num_head_channels=None, parts=['global', 'data', 'context']):
+        super().__init__()
+        self.in_channels = in_channels
+        self.model_channels = model_channels
+        self.out_channels = out_channels
+        if isinstance(num_res_blocks, int):
+            num_res_blocks = len(channel_mult) * [num_res_blocks]
+        elif len(num_res_blocks) != len(channel_mult):
+            raise ValueError("provide num_res_blocks either as an int (globally constant) or "
+                             "as a list/tuple (per-level) with the same length as channel_mult")
+        self.num_res_blocks = num_res_blocks
+        self.attention_resolutions = attention_resolutions
+        self.context_dim = context_dim
+        self.dropout = dropout
+        self.channel_mult = channel_mult
+        self.conv_resample = conv_resample
+        self.use_checkpoint = use_checkpoint
+        self.num_heads = num_heads
+        self.num_head_channels = num_head_channels
+        assert (num_heads is None) + (num_head_channels is None) == 1, \
+            "One of num_heads or num_head_channels need to be set"
+        self.parts = parts if isinstance(parts, list) else [parts]
+        self.glayer_included = 'global' in self.parts
+        self.dlayer_included = 'data' in self.parts
+        self.clayer_included = 'context' in self.parts
+
+        time_embed_dim = model_channels * 4
+        if self.glayer_included:
+            self.time_embed = nn.Sequential(
+                L.Linear(model_channels, time_embed_dim), nn.SiLU(), L.Linear(time_embed_dim, time_embed_dim))
+        if self.dlayer_included:
+            self.data_blocks = nn.ModuleList()
+        if self.clayer_included:
+            self.context_blocks = nn.ModuleList()
+
+        def res(cin, cout):
+            if not self.dlayer_included:
+                return None
+            return ResBlock(cin, time_embed_dim, dropout, out_channels=cout, dims=2,
+                            use_checkpoint=use_checkpoint, use_scale_shift_norm=False)
+
+        def xattn(ch):
+            if not self.clayer_included:
+                return None
+            d_head, n_heads = self.get_d_head_n_heads(ch)
+            return SpatialTransformer(ch, n_heads, d_head, context_dim=context_dim, disable_self_attn=False)
+
+        order = []
+        self._order = order
+
+        # ---- input half ----
+        self.add_data_layer(L.Conv2d(in_channels, model_channels, 3, padding=1) if self.dlayer_included else None)
+        order.append('save_hidden_feature')
+        skip_chans = [model_channels]
+        ch, ds = model_channels, 1
+        for level, mult in enumerate(channel_mult):
+            for _ in range(num_res_blocks[level]):
+                self.add_data_layer(res(ch, mult * model_channels))
+                ch = mult * model_channels
+                if ds in attention_resolutions:
+                    self.add_context_layer(xattn(ch))
+                skip_chans.append(ch)
+                order.append('save_hidden_feature')
+            if level != len(channel_mult) - 1:
+                self.add_data_layer(Downsample(ch, True, dims=2, out_channels=ch) if self.dlayer_included else None)
+                skip_chans.append(ch)
+                order.append('save_hidden_feature')
+                ds *= 2
+        self.i_order = list(order)
+        order.clear()
+
+        # ---- middle ----
+        self.add_data_layer(res(ch, ch))
+        self.add_context_layer(xattn(ch))
+        self.add_data_layer(res(ch, ch))
+        self.m_order = list(order)
+        order.clear()
+
+        # ---- output half ----
+        for level, mult in list(enumerate(channel_mult))[::-1]:
+            for _ in range(num_res_blocks[level] + 1):
+                order.append('load_hidden_feature')
+                self.add_data_layer(res(ch + skip_chans.pop(), model_channels * mult))
+                ch = model_channels * mult
+                if ds in attention_resolutions:
+                    self.add_context_layer(xattn(ch))
+            if level != 0:
+                self.add_data_layer(Upsample(ch, conv_resample, dims=2, out_channels=ch)
+                                    if self.dlayer_included else None)
+                ds //= 2
+        if self.dlayer_included:
+            head_conv = L.Conv2d(model_channels, out_channels, 3, padding=1)
+            for p in head_conv.parameters():  # zero_module in the reference (:2735)
+                p.detach().zero_()
+            head = nn.Sequential(normalization(ch), nn.SiLU(), head_conv)
+        else:
+            head = None
+        self.add_data_layer(head)
+        self.o_order = list(order)
+        self.layer_order = copy.deepcopy(self.i_order + self.m_order + self.o_order)
+        del self._order
+
+        self.parameter_group = {}
+        if self.glayer_included:
+            self.parameter_group['global'] = self.time_embed
+        if self.dlayer_included:
+            self.parameter_group['data'] = self.data_blocks
+        if self.clayer_included:
+            self.parameter_group['context'] = self.context_blocks
+
+    def get_d_head_n_heads(self, ch):
+        if self.num_head_channels is None:
+            return ch // self.num_heads, self.num_heads
+        return self.num_head_channels, ch // self.num_head_channels
+
+    def add_data_layer(self, layer):
+        if self.dlayer_included:
+            layers = layer if isinstance(layer, (list, tuple)) else [layer]
+            self.data_blocks.append(TimestepEmbedSequential(*layers))
+        self._order.append('d')
+
+    def add_context_layer(self, layer):
+        if self.clayer_included:
+            layers = layer if isinstance(layer, (list, tuple)) else [layer]
+            self.context_blocks.append(TimestepEmbedSequential(*layers))
+        self._order.append('c')
+
+    # -------------------------------------------------------------------------------------------
+    def silu_time_embedding(self, timesteps):
+        """SiLU(time_embed(timestep_embedding(t))) [B, 4*model_channels] fp16: every consumer of the
+        embedding (the 22 ResBlock emb_layers) applies SiLU first (:217), so only this is kept."""
+        t_emb = timestep_embedding(timesteps, self.model_channels)
+        h = self.time_embed[0].hip(t_emb, act=ops.ACT_SILU)
+        return self.time_embed[2].hip(h, act=ops.ACT_SILU)
+
+    def hip(self, x, timesteps, context, control=None, context_net=None):
+        """The forward that pfd.apply_model defines (pfd.py:314-365, :466-528), NHWC fp16 in/out.
+        control: list of 13 NHWC residuals from ControlNet (popped from the end) or None.
+        context_net: the UNet that owns the context blocks (defaults to self)."""
+        cnet = self if context_net is None else context_net
+        semb = self.silu_time_embedding(timesteps)
+        d_iter, c_iter = iter(self.data_blocks), iter(cnet.context_blocks)
+        ccs = list(control) if control is not None else None
+        hs = []
+        h = x
+        for ltype in self.i_order:
+            if ltype == 'd':
+                h = next(d_iter).hip(h, semb)
+            elif ltype == 'c':
+                h = next(c_iter).hip(h, semb, context)
+            else:
+                hs.append(h)
+        for ltype in self.m_order:
+            h = next(d_iter).hip(h, semb) if ltype == 'd' else next(c_iter).hip(h, semb, context)
+        if ccs is not None:
+            h = ops.add(h, ccs.pop())
+        skip = None
+        for ltype in self.o_order:
+            if ltype == 'load_hidden_feature':
+                skip = hs.pop()
+                if ccs is not None:
+                    skip = ops.add(skip, ccs.pop())
+            elif ltype == 'd':
+                h, skip = next(d_iter).hip(h, semb, x2=skip), None
+            else:
+                h = next(c_iter).hip(h, semb, context)
+        return h
+
+    def forward(self, x, timesteps, context):
+        y = self.hip(ops.to_nhwc(x), timesteps, as_context_kv(context))
+        return ops.to_nchw(y, x.dtype)
