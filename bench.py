@@ -1,0 +1,179 @@
+#!/usr/bin/env python
+"""Headline benchmark: images/s @512x512, 50-step DDIM (CFG 2.0), SD-v1.5 UNet + SeeCoder, fp16.
+
+One "step" = one pass of the whole hot path over one batch: SeeCoder encode of the reference
+image, 50 DDIM steps with classifier-free guidance (UNet batch 2B), AutoKL decode, and -- on
+N > 1 GPUs -- the one RCCL all-gather of the decoded images.  N=1 runs BASELINE.json configs[1]
+(batch 4); N>1 keeps 4 images per GPU (weak scaling, global batch 4N; configs[3] is the 8-GPU
+point of the same family).  Synthetic data, synthetic weights of the exact architecture (no
+checkpoints / datasets in the environment).
+
+  python bench.py [--gpus N --steps K --warmup W]          (N>1: launched by torch.distributed.run)
+
+Prints ONE JSON line (rank 0).  `roofline` is measured live: HIP-event pairs around every launch
+of the dominant kernel on its launch stream during the timed region (libpfd_hip's pfd_prof_*).
+`cpu_baseline` times the CPU oracle (a port of the reference's algorithm, oracle/pfd_oracle.py)
+on a bounded sample of the same workload on this host's cores.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+for p in (os.path.join(REPO, "prompt-free-diffusion_amd"), os.path.join(REPO, "oracle")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+os.environ.setdefault("PFD_QUIET", "1")
+
+MFMA_PEAK_TFLOPS = 2500.0   # dense fp16, MI355X_MICROARCH.md
+HBM_PEAK_GBS = 8000.0
+
+
+def cpu_baseline(net, height, width, ddim_steps, scale):
+    """oracle on the host cores: 1 SeeCoder encode + 1 CFG UNet step (batch 2) + 1 VAE decode for ONE
+    image, extrapolated to the 50-step schedule (every step costs the same)."""
+    import torch
+    import pfd_oracle as O
+    threads = torch.get_num_threads()
+    sd = {k: v.detach().float().cpu() for k, v in net.state_dict().items()
+          if k.startswith(("diffuser.image.", "vae.image.", "ctx.image."))}
+    g = torch.Generator().manual_seed(1234)
+    img = torch.rand((1, 3, height, width), generator=g)
+    with torch.no_grad():
+        t0 = time.perf_counter()
+        ctx = O.seecoder_encode(sd, "ctx.image.", img)
+        t1 = time.perf_counter()
+        x = torch.randn((1, 4, height // 8, width // 8), generator=g)
+        tt = torch.tensor([981])
+        eps_fn = lambda xx, ttt, cc: O.unet_apply(sd, "diffuser.image.", xx, ttt, cc)  # noqa: E731
+        x, _ = O.ddim_step(eps_fn, x, tt, ctx, torch.zeros_like(ctx), scale, 0.5, 0.6, 0.0)
+        t2 = time.perf_counter()
+        O.vae_decode(sd, "vae.image.", x)
+        t3 = time.perf_counter()
+    t_ctx, t_step, t_vae = t1 - t0, t2 - t1, t3 - t2
+    per_image = t_ctx + ddim_steps * t_step + t_vae
+    return {"value": 1.0 / per_image, "unit": "images/s", "cores": threads, "kind": "port",
+            "sample": f"1 image {height}x{width}: SeeCoder encode {t_ctx:.2f}s + 1 CFG UNet step (batch 2) "
+                      f"{t_step:.2f}s x{ddim_steps} (extrapolated) + VAE decode {t_vae:.2f}s, fp32 torch CPU"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--batch", type=int, default=4, help="images per GPU")
+    ap.add_argument("--height", type=int, default=512)
+    ap.add_argument("--width", type=int, default=512)
+    ap.add_argument("--ddim-steps", type=int, default=50)
+    ap.add_argument("--scale", type=float, default=2.0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-prof", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch N>1 with: python -m torch.distributed.run --nnodes=1 --nproc-per-node N "
+                             "--master-addr 127.0.0.1 --master-port P bench.py --gpus N ...")
+    torch.cuda.set_device(local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world)  # "nccl" == RCCL on ROCm
+
+    from lib.hip import binding
+    from lib.pipeline import PromptFreePipeline, build_model
+    net = build_model('pfd_seecoder', device=f'cuda:{local}', fp16=True)
+    pipe = PromptFreePipeline(net, rank=rank, world_size=world)
+    image = torch.rand((1, 3, args.height, args.width), generator=torch.Generator().manual_seed(1234))
+    n_global = args.batch * world
+
+    def step(i):
+        img, _ = pipe.generate(image, n_global, args.height, args.width, steps=args.ddim_steps, scale=args.scale,
+                               eta=0.0, seed=20 + i, gather=True)
+        return img
+
+    for i in range(args.warmup):
+        step(i)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    barrier()
+    if not args.no_prof:
+        binding.prof_enable(True)
+    t0 = time.perf_counter()
+    out = None
+    for i in range(args.steps):
+        out = step(100 + i)
+    torch.cuda.synchronize()
+    barrier()
+    dt = time.perf_counter() - t0
+    prof = binding.prof_read() if not args.no_prof else []
+    binding.prof_enable(False)
+    if world > 1:
+        tmax = torch.tensor([dt], device='cuda', dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+    assert out is not None and out.shape[0] == n_global and bool(torch.isfinite(out).all())
+
+    if rank == 0:
+        ddim_real = len(pipe.sampler.ddim_timesteps)
+        res = {
+            "metric": "images/sec @512x512 50-step DDIM, SD-v1.5+SeeCoder",
+            "value": n_global * args.steps / dt,
+            "unit": "images/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f16", "data": "synthetic",
+            "config": {"workload": f"SD-v1.5 UNet + seecoder-v1-0, {args.height}x{args.width}, "
+                                   f"{args.ddim_steps}-step DDIM ({ddim_real} real steps), CFG {args.scale}, fp16, "
+                                   f"batch={args.batch}/GPU, 1 SeeCoder encode + VAE decode per batch",
+                       "global_batch": n_global, "parallelism": f"dp{world}"},
+        }
+        if prof:
+            top = max(prof, key=lambda b: b["ms"])
+            mfma = top["name"].startswith(("gemm", "attention", "swin"))
+            secs = top["ms"] / 1e3
+            if mfma:
+                ach = top["flops"] / secs / 1e12
+                res["roofline"] = {"bound": "mfma", "achieved": ach, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                   "frac": ach / MFMA_PEAK_TFLOPS}
+            else:
+                ach = top["bytes"] / secs / 1e9
+                res["roofline"] = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                   "frac": ach / HBM_PEAK_GBS}
+            pmc = os.path.join(REPO, "profiles", "pmc_traffic.json")
+            traffic = None
+            if os.path.exists(pmc):
+                try:
+                    traffic = json.load(open(pmc)).get(top["name"])
+                except Exception:
+                    traffic = None
+            res["roofline"].update({"traffic": traffic, "kernel": top["name"], "launches": top["launches"],
+                                    "avg_launch_ms": top["ms"] / top["launches"],
+                                    "alg_flops_per_launch": top["flops"] / top["launches"],
+                                    "alg_bytes_per_launch": top["bytes"] / top["launches"]})
+            tot = sum(b["ms"] for b in prof)
+            res["kernel_time_ms_per_step"] = {b["name"]: round(b["ms"] / args.steps, 3) for b in prof}
+            res["kernel_tflops"] = {b["name"]: round(b["flops"] / (b["ms"] / 1e3) / 1e12, 1) for b in prof
+                                    if b["flops"] > 0 and b["ms"] > 0}
+            res["instrumented_kernel_ms_per_step"] = tot / args.steps
+        if world == 1 and not args.no_cpu_baseline:
+            res["cpu_baseline"] = cpu_baseline(net, args.height, args.width, ddim_real, args.scale)
+        print(json.dumps(res))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -218,6 +218,19 @@ int pfd_add_rowvec_f16(const void* x, int64_t ldx, const void* v, void* y, int64
  * time embedding, and nonlinearity() on its own (autokl_modules.py:33-35). */
 int pfd_act_f16(const void* x, void* y, int64_t n, int32_t act, pfd_stream_t stream);
 
+/* ------------------------------------------------------------------------------------
+ * Measurement hooks (no reference counterpart: the reference has no profiling).
+ * pfd_prof_enable(1) resets the counters and makes the GEMM/conv, attention and GroupNorm
+ * entry points bracket their kernel with a HIP event pair on the launch stream;
+ * pfd_prof_read waits for outstanding events and returns, for one kernel bucket, the summed
+ * kernel time [ms], launch count and the ALGORITHMIC flops / HBM bytes of those launches
+ * (2MNK; operands and result once).  Not for use under hipGraph capture.
+ * ---------------------------------------------------------------------------------- */
+int pfd_prof_enable(int32_t on);
+int pfd_prof_read(int32_t bucket, double* ms, int64_t* launches, double* flops, double* bytes);
+const char* pfd_prof_bucket_name(int32_t bucket);
+int pfd_prof_num_buckets(void);
+
 #ifdef __cplusplus
 }
 #endif

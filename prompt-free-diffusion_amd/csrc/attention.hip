@@ -195,7 +195,12 @@ __global__ __launch_bounds__(256) void attention_kernel(const AttnParams p) {
 template <int D>
 int launch(const AttnParams& p, hipStream_t s) {
   dim3 grid((p.Nq + 127) / 128, p.H, p.B);
+  const bool prof = pfd_prof_on();
+  if (prof)
+    pfd_prof_begin(8, 4.0 * p.B * p.H * (double)p.Nq * p.Nk * D,
+                   2.0 * p.B * p.H * D * (2.0 * p.Nq + 2.0 * p.Nk), s);
   hipLaunchKernelGGL((attention_kernel<D>), grid, dim3(256), 0, s, p);
+  if (prof) pfd_prof_end(s);
   return pfd_check_launch("pfd_attention_f16");
 }
 

@@ -275,10 +275,19 @@ int launch(const GemmParams& p0, hipStream_t s) {
   p.tiles_m = (p.M + C_::BM - 1) / C_::BM;
   p.tiles_n = (p.N + C_::BN - 1) / C_::BN;
   const int grid = p.tiles_m * p.tiles_n;
+  const bool prof = pfd_prof_on();
+  if (prof) {
+    // algorithmic work of this launch: 2MNK flops; bytes = A read once + W read once + C written
+    // (+ residual read); for the implicit conv, A is the input image read once (not 9x)
+    const double a_bytes = p.ksize > 0 ? 2.0 * p.B * p.H * p.Wd * p.Cin : 2.0 * p.M * p.K;
+    const double bytes = a_bytes + 2.0 * p.N * p.K + 2.0 * p.M * p.N * (p.R ? 2 : 1);
+    pfd_prof_begin((TM - 1) * 2 + (TN - 1) + (p.ksize > 0 ? 4 : 0), 2.0 * p.M * p.N * p.K, bytes, s);
+  }
   if (p.ksize > 0)
     hipLaunchKernelGGL((gemm_conv_kernel<TM, TN, true>), dim3(grid), dim3(256), 0, s, p);
   else
     hipLaunchKernelGGL((gemm_conv_kernel<TM, TN, false>), dim3(grid), dim3(256), 0, s, p);
+  if (prof) pfd_prof_end(s);
   return pfd_check_launch("pfd_gemm_f16");
 }
 

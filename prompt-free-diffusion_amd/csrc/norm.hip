@@ -310,11 +310,14 @@ extern "C" int pfd_groupnorm_f16(const void* x1, int32_t C1, int64_t ldx1, const
   nchunks = (HW + rpc - 1) / rpc;
   float* partial = (float*)ws;
   float* stats = partial + (size_t)B * GN_MAX_CHUNKS * GN_MAX_G * 2;
+  const bool prof = pfd_prof_on();
+  if (prof) pfd_prof_begin(10, 8.0 * B * HW * C, 6.0 * B * HW * C, s);  // 2B stats read + 2B read + 2B write
   hipLaunchKernelGGL(gn_stats_kernel, dim3(nchunks, B), dim3(256), 0, s, src, HW, G, rpc, partial);
   hipLaunchKernelGGL(gn_finalize_kernel, dim3(B), dim3(64), 0, s, partial, nchunks, G,
                      (float)HW * (float)(C / G), eps, stats);
   hipLaunchKernelGGL(gn_apply_kernel, dim3(nchunks, B), dim3(256), 0, s, src, (const half_t*)gamma,
                      (const half_t*)beta, stats, (half_t*)y, (long)ldy, HW, G, rpc, act);
+  if (prof) pfd_prof_end(s);
   return pfd_check_launch("pfd_groupnorm_f16");
 }
 

@@ -54,6 +54,12 @@ __device__ __forceinline__ int xcd_remap(int bid, int nblk) {
   return start + idx;
 }
 
+// optional per-launch event timing (capi.hip); buckets: 0-7 gemm <TM,TN,CONV>, 8 attention,
+// 9 swin attention, 10 groupnorm, 11 layernorm
+bool pfd_prof_on();
+void pfd_prof_begin(int bucket, double flops, double bytes, hipStream_t stream);
+void pfd_prof_end(hipStream_t stream);
+
 // host-side error plumbing (defined in capi.cpp)
 int pfd_check_launch(const char* what);
 void pfd_set_error(const char* msg);

@@ -71,6 +71,11 @@ SIGNATURES = {
     "pfd_add_f16": (_i32, [_vp, _vp, _vp, _i64, _vp]),
     "pfd_add_rowvec_f16": (_i32, [_vp, _i64, _vp, _vp, _i64, _i32, _i32, _vp]),
     "pfd_act_f16": (_i32, [_vp, _vp, _i64, _i32, _vp]),
+    "pfd_prof_enable": (_i32, [_i32]),
+    "pfd_prof_read": (_i32, [_i32, C.POINTER(C.c_double), C.POINTER(_i64), C.POINTER(C.c_double),
+                             C.POINTER(C.c_double)]),
+    "pfd_prof_bucket_name": (C.c_char_p, [_i32]),
+    "pfd_prof_num_buckets": (_i32, []),
 }
 
 
@@ -113,3 +118,20 @@ def check(rc, what):
     if rc != 0:
         msg = load().pfd_last_error().decode(errors="replace")
         raise PfdError(f"{what} failed: {_ERR.get(rc, rc)} {msg}")
+
+
+def prof_enable(on=True):
+    check(load().pfd_prof_enable(1 if on else 0), "pfd_prof_enable")
+
+
+def prof_read():
+    """[{name, ms, launches, flops, bytes}] for every bucket that saw a launch"""
+    lib = load()
+    out = []
+    for b in range(lib.pfd_prof_num_buckets()):
+        ms, n, fl, by = C.c_double(), _i64(), C.c_double(), C.c_double()
+        check(lib.pfd_prof_read(b, C.byref(ms), C.byref(n), C.byref(fl), C.byref(by)), "pfd_prof_read")
+        if n.value:
+            out.append(dict(bucket=b, name=lib.pfd_prof_bucket_name(b).decode(), ms=ms.value, launches=n.value,
+                            flops=fl.value, bytes=by.value))
+    return out

@@ -138,9 +138,16 @@ class CrossAttention(nn.Module, L._Packed):
         Cd, H, D = self.inner_dim, self.heads, self.dim_head
         if context is None:
             qk = ops.gemm(x, self._pk_qk())                 # [M, 2*inner]: q | k
-            vt = self.to_v.hip_t(x)                          # [inner, M]
+            if N % 8 == 0:
+                Np = N
+                vt = self.to_v.hip_t(x)                      # [inner, B*N]
+            else:  # odd token counts (tiny latents): pad every sample's V^T rows to 16-byte multiples
+                Np = (N + 7) // 8 * 8
+                vt = torch.zeros((Cd, B * Np), dtype=torch.float16, device=x.device)
+                for b in range(B):
+                    self.to_v.hip_t(x[b * N:(b + 1) * N], out=vt[:, b * Np:b * Np + N])
             o = ops.attention(qk, qk[:, Cd:], vt, B, H, N, N, D, self.scale, ldq=2 * Cd, ldk=2 * Cd,
-                              ldvt=B * N, q_bs=N * 2 * Cd, k_bs=N * 2 * Cd, vt_bs=N)
+                              ldvt=B * Np, q_bs=N * 2 * Cd, k_bs=N * 2 * Cd, vt_bs=Np)
         else:
             q = self.to_q.hip(x)
             k, vt = context.get(self)

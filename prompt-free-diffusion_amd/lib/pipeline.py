@@ -1,0 +1,102 @@
+"""Request front-end of the hot path: reference image -> SeeCoder context -> DDIM/CFG loop ->
+VAE decode, for one rank's shard of a (possibly multi-GPU) batch.
+
+Restates the arithmetic-free glue of the reference's `prompt_free_diffusion.action_inference`
+(app.py:229-274): ctx = ctx_encode(image).repeat(n); uncond = zeros_like(ctx) (or a padded fixed
+tensor for SeeCoder-Anime, app.py:236-241); x_T ~ N(0, 1) of shape [n, 4, H/8, W/8];
+DDIMSampler.sample(steps, eta, CFG scale, optional control); vae_decode.  The Gradio UI itself
+is out of scope.
+
+Multi-GPU (new, the reference is single-device): samples are independent, so rank r of P takes
+samples [r*n/P, (r+1)*n/P) of the global batch.  x_T is drawn ONCE for the global shape from a
+CPU generator and sliced, so results do not depend on P.  The only collective is one RCCL
+all-gather of the decoded images after the loop (`gather=True`).
+"""
+import torch
+
+
+def build_model(name='pfd_seecoder', device='cuda', fp16=True, randomize_zero_init=True, seed=0, verbose=False):
+    """Construct a composite from the config bank with synthetic weights (no checkpoints exist in
+    the build/bench environment): default initialisation, plus re-randomised zero-initialised
+    tensors so that no branch of the network is multiplied by zero."""
+    from .cfg_helper import model_cfg_bank
+    from .model_zoo import get_model
+    cfg = model_cfg_bank()(name)
+    cfg.args.vae_cfg_list[0][1].pth = None  # checkpoint not available: synthetic weights
+    torch.manual_seed(seed)
+    if device != 'cpu' and torch.cuda.is_available():
+        with torch.device(device):
+            net = get_model()(cfg, verbose=verbose)
+    else:
+        net = get_model()(cfg, verbose=verbose)
+    if randomize_zero_init:
+        g = torch.Generator(device='cpu').manual_seed(seed + 1)
+        with torch.no_grad():
+            for p in net.parameters():
+                if p.is_floating_point() and p.numel() > 0 and float(p.detach().abs().max()) == 0.0:
+                    fan_in = max(1, p.numel() // p.shape[0]) if p.dim() > 1 else 1
+                    std = fan_in ** -0.5 if p.dim() > 1 else 0.02
+                    p.copy_((torch.randn(p.shape, generator=g) * std).to(p.device, p.dtype))
+    if fp16:
+        net.half()
+    net.to(device)
+    net.eval()
+    return net
+
+
+def shard_xT(n_global, height, width, seed, rank, world_size):
+    """rank's slice of the x_T drawn once for the GLOBAL batch (CPU generator => independent of P)"""
+    assert n_global % world_size == 0, "global batch must divide over the ranks"
+    n = n_global // world_size
+    g = torch.Generator(device='cpu').manual_seed(seed)
+    return torch.randn([n_global, 4, height // 8, width // 8], generator=g)[rank * n:(rank + 1) * n]
+
+
+def all_gather_batch(local, world_size):
+    """the one collective of the path: concatenate every rank's shard in rank order"""
+    if world_size == 1:
+        return local
+    import torch.distributed as dist
+    out = [torch.empty_like(local) for _ in range(world_size)]
+    dist.all_gather(out, local.contiguous())  # RCCL over xGMI on the GPU box; gloo in the CPU tests
+    return torch.cat(out, 0)
+
+
+class PromptFreePipeline:
+    def __init__(self, net, rank=0, world_size=1):
+        from .model_zoo.ddim import DDIMSampler
+        self.net = net
+        self.sampler = DDIMSampler(net)
+        self.rank, self.world_size = rank, world_size
+
+    @torch.no_grad()
+    def encode_reference(self, image, n):
+        """image: [1,3,H,W] in [0,1] -> (cond [n,148,768], uncond zeros), app.py:234-236"""
+        c = self.net.ctx_encode(image, 'image')
+        cond = c.repeat(n, 1, 1)
+        return cond, torch.zeros_like(cond)
+
+    @torch.no_grad()
+    def generate(self, image, n_global, height, width, steps=50, scale=2.0, eta=0.0, seed=20, control=None,
+                 uncond=None, decode=True, gather=False, verbose=False):
+        """returns (images [n_local|n_global, 3, H, W] in [0,1] or latents, latents [n_local,4,h,w])"""
+        P, r = self.world_size, self.rank
+        xT = shard_xT(n_global, height, width, seed, r, P)
+        n = xT.shape[0]
+        dev = self.net.device
+        cond, zeros = self.encode_reference(image.to(dev), n)
+        if uncond is None:
+            uncond = zeros
+        x_info = {'type': 'image', 'xt': xT.to(dev)}
+        c_info = {'type': 'image', 'conditioning': cond, 'unconditional_conditioning': uncond,
+                  'unconditional_guidance_scale': scale}
+        if control is not None:
+            c_info['control'] = control.to(dev)
+        x, _ = self.sampler.sample(steps=steps, shape=list(xT.shape), x_info=x_info, c_info=c_info, eta=eta,
+                                   verbose=verbose)
+        if not decode:
+            return x, x
+        img = self.net.vae_decode(x, 'image')
+        if gather:
+            img = all_gather_batch(img, P)
+        return img, x

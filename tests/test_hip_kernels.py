@@ -1,0 +1,122 @@
+"""GPU (-m gpu): individual C-ABI entry points against plain fp32 torch formulas (these are
+floating-point kernels), including the ragged / edge shapes the path produces."""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def _dev(*shape, scale=1.0, seed=0):
+    g = torch.Generator().manual_seed(seed + sum(shape))
+    return (torch.randn(shape, generator=g) * scale).half().cuda()
+
+
+def close(a, ref, tol=1e-2):
+    e = float((a.float().cpu() - ref.float().cpu()).abs().max() / max(1.0, float(ref.abs().max())))
+    assert e <= tol, e
+    return e
+
+
+@pytest.mark.parametrize("M,N,K", [(1, 320, 1280), (8, 1280, 320), (301, 200, 192), (4096, 640, 320), (148, 768, 768)])
+def test_gemm_bias_act_residual(M, N, K):
+    from lib.hip import ops
+    a, w, b, r = _dev(M, K), _dev(N, K, scale=K ** -0.5), _dev(N), _dev(M, N)
+    y = ops.gemm(a, w, bias=b, res=r, act=ops.ACT_SILU)
+    ref = F.silu(a.float() @ w.float().t() + b.float()) + r.float()
+    close(y, ref)
+
+
+def test_gemm_geglu_and_strided_views():
+    from lib.hip import ops
+    from lib.model_zoo.attention import GEGLU
+    m = GEGLU(320, 1280).half().cuda()
+    x = _dev(77, 320)
+    y = m.hip(x)
+    h = F.linear(x.float(), m.proj.weight.float(), m.proj.bias.float())
+    a, g = h.chunk(2, -1)
+    close(y, a * F.gelu(g))
+    # A operand = column slice of a wider matrix, W = column slice (two-source 1x1 skip conv)
+    big, w = _dev(50, 640), _dev(96, 640, scale=0.05)
+    y = ops.gemm(big[:, 320:], w[:, 320:], k=320)
+    close(y, big[:, 320:].float() @ w[:, 320:].float().t())
+
+
+@pytest.mark.parametrize("cin,cout,k,s,ups,hw", [(64, 96, 3, 1, False, (9, 7)), (128, 64, 3, 2, False, (10, 8)),
+                                                  (64, 64, 3, 1, True, (5, 6)), (4, 320, 3, 1, False, (8, 8)),
+                                                  (3, 192, 4, 4, False, (10, 13)), (320, 4, 3, 1, False, (8, 8))])
+def test_conv_layers(cin, cout, k, s, ups, hw):
+    from lib.hip import layers as L
+    from lib.hip import ops
+    torch.manual_seed(1)
+    pad = 0 if k == 4 else 1
+    conv = L.Conv2d(cin, cout, k, stride=s, padding=pad).half().cuda()
+    x = _dev(2, cin, *hw)
+    xin = ops.to_nhwc(x)
+    if k == 4:  # patch-embed: right/bottom zero pad to a multiple of 4
+        H, W = hw
+        y = conv.hip(xin, out_hw=((H + 3) // 4, (W + 3) // 4))
+        xr = F.pad(x.float(), (0, (4 - W % 4) % 4, 0, (4 - H % 4) % 4))
+    else:
+        y = conv.hip(xin, ups=ups)
+        xr = F.interpolate(x.float(), scale_factor=2, mode="nearest") if ups else x.float()
+    ref = F.conv2d(xr, conv.weight.float(), conv.bias.float(), stride=s, padding=pad)
+    close(ops.to_nchw(y, torch.float32), ref)
+
+
+def test_groupnorm_concat_and_layernorm():
+    from lib.hip import ops
+    x1, x2 = _dev(2, 6, 5, 320), _dev(2, 6, 5, 640, seed=3)
+    g, b = _dev(960, scale=0.2) + 1, _dev(960, scale=0.1)
+    y = ops.groupnorm(x1, g, b, 32, 1e-5, x2=x2, silu=True)
+    cat = torch.cat([x1, x2], -1).float().permute(0, 3, 1, 2)
+    ref = F.silu(F.group_norm(cat, 32, g.float(), b.float(), 1e-5)).permute(0, 2, 3, 1)
+    close(y, ref)
+    t = _dev(37, 1536)
+    g, b = _dev(1536, scale=0.2) + 1, _dev(1536, scale=0.1)
+    close(ops.layernorm(t, g, b), F.layer_norm(t.float(), (1536,), g.float(), b.float()))
+
+
+@pytest.mark.parametrize("B,H,Nq,Nk,D", [(2, 8, 64, 64, 160), (2, 8, 300, 148, 40), (1, 8, 144, 1000, 96),
+                                          (1, 8, 148, 148, 96), (3, 8, 256, 256, 80)])
+def test_attention(B, H, Nq, Nk, D):
+    from lib.hip import ops
+    Cd = H * D
+    q, k, v = _dev(B, Nq, Cd), _dev(B, Nk, Cd, seed=1), _dev(B, Nk, Cd, seed=2)
+    Nkp = (Nk + 7) // 8 * 8
+    vt = torch.zeros((Cd, B, Nkp), dtype=torch.float16, device='cuda')
+    vt[:, :, :Nk] = v.permute(2, 0, 1)
+    o = ops.attention(q, k, vt, B, H, Nq, Nk, D, D ** -0.5, ldq=Cd, ldk=Cd, ldvt=B * Nkp, q_bs=Nq * Cd,
+                      k_bs=Nk * Cd, vt_bs=Nkp)
+    sp = lambda t: t.float().view(B, -1, H, D).permute(0, 2, 1, 3)  # noqa: E731
+    ref = ((sp(q) @ sp(k).transpose(-1, -2)) * D ** -0.5).softmax(-1) @ sp(v)
+    close(o.view(B, Nq, H, D), ref.permute(0, 2, 1, 3), 5e-3)
+
+
+def test_cfg_ddim_step_matches_formula():
+    from lib.hip import ops
+    B, C, h, w = 2, 4, 8, 8
+    eps = _dev(2 * B, h, w, C)
+    x = torch.randn(B, C, h, w, device='cuda')
+    noise = torch.randn(B, C, h, w, device='cuda')
+    a_t, a_prev, sig, scale = 0.4, 0.6, 0.1, 2.0
+    coef = torch.tensor([a_t, a_prev, sig, math.sqrt(1 - a_t), scale], device='cuda')
+    xp, p0, xin = ops.cfg_ddim_step(eps, 2, x, coef, noise=noise)
+    e = eps.float().permute(0, 3, 1, 2)
+    e = e[:B] + scale * (e[B:] - e[:B])
+    r0 = (x - math.sqrt(1 - a_t) * e) / math.sqrt(a_t)
+    rp = math.sqrt(a_prev) * r0 + math.sqrt(1 - a_prev - sig ** 2) * e + sig * noise
+    close(p0, r0, 1e-5)
+    close(xp, rp, 1e-5)
+    close(xin[:B].permute(0, 3, 1, 2), rp, 2e-3)
+    close(xin[B:].permute(0, 3, 1, 2), rp, 2e-3)
+
+
+def test_errors_are_loud():
+    from lib.hip import binding, ops
+    with pytest.raises(binding.PfdError):
+        ops.gemm(_dev(8, 100), _dev(8, 100))          # K % 64 != 0 -> PFD_ESHAPE
+    with pytest.raises(RuntimeError):
+        ops.gemm(torch.zeros(8, 64, dtype=torch.float16), torch.zeros(8, 64, dtype=torch.float16))  # CPU tensors

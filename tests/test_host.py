@@ -1,0 +1,188 @@
+"""CPU: host-side logic of the product package -- config bank, registry, state-dict surface,
+C-ABI symbol table.  No kernel is launched here."""
+import ctypes
+import json
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import REPO
+
+
+def _plain(o):
+    if isinstance(o, dict):
+        return {k: _plain(v) for k, v in o.items()}
+    if isinstance(o, (list, tuple)):
+        return [_plain(v) for v in o]
+    return o
+
+
+def test_cfg_bank_matches_reference():
+    from lib.cfg_helper import model_cfg_bank
+    cfg = model_cfg_bank()('pfd_seecoder_with_controlnet')
+    with open(os.path.join(REPO, "tests", "golden", "cfg_pfd_seecoder_with_controlnet.json")) as f:
+        ref = json.load(f)
+    ref["args"]["vae_cfg_list"][0][1]["pth"] = "pretrained/pfd/vae/sd-v2-0-base-autokl.pth"  # harness nulled it
+    assert _plain(cfg) == ref
+    assert cfg.type == 'pfd_with_control' and cfg.args.ctl_cfg.type == 'controlnet'
+    assert cfg.args.ctx_cfg_list[0][1].args.imencoder_cfg.args.window_size == 12
+
+
+def test_cfg_bank_inheritance_and_broken_entries():
+    from lib.cfg_helper import model_cfg_bank
+    bank = model_cfg_bank()
+    base = bank('pfd_seecoder')
+    assert base.type == 'pfd' and base.args.timesteps == 1000 and base.args.latent_scale_factor.image == 0.18215
+    qpa = bank('seecoder_query_transformer_position_aware')
+    assert qpa.args.with_fea2d_pos is True and qpa.args.num_queries == [4, 144]
+    with pytest.raises(ValueError):     # super_cfg: seet does not exist (kept broken like the reference)
+        bank('seecoder_pa')
+    with pytest.raises(ValueError):     # unknown prefix
+        bank('nonexistent_model')
+    # returned configs are copies
+    base.args.timesteps = 5
+    assert bank('pfd_seecoder').args.timesteps == 1000
+
+
+def test_cfg_unique_holder_singleton():
+    from lib.cfg_holder import cfg_unique_holder
+    a, b = cfg_unique_holder(), cfg_unique_holder()
+    assert a is b
+    a.save_cfg({'x': [1, 2]})
+    a.add_code('main')
+    assert b.cfg == {'x': [1, 2]} and 'main' in b.code
+
+
+def test_registry_names():
+    from lib.model_zoo import get_model
+    from lib.cfg_helper import model_cfg_bank
+    import lib.model_zoo.pfd, lib.model_zoo.autokl, lib.model_zoo.openaimodel  # noqa: F401,E401
+    import lib.model_zoo.controlnet, lib.model_zoo.seecoder, lib.model_zoo.swin  # noqa: F401,E401
+    reg = get_model().model
+    for name in ('pfd', 'pfd_with_control', 'autoencoderkl', 'openai_unet_2d_next', 'controlnet', 'seecoder',
+                 'seecoder_decoder', 'seecoder_query_transformer', 'swin'):
+        assert name in reg, name
+    assert get_model() is get_model()
+    assert get_model()(None) is None
+    from lib.model_zoo.seecoder import PPE_MLP  # app.py imports this by name (app.py:166-177)
+    assert PPE_MLP(freq_num=20, freq_max=None, out_channel=768, mlp_layer=3).mlp[0].in_features == 80
+
+
+@pytest.fixture(scope="module")
+def full_net():
+    from lib.cfg_helper import model_cfg_bank
+    from lib.model_zoo import get_model
+    cfg = model_cfg_bank()('pfd_seecoder_with_controlnet')
+    cfg.args.vae_cfg_list[0][1].pth = None
+    torch.manual_seed(0)
+    return get_model()(cfg, verbose=False)
+
+
+def test_state_dict_surface(full_net, state_spec):
+    """same 1902 keys, shapes, dtypes and parameter/buffer split as the reference composite"""
+    sd = full_net.state_dict()
+    assert len(state_spec) == 1902
+    assert set(sd.keys()) == set(state_spec.keys())
+    pnames = set(n for n, _ in full_net.named_parameters())
+    for k, v in sd.items():
+        ref = state_spec[k]
+        assert list(v.shape) == ref["shape"], k
+        assert str(v.dtype).replace("torch.", "") == ref["dtype"], k
+        assert (k in pnames) == ref["param"], k
+
+
+def test_schedule_buffers_match_reference(full_net, golden):
+    for k in ("betas", "alphas_cumprod", "alphas_cumprod_prev", "sqrt_alphas_cumprod",
+              "sqrt_one_minus_alphas_cumprod", "posterior_variance", "posterior_mean_coef1", "posterior_mean_coef2"):
+        np.testing.assert_allclose(getattr(full_net, k).numpy(), golden["sched." + k], rtol=2e-6, atol=1e-9)
+    assert full_net.num_timesteps == 1000
+    i = full_net.diffuser['image']
+    assert (len(i.i_order), len(i.m_order), len(i.o_order)) == (30, 3, 37)
+    assert len(i.data_blocks) == 30 and len(i.context_blocks) == 16
+
+
+def test_composite_quirks(full_net):
+    assert full_net.to('cpu') is None and full_net.device == 'cpu'     # pfd.py:100-102
+    assert full_net.control_scales == [1.0] * 13
+    assert full_net.ctx['image'].qtransformer.pe_layer is None
+    full_net.ctx['image'].fp16 = True                                  # dead attribute app.py sets (:119)
+    rpi = full_net.ctx['image'].imencoder.layers[0].blocks[0].attn.relative_position_index
+    assert rpi.dtype == torch.int64 and rpi.shape == (144, 144) and int(rpi[0, 0]) == 11 * 23 + 11
+    sd = full_net.state_dict()
+    full_net.load_state_dict(sd, strict=True)
+
+
+@pytest.mark.parametrize("steps,nreal", [(50, 50), (10, 10), (30, 31)])
+def test_ddim_schedule_host(full_net, golden, steps, nreal):
+    from lib.model_zoo.ddim import DDIMSampler
+    full_net.to('cpu')
+    s = DDIMSampler(full_net)
+    for eta in (0.0, 0.5):
+        s.make_schedule(steps, ddim_eta=eta, verbose=False)
+        tag = f"ddim.s{steps}.eta{eta}."
+        assert len(s.ddim_timesteps) == nreal
+        np.testing.assert_array_equal(s.ddim_timesteps, golden[tag + "timesteps"])
+        np.testing.assert_allclose(s.ddim_alphas, golden[tag + "alphas"], rtol=1e-6)
+        np.testing.assert_allclose(s.ddim_alphas_prev, golden[tag + "alphas_prev"], rtol=1e-6)
+        np.testing.assert_allclose(s.ddim_sigmas, golden[tag + "sigmas"], rtol=1e-5, atol=1e-12)
+    tab = s._coef_table(2.0)
+    assert tab.shape == (nreal, 5) and float(tab[0, 4]) == 2.0
+
+
+def test_product_path_has_no_cpu_fallback(full_net):
+    """CPU tensors must be refused loudly, never computed with torch ops"""
+    full_net.to('cpu')
+    with pytest.raises(RuntimeError):
+        full_net.ctx_encode(torch.rand(1, 3, 64, 64), 'image')
+    with pytest.raises(RuntimeError):
+        full_net.vae_decode(torch.randn(1, 4, 8, 8), 'image')
+    with pytest.raises(RuntimeError):
+        full_net.apply_model({'type': 'image', 'x': torch.randn(1, 4, 8, 8)}, torch.tensor([1]),
+                             {'type': 'image', 'c': torch.randn(1, 148, 768)})
+
+
+def test_oracle_is_not_imported_by_product():
+    pkg = os.path.join(REPO, "prompt-free-diffusion_amd")
+    for root, _, files in os.walk(pkg):
+        for fn in files:
+            if fn.endswith(".py"):
+                src = open(os.path.join(root, fn)).read()
+                assert "pfd_oracle" not in src and "import oracle" not in src and "from oracle" not in src, fn
+
+
+# ------------------------------------------------------------------------------------------------
+# C ABI
+# ------------------------------------------------------------------------------------------------
+def _header_functions():
+    src = open(os.path.join(REPO, "include", "pfd_hip.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(pfd_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_cabi_exports_every_declared_symbol():
+    from lib.hip import binding
+    names = _header_functions()
+    assert len(names) >= 18
+    assert set(names) == set(binding.SIGNATURES.keys())
+    lib = ctypes.CDLL(binding.lib_path())
+    for n in names:
+        assert hasattr(lib, n), n
+    lib.pfd_abi_version.restype = ctypes.c_int32
+    assert lib.pfd_abi_version() == binding.ABI_VERSION
+    assert binding.load().pfd_groupnorm_ws_bytes(2, 320, 4096) > 0
+
+
+def test_cabi_rejects_bad_arguments_without_a_gpu():
+    """argument validation happens before any launch, so it is testable on CPU"""
+    from lib.hip import binding
+    lib = binding.load()
+    d = binding.PfdGemmDesc()
+    assert lib.pfd_gemm_f16(ctypes.byref(d), None) == -1           # null pointers -> PFD_EINVAL
+    assert lib.pfd_gemm_f16(None, None) == -1
+    a = binding.PfdAttnDesc()
+    assert lib.pfd_attention_f16(ctypes.byref(a), None) == -1
+    with pytest.raises(binding.PfdError):
+        binding.check(-2, "unit")
