@@ -34,7 +34,7 @@ extern "C" {
 #define PFD_ESHAPE (-2)   /* shape outside what the kernels are built for           */
 #define PFD_ELAUNCH (-3)  /* hipGetLastError() != hipSuccess after the launch       */
 
-#define PFD_ABI_VERSION 1
+#define PFD_ABI_VERSION 2
 
 typedef void* pfd_stream_t; /* hipStream_t */
 
@@ -72,6 +72,9 @@ const char* pfd_last_error(void);
  *
  * Requirements: K % 64 == 0 (linear) or Cin % 64 == 0 (conv); lda/ldw % 8 == 0;
  * A, W 16-byte aligned.  M, N arbitrary (tails are masked).
+ * PFD_ACT_GEGLU weight packing: when N % 160 == 0 (wide-tile kernel) every group of 40 outputs
+ * stores its 40 x-rows then its 40 gate-rows (80 packed rows); otherwise (N % 128 == 0) every
+ * group of 32 outputs stores 32 x-rows then 32 gate-rows.  bias is packed the same way.
  * ---------------------------------------------------------------------------------- */
 typedef struct PfdGemmDesc {
   const void* A;
@@ -89,10 +92,17 @@ typedef struct PfdGemmDesc {
   int32_t ksize, stride, pad, ups;
   int32_t B, H, Wd, Cin; /* input image (before the optional upsample) */
   int32_t Ho, Wo;        /* output image; M must equal B*Ho*Wo          */
+  /* optional fp32 scratch for split-K (small M*N, huge K: the 8x8 / 16x16 UNet levels); the
+   * library never allocates.  NULL / 0 = never split.  Must not be shared by concurrent streams. */
+  void* ws;
+  size_t ws_bytes;
 } PfdGemmDesc;
 int pfd_gemm_f16(const PfdGemmDesc* d, pfd_stream_t stream);
-/* Same, with the block tile forced: tile = 10*TM + TN in {22, 21, 12, 11} meaning a
- * (64*TM) x (64*TN) x 64 tile; 0 = the library's heuristic.  Tests and tuning only. */
+/* Same, with the kernel variant forced (tests and tuning only); 0 = the library's heuristic.
+ *   tile in {22, 21, 12, 11}: register-staged kernel, (64*TM) x (64*TN) x 64 tile, tile = 10*TM+TN
+ *   tile = 1000 + 10*v + s : LDS-DMA wide-tile kernel (needs N % 160 == 0), v in {44, 24, 22} =
+ *          256x160 / 128x160 / 64x160 block tile (or 0), split-K factor s in 0..8 (0 = heuristic),
+ *          encoded as 1000 + 100*v + s, e.g. 1000 + 4400 + 2 = 5402. */
 int pfd_gemm_f16_ex(const PfdGemmDesc* d, int32_t tile, pfd_stream_t stream);
 
 /* ------------------------------------------------------------------------------------

@@ -33,7 +33,7 @@ extern "C" const char* pfd_last_error(void) { return g_err; }
 #include <vector>
 
 namespace {
-constexpr int kProfBuckets = 16;
+constexpr int kProfBuckets = 20;
 constexpr int kProfRing = 16384;
 struct ProfSlot {
   hipEvent_t a = nullptr, b = nullptr;
@@ -56,8 +56,9 @@ const char* kBucketNames[kProfBuckets] = {
     "gemm_conv_kernel<2,2,false>", "gemm_conv_kernel<1,1,true>",  "gemm_conv_kernel<1,2,true>",
     "gemm_conv_kernel<2,1,true>",  "gemm_conv_kernel<2,2,true>",  "attention_kernel",
     "swin_attn_kernel",            "groupnorm(stats+finalize+apply)", "layernorm_kernel",
-    "other",                       "other",                       "other",
-    "other"};
+    "gemm160_kernel<4,4>(256x160)", "gemm160_kernel<2,4>(128x160)", "gemm160_kernel<2,2>(64x160)",
+    "other",                       "gemm160_kernel<4,4,conv>(256x160)", "gemm160_kernel<2,4,conv>(128x160)",
+    "gemm160_kernel<2,2,conv>(64x160)", "other"};
 
 void harvest(ProfSlot& s) {
   if (s.bucket < 0) return;

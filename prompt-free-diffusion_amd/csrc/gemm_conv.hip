@@ -293,6 +293,8 @@ int launch(const GemmParams& p0, hipStream_t s) {
 
 }  // namespace
 
+int pfd_gemm160_try(const PfdGemmDesc* d, int variant, int splits, hipStream_t s);  // gemm_glds.hip
+
 extern "C" int pfd_gemm_f16_ex(const PfdGemmDesc* d, int32_t tile, pfd_stream_t stream) {
   if (!d || !d->A || !d->W || !d->C) return PFD_EINVAL;
   if (d->M <= 0 || d->N <= 0 || d->K <= 0) return PFD_EINVAL;
@@ -300,6 +302,18 @@ extern "C" int pfd_gemm_f16_ex(const PfdGemmDesc* d, int32_t tile, pfd_stream_t 
   if ((reinterpret_cast<uintptr_t>(d->A) & 15) || (reinterpret_cast<uintptr_t>(d->W) & 15)) return PFD_EINVAL;
   if (d->K % BK) return PFD_ESHAPE;
   if (d->rowvec && d->rows_per_rv < 1) return PFD_EINVAL;
+  if (d->act < PFD_ACT_NONE || d->act > PFD_ACT_GEGLU) return PFD_EINVAL;
+  if (d->ksize > 0) {
+    if (d->Cin <= 0 || d->K != d->ksize * d->ksize * d->Cin) return PFD_EINVAL;
+    if ((long)d->B * d->Ho * d->Wo != d->M) return PFD_EINVAL;
+    if (d->stride < 1) return PFD_EINVAL;
+  }
+  if (tile == 0 || tile >= 1000) {  // wide-tile LDS-DMA path (N % 160 == 0)
+    const int enc = tile >= 1000 ? tile - 1000 : 0;
+    const int rc = pfd_gemm160_try(d, enc / 100, enc % 100, (hipStream_t)stream);
+    if (rc <= 0) return rc;
+    if (tile >= 1000) return PFD_ESHAPE;  // forced but not applicable
+  }
   GemmParams p;
   p.A = (const half_t*)d->A;
   p.W = (const half_t*)d->W;

@@ -1,0 +1,453 @@
+// pfd_gemm_f16, wide-tile path: linear / 1x1 / 3x3 implicit-GEMM convolution for N % 160 == 0
+// (every SD-v1.5 UNet / ControlNet width is a multiple of 320) on v_mfma_f32_16x16x32_f16.
+//
+// Block tile BM x 160 x 64 with BM = WAVES_M * WMB * 16; waves laid out WAVES_M (M) x 2 (N); each
+// wave owns a (WMB*16) x 80 sub-tile = WMB x 5 MFMA tiles of 16x16 (fp32 accumulators in the
+// unified VGPR/AGPR file: WMB*5*4 registers).  Variants: <4,4> 256x160 (8 waves), <2,4> 128x160,
+// <2,2> 64x160 (4 waves); small-MN / huge-K problems add split-K over gridDim.z with fp32 slabs
+// and a reduce+epilogue kernel (no in-launch inter-workgroup hand-off).
+//
+// Staging is LDS-DMA (global_load_lds_dwordx4): one wave instruction moves 8 rows x 128 B straight
+// from global memory into LDS, two LDS stages, the next K tile in flight during the MFMAs of the
+// current one, one vmcnt(0)+barrier per K step.  The LDS image is lane-linear, so the bank-
+// conflict swizzle is applied to the per-lane SOURCE address: 16-byte chunk c of row r is stored
+// at chunk position c ^ ((r >> 1) & 7); the fragment ds_read_b128 applies the same XOR.  With
+// 128-byte rows two rows share one 256-byte bank row, so (row parity, chunk ^ (row>>1)) gives every
+// lane group of a ds_read_b128 sixteen distinct 16-byte slots (conflict free).
+//
+// Convolution: the A operand is a per-lane gather -- the source address of lane (row, chunk) is
+// the input pixel under the current filter tap; taps outside the image (and rows past M) read a
+// 256-byte zero page instead, so zero padding, stride 2 and the fused nearest-2x upsample
+// (openaimodel.py:114) are pure address arithmetic.  K is walked tap-major / channel-minor with
+// counters (no integer division in the loop).
+//
+// Epilogue: each wave stages 32 x 80 fp32 results through its private LDS region and emits whole
+// 16-byte row segments: + bias + per-sample row vector (time embedding) -> activation (or GEGLU:
+// the packed weight keeps the 40 x-rows and 40 gate-rows of a wave's 40 outputs adjacent) ->
+// + residual -> fp16.
+//
+// Algorithmic bytes / flops per launch: see pfd_prof_begin below (operands + result once; 2MNK).
+#include "pfd_common.h"
+
+namespace {
+
+constexpr int BK = 64;
+constexpr int BN = 160;
+constexpr int ROWB = BK * 2;         // bytes per LDS row (128)
+constexpr int EP_LD = 84;            // floats per staged epilogue row (80 + 4 pad; 336 B = 21 x 16 B)
+constexpr int EP_WAVE_BYTES = 32 * EP_LD * 4;
+
+__device__ __attribute__((aligned(256))) half_t g_zero_page[128];  // zero-initialised: OOB source of the gather
+
+struct G160Params {
+  const half_t* A;
+  const half_t* W;
+  const half_t* bias;
+  const half_t* rowvec;
+  const half_t* R;
+  half_t* C;
+  float* ws;  // split-K slabs [splits][M][N] fp32
+  long lda, ldw, ldr, ldc, ldrv;
+  int M, N, K;
+  int rows_per_rv, act;
+  int ksize, stride, pad, ups;
+  int B, H, Wd, Cin, Ho, Wo;
+  int tiles_m, tiles_n, splits, kt_per_split;
+};
+
+__device__ __forceinline__ void glds16(const void* src, void* lds_dst) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                   (__attribute__((address_space(3))) void*)lds_dst, 16, 0, 0);
+}
+
+template <int WAVES_M, int WMB, bool CONV>
+__global__ __launch_bounds__(WAVES_M * 128) void gemm160_kernel(const G160Params p) {
+  constexpr int NW = WAVES_M * 2;
+  constexpr int NT = NW * 64;
+  constexpr int BM = WAVES_M * WMB * 16;
+  constexpr int A_INSTR = BM / 8;                  // wave-instructions per A tile
+  constexpr int B_INSTR = BN / 8;                  // 20
+  constexpr int A_PER_WAVE = A_INSTR / NW;         // 4, 4, 2
+  constexpr int B_PER_WAVE = (B_INSTR + NW - 1) / NW;
+  constexpr int STAGE = (BM + BN) * ROWB;
+  constexpr int MAIN_BYTES = 2 * STAGE;
+  constexpr int EPI_BYTES = NW * EP_WAVE_BYTES;
+  constexpr int SMEM = MAIN_BYTES > EPI_BYTES ? MAIN_BYTES : EPI_BYTES;
+  static_assert(A_INSTR % NW == 0, "A tile must split evenly over the waves");
+  __shared__ __attribute__((aligned(1024))) char smem[SMEM];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int l15 = lane & 15, g = lane >> 4;
+
+  const int nblk = p.tiles_m * p.tiles_n;
+  const int t = xcd_remap(blockIdx.x, nblk);
+  const int tile_m = t / p.tiles_n;
+  const int tile_n = t - tile_m * p.tiles_n;
+  const int m0 = tile_m * BM;
+  const int n0 = tile_n * BN;
+  const int split = blockIdx.z;
+  const int kt_begin = split * p.kt_per_split;
+  const int nk_total = p.K / BK;
+  const int kt_end = min(nk_total, kt_begin + p.kt_per_split);
+
+  // ---- staging state: this lane moves chunk position (lane & 7) of row (q*8 + lane>>3) ----
+  const int srow = lane >> 3;
+  const int cpos = lane & 7;
+  const half_t* a_ptr[A_PER_WAVE];   // linear mode: pointer to (row, swizzled source chunk) at k = 0
+  int a_oy[A_PER_WAVE], a_ox[A_PER_WAVE];
+  long a_img[A_PER_WAVE];
+  bool a_ok[A_PER_WAVE];
+  int a_chunk[A_PER_WAVE];
+#pragma unroll
+  for (int j = 0; j < A_PER_WAVE; ++j) {
+    const int r = (wave + NW * j) * 8 + srow;
+    const int c = cpos ^ ((r >> 1) & 7);
+    a_chunk[j] = c * 8;
+    const int m = m0 + r;
+    a_ok[j] = m < p.M;
+    if (CONV) {
+      const int hw = p.Ho * p.Wo;
+      const int b = m / hw;
+      const int rem = m - b * hw;
+      const int oy = rem / p.Wo;
+      a_oy[j] = oy * p.stride - p.pad;
+      a_ox[j] = (rem - oy * p.Wo) * p.stride - p.pad;
+      a_img[j] = (long)b * p.H * p.Wd * p.lda;
+      a_ptr[j] = p.A;
+    } else {
+      a_ptr[j] = a_ok[j] ? p.A + (long)m * p.lda + c * 8 : g_zero_page;
+      a_oy[j] = a_ox[j] = 0;
+      a_img[j] = 0;
+    }
+  }
+  const half_t* b_ptr[B_PER_WAVE];
+#pragma unroll
+  for (int j = 0; j < B_PER_WAVE; ++j) {
+    const int q = wave + NW * j;
+    const int r = q * 8 + srow;
+    const int c = cpos ^ ((r >> 1) & 7);
+    b_ptr[j] = p.W + (long)(n0 + (q < B_INSTR ? r : 0)) * p.ldw + c * 8;
+  }
+  const int Hin = p.ups ? 2 * p.H : p.H;
+  const int Win = p.ups ? 2 * p.Wd : p.Wd;
+
+  // conv K walk: tap (ky, kx) outer, channel block inner
+  int tap_ky = 0, tap_kx = 0, ci0 = 0;
+  if (CONV) {
+    const int k0 = kt_begin * BK;
+    const int tap = k0 / p.Cin;  // once per block
+    ci0 = k0 - tap * p.Cin;
+    tap_ky = tap / p.ksize;
+    tap_kx = tap - tap_ky * p.ksize;
+  }
+  const half_t* a_tap[A_PER_WAVE];  // conv: source pointer for the current tap at ci = 0 (or zero page)
+  auto set_tap = [&]() {
+#pragma unroll
+    for (int j = 0; j < A_PER_WAVE; ++j) {
+      int iy = a_oy[j] + tap_ky, ix = a_ox[j] + tap_kx;
+      const bool ok = a_ok[j] && iy >= 0 && iy < Hin && ix >= 0 && ix < Win;
+      if (p.ups) {
+        iy >>= 1;
+        ix >>= 1;
+      }
+      a_tap[j] = ok ? p.A + a_img[j] + ((long)iy * p.Wd + ix) * p.lda + a_chunk[j] : nullptr;
+    }
+  };
+  if (CONV) set_tap();
+
+  auto issue = [&](int stage, int kt) {
+    char* As = smem + stage * STAGE;
+    char* Bs = As + BM * ROWB;
+    if (CONV) {
+#pragma unroll
+      for (int j = 0; j < A_PER_WAVE; ++j) {
+        const half_t* src = a_tap[j] ? a_tap[j] + ci0 : g_zero_page;
+        glds16(src, As + (wave + NW * j) * 1024);
+      }
+      ci0 += BK;
+      if (ci0 >= p.Cin) {  // next tap (wave-uniform)
+        ci0 = 0;
+        if (++tap_kx == p.ksize) {
+          tap_kx = 0;
+          ++tap_ky;
+        }
+        set_tap();
+      }
+    } else {
+      const int k0 = kt * BK;
+#pragma unroll
+      for (int j = 0; j < A_PER_WAVE; ++j)
+        glds16(a_ok[j] ? a_ptr[j] + k0 : a_ptr[j], As + (wave + NW * j) * 1024);
+    }
+    const int k0 = kt * BK;
+#pragma unroll
+    for (int j = 0; j < B_PER_WAVE; ++j) {
+      const int q = wave + NW * j;
+      if (q < B_INSTR) glds16(b_ptr[j] + k0, Bs + q * 1024);
+    }
+  };
+
+  float4_t acc[WMB][5];
+#pragma unroll
+  for (int i = 0; i < WMB; ++i)
+#pragma unroll
+    for (int j = 0; j < 5; ++j) acc[i][j] = (float4_t){0.f, 0.f, 0.f, 0.f};
+
+  // fragment read offsets (bytes): row (.. + l15), chunk (ks*4 + g) ^ ((l15 >> 1) & 7)
+  const int sw = (l15 >> 1) & 7;
+  const int off_k0 = ((0 + g) ^ sw) * 16 + l15 * ROWB;
+  const int off_k1 = ((4 + g) ^ sw) * 16 + l15 * ROWB;
+  const int a_row0 = wm * WMB * 16 * ROWB;
+  const int b_row0 = BM * ROWB + wn * 80 * ROWB;
+
+  if (kt_begin < kt_end) {
+    issue(0, kt_begin);
+    __builtin_amdgcn_s_waitcnt(0);  // vmcnt(0): tile 0 landed
+    __syncthreads();
+    for (int kt = kt_begin; kt < kt_end; ++kt) {
+      const int stage = (kt - kt_begin) & 1;
+      if (kt + 1 < kt_end) issue(stage ^ 1, kt + 1);
+      const char* base = smem + stage * STAGE;
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        const int off = ks ? off_k1 : off_k0;
+        half8_t af[WMB], bf[5];
+#pragma unroll
+        for (int i = 0; i < WMB; ++i) af[i] = *reinterpret_cast<const half8_t*>(base + a_row0 + i * 16 * ROWB + off);
+#pragma unroll
+        for (int j = 0; j < 5; ++j) bf[j] = *reinterpret_cast<const half8_t*>(base + b_row0 + j * 16 * ROWB + off);
+#pragma unroll
+        for (int i = 0; i < WMB; ++i)
+#pragma unroll
+          for (int j = 0; j < 5; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[i], bf[j], acc[i][j], 0, 0, 0);
+      }
+      __syncthreads();  // carries vmcnt(0): the next tile has landed, this one is consumed
+    }
+  }
+
+  // ---- epilogue ----
+  float* Es = reinterpret_cast<float*>(smem + wave * EP_WAVE_BYTES);
+  const bool geglu = p.act == PFD_ACT_GEGLU;
+  const bool raw = p.splits > 1;
+  const bool vec_ok = ((p.ldc & 7) == 0) && (p.R == nullptr || (p.ldr & 7) == 0) &&
+                      ((reinterpret_cast<uintptr_t>(p.C) & 15) == 0) &&
+                      (p.R == nullptr || (reinterpret_cast<uintptr_t>(p.R) & 15) == 0);
+#pragma unroll
+  for (int h = 0; h < WMB / 2; ++h) {
+#pragma unroll
+    for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+      for (int j = 0; j < 5; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) Es[(ii * 16 + 4 * g + r) * EP_LD + j * 16 + l15] = acc[2 * h + ii][j][r];
+    const int mrow0 = m0 + wm * WMB * 16 + h * 32;
+    if (raw) {
+      for (int idx = lane; idx < 32 * 20; idx += 64) {  // 20 float4 per row
+        const int rr = idx / 20, cc = idx - rr * 20;
+        const int m = mrow0 + rr;
+        if (m < p.M)
+          *reinterpret_cast<float4_t*>(p.ws + ((long)split * p.M + m) * p.N + n0 + wn * 80 + cc * 4) =
+              *reinterpret_cast<const float4_t*>(Es + rr * EP_LD + cc * 4);
+      }
+    } else if (geglu) {
+      for (int idx = lane; idx < 32 * 5; idx += 64) {
+        const int rr = idx / 5, cc = idx - rr * 5;
+        const int m = mrow0 + rr;
+        if (m >= p.M) continue;
+        const int nx = n0 + wn * 80 + cc * 8;  // packed-weight row of the x half; gate = +40
+        Pack16 bx, bg, o;
+        bx.u = bg.u = make_uint4(0, 0, 0, 0);
+        if (p.bias) {
+          bx.u = *reinterpret_cast<const uint4*>(p.bias + nx);
+          bg.u = *reinterpret_cast<const uint4*>(p.bias + nx + 40);
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float xv = Es[rr * EP_LD + cc * 8 + e] + (float)bx.e[e];
+          const float gv = Es[rr * EP_LD + 40 + cc * 8 + e] + (float)bg.e[e];
+          o.e[e] = (half_t)(xv * pfd_gelu(gv));
+        }
+        *reinterpret_cast<uint4*>(p.C + (long)m * p.ldc + (n0 >> 1) + wn * 40 + cc * 8) = o.u;
+      }
+    } else {
+      for (int idx = lane; idx < 32 * 10; idx += 64) {
+        const int rr = idx / 10, cc = idx - rr * 10;
+        const int m = mrow0 + rr;
+        if (m >= p.M) continue;
+        const int n = n0 + wn * 80 + cc * 8;
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = Es[rr * EP_LD + cc * 8 + e];
+        if (p.bias) {
+          Pack16 b;
+          b.u = *reinterpret_cast<const uint4*>(p.bias + n);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] += (float)b.e[e];
+        }
+        if (p.rowvec) {
+          Pack16 b;
+          b.u = *reinterpret_cast<const uint4*>(p.rowvec + (long)(m / p.rows_per_rv) * p.ldrv + n);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] += (float)b.e[e];
+        }
+        if (p.act == PFD_ACT_GELU) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] = pfd_gelu(v[e]);
+        } else if (p.act == PFD_ACT_RELU) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
+        } else if (p.act == PFD_ACT_SILU) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] = pfd_silu(v[e]);
+        }
+        if (vec_ok) {
+          if (p.R) {
+            Pack16 r;
+            r.u = *reinterpret_cast<const uint4*>(p.R + (long)m * p.ldr + n);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] += (float)r.e[e];
+          }
+          Pack16 o;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) o.e[e] = (half_t)v[e];
+          *reinterpret_cast<uint4*>(p.C + (long)m * p.ldc + n) = o.u;
+        } else {
+          for (int e = 0; e < 8; ++e) {
+            float x = v[e];
+            if (p.R) x += (float)p.R[(long)m * p.ldr + n + e];
+            p.C[(long)m * p.ldc + n + e] = (half_t)x;
+          }
+        }
+      }
+    }
+  }
+}
+
+// sum the split-K slabs and apply the epilogue (bias, row vector, activation, residual)
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const G160Params p) {
+  const long nvec = (long)p.M * (p.N / 8);
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (long)gridDim.x * 256) {
+    const int m = (int)(i / (p.N / 8));
+    const int n = (int)(i - (long)m * (p.N / 8)) * 8;
+    float v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int s = 0; s < p.splits; ++s) {
+      const float4_t a = *reinterpret_cast<const float4_t*>(p.ws + ((long)s * p.M + m) * p.N + n);
+      const float4_t b = *reinterpret_cast<const float4_t*>(p.ws + ((long)s * p.M + m) * p.N + n + 4);
+      v[0] += a[0]; v[1] += a[1]; v[2] += a[2]; v[3] += a[3];
+      v[4] += b[0]; v[5] += b[1]; v[6] += b[2]; v[7] += b[3];
+    }
+    if (p.bias) {
+      Pack16 b;
+      b.u = *reinterpret_cast<const uint4*>(p.bias + n);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] += (float)b.e[e];
+    }
+    if (p.rowvec) {
+      Pack16 b;
+      b.u = *reinterpret_cast<const uint4*>(p.rowvec + (long)(m / p.rows_per_rv) * p.ldrv + n);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] += (float)b.e[e];
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      if (p.act == PFD_ACT_GELU) v[e] = pfd_gelu(v[e]);
+      else if (p.act == PFD_ACT_RELU) v[e] = fmaxf(v[e], 0.f);
+      else if (p.act == PFD_ACT_SILU) v[e] = pfd_silu(v[e]);
+    }
+    for (int e = 0; e < 8; ++e) {
+      float x = v[e];
+      if (p.R) x += (float)p.R[(long)m * p.ldr + n + e];
+      p.C[(long)m * p.ldc + n + e] = (half_t)x;
+    }
+  }
+}
+
+template <int WAVES_M, int WMB>
+int launch160(G160Params& p, int bucket, hipStream_t s) {
+  constexpr int BM = WAVES_M * WMB * 16;
+  p.tiles_m = (p.M + BM - 1) / BM;
+  p.tiles_n = p.N / BN;
+  const int nk = p.K / BK;
+  p.kt_per_split = (nk + p.splits - 1) / p.splits;
+  p.splits = (nk + p.kt_per_split - 1) / p.kt_per_split;
+  dim3 grid(p.tiles_m * p.tiles_n, 1, p.splits);
+  const bool prof = pfd_prof_on();
+  if (prof) {
+    const double a_bytes = p.ksize > 0 ? 2.0 * p.B * p.H * p.Wd * p.Cin : 2.0 * p.M * p.K;
+    const double n_out = p.act == PFD_ACT_GEGLU ? p.N / 2 : p.N;
+    pfd_prof_begin(bucket, 2.0 * p.M * p.N * p.K, a_bytes + 2.0 * p.N * p.K + 2.0 * p.M * n_out * (p.R ? 2 : 1), s);
+  }
+  if (p.ksize > 0)
+    hipLaunchKernelGGL((gemm160_kernel<WAVES_M, WMB, true>), grid, dim3(WAVES_M * 128), 0, s, p);
+  else
+    hipLaunchKernelGGL((gemm160_kernel<WAVES_M, WMB, false>), grid, dim3(WAVES_M * 128), 0, s, p);
+  if (p.splits > 1) {
+    const long nvec = (long)p.M * (p.N / 8);
+    int g = (int)((nvec + 255) / 256);
+    if (g > 2048) g = 2048;
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(g), dim3(256), 0, s, p);
+  }
+  if (prof) pfd_prof_end(s);
+  return pfd_check_launch("pfd_gemm_f16(wide)");
+}
+
+}  // namespace
+
+// Called by pfd_gemm_f16_ex (gemm_conv.hip).  Returns 1 if the problem is not for this path.
+// variant: 0 = heuristic, 44 / 24 / 22 force <WAVES_M,WMB>; splits: 0 = heuristic.
+int pfd_gemm160_try(const PfdGemmDesc* d, int variant, int splits, hipStream_t s) {
+  if (d->N % BN || d->bias_per_row || d->K % BK) return 1;
+  if (d->ksize > 0 && (d->Cin % BK)) return 1;
+  if (d->act == PFD_ACT_GEGLU && (d->rowvec || d->R)) return 1;
+  if ((d->ldc & 7) || (reinterpret_cast<uintptr_t>(d->C) & 15)) return 1;
+  if (d->bias && (reinterpret_cast<uintptr_t>(d->bias) & 15)) return 1;
+  if (d->rowvec && ((d->ldrv & 7) || (reinterpret_cast<uintptr_t>(d->rowvec) & 15))) return 1;
+  G160Params p;
+  p.A = (const half_t*)d->A; p.W = (const half_t*)d->W; p.bias = (const half_t*)d->bias;
+  p.rowvec = (const half_t*)d->rowvec; p.R = (const half_t*)d->R; p.C = (half_t*)d->C;
+  p.ws = (float*)d->ws;
+  p.lda = d->lda; p.ldw = d->ldw; p.ldr = d->ldr; p.ldc = d->ldc; p.ldrv = d->ldrv;
+  p.M = d->M; p.N = d->N; p.K = d->K;
+  p.rows_per_rv = d->rows_per_rv > 0 ? d->rows_per_rv : 1;
+  p.act = d->act;
+  p.ksize = d->ksize; p.stride = d->stride; p.pad = d->pad; p.ups = d->ups;
+  p.B = d->B; p.H = d->H; p.Wd = d->Wd; p.Cin = d->Cin; p.Ho = d->Ho; p.Wo = d->Wo;
+  p.tiles_m = p.tiles_n = 0;
+  p.kt_per_split = 0;
+  const int tn = p.N / BN;
+  auto tiles = [&](int bm) { return (long)((p.M + bm - 1) / bm) * tn; };
+  const bool auto_variant = variant == 0;
+  if (auto_variant) {
+    // measured on MI355X (profiles/r01_selftest_kernels_b.log): the 256x160 tile wins whenever it
+    // yields >= ~100 blocks; below that 128x160 tiles with split-K up to 512 blocks
+    variant = tiles(256) >= 96 ? 44 : 24;
+  }
+  const int bm = variant == 44 ? 256 : variant == 24 ? 128 : 64;
+  if (splits == 0) {
+    splits = 1;
+    const long tl = tiles(bm);
+    const int nk = p.K / BK;
+    if (p.act != PFD_ACT_GEGLU && d->ws && variant == 44 && tl < 200 && nk >= 32 &&
+        (size_t)2 * p.M * p.N * 4 <= d->ws_bytes) {
+      splits = 2;  // 128 tiles of 256x160: two K halves fill the chip (758 vs 579 TF at 640->640 @32^2)
+    } else if (p.act != PFD_ACT_GEGLU && d->ws && variant != 44 && tl < 256) {
+      splits = (int)((512 + tl - 1) / tl);
+      if (splits > 8) splits = 8;
+      while (splits > 1 && nk / splits < 8) --splits;
+      while (splits > 1 && (size_t)splits * p.M * p.N * 4 > d->ws_bytes) --splits;
+    }
+  }
+  if (splits > 1 && (!d->ws || (size_t)splits * p.M * p.N * 4 > d->ws_bytes || p.act == PFD_ACT_GEGLU)) splits = 1;
+  p.splits = splits;
+  const int conv = p.ksize > 0 ? 1 : 0;
+  switch (variant) {
+    case 44: return launch160<4, 4>(p, 12 + 4 * conv, s) < 0 ? PFD_ELAUNCH : 0;
+    case 24: return launch160<2, 4>(p, 13 + 4 * conv, s) < 0 ? PFD_ELAUNCH : 0;
+    case 22: return launch160<2, 2>(p, 14 + 4 * conv, s) < 0 ? PFD_ELAUNCH : 0;
+    default: return PFD_EINVAL;
+  }
+}

@@ -88,20 +88,34 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(GnSrc s, int HW, int G, i
   }
 }
 
-__global__ void gn_finalize_kernel(const float* __restrict__ partial, int nchunks, int G, float count,
-                                   float eps, float* __restrict__ stats) {
-  const int b = blockIdx.x, g = threadIdx.x;
-  if (g >= G) return;
+__global__ __launch_bounds__(256) void gn_finalize_kernel(const float* __restrict__ partial, int nchunks, int G,
+                                                         float count, float eps, float* __restrict__ stats) {
+  // one block per sample; thread (part, g) sums chunks part, part+P, ... then an LDS tree over parts
+  __shared__ float ra[256], rq[256];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const int P = 256 / G;  // G <= 64 -> P >= 4
+  const int g = tid % G, part = tid / G;
   float a = 0.f, q = 0.f;
-  for (int k = 0; k < nchunks; ++k) {
-    const float* p = partial + (((long)b * nchunks + k) * G + g) * 2;
-    a += p[0];
-    q += p[1];
+  if (part < P) {
+    for (int k = part; k < nchunks; k += P) {
+      const float2 v = *reinterpret_cast<const float2*>(partial + (((long)b * nchunks + k) * G + g) * 2);
+      a += v.x;
+      q += v.y;
+    }
   }
-  const float mean = a / count;
-  const float var = fmaxf(q / count - mean * mean, 0.f);
-  stats[((long)b * G + g) * 2] = mean;
-  stats[((long)b * G + g) * 2 + 1] = rsqrtf(var + eps);
+  ra[tid] = a;
+  rq[tid] = q;
+  __syncthreads();
+  if (tid < G) {
+    for (int k = 1; k < P; ++k) {
+      a += ra[k * G + tid];
+      q += rq[k * G + tid];
+    }
+    const float mean = a / count;
+    const float var = fmaxf(q / count - mean * mean, 0.f);
+    stats[((long)b * G + tid) * 2] = mean;
+    stats[((long)b * G + tid) * 2 + 1] = rsqrtf(var + eps);
+  }
 }
 
 __global__ __launch_bounds__(256) void gn_apply_kernel(GnSrc s, const half_t* __restrict__ gamma,
@@ -313,7 +327,7 @@ extern "C" int pfd_groupnorm_f16(const void* x1, int32_t C1, int64_t ldx1, const
   const bool prof = pfd_prof_on();
   if (prof) pfd_prof_begin(10, 8.0 * B * HW * C, 6.0 * B * HW * C, s);  // 2B stats read + 2B read + 2B write
   hipLaunchKernelGGL(gn_stats_kernel, dim3(nchunks, B), dim3(256), 0, s, src, HW, G, rpc, partial);
-  hipLaunchKernelGGL(gn_finalize_kernel, dim3(B), dim3(64), 0, s, partial, nchunks, G,
+  hipLaunchKernelGGL(gn_finalize_kernel, dim3(B), dim3(256), 0, s, partial, nchunks, G,
                      (float)HW * (float)(C / G), eps, stats);
   hipLaunchKernelGGL(gn_apply_kernel, dim3(nchunks, B), dim3(256), 0, s, src, (const half_t*)gamma,
                      (const half_t*)beta, stats, (half_t*)y, (long)ldy, HW, G, rpc, act);

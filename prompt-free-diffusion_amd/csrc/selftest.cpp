@@ -132,8 +132,10 @@ static void run_gemm_case(const GemmCase& c) {
   auto rv = rand_h((size_t)n_rv * ldrv, 0.5f);
   auto R = rand_h((size_t)M * ldr, 1.0f);
   Dev<h16> dA(A), dW(W), dB(bias), dRV(rv), dR(R), dC((size_t)M * ldc);
+  Dev<float> dWS((size_t)8 * M * N + 64);
   PfdGemmDesc d;
   memset(&d, 0, sizeof(d));
+  d.ws = dWS.p; d.ws_bytes = ((size_t)8 * M * N + 64) * sizeof(float);
   d.A = dA.p; d.W = dW.p; d.bias = c.bias ? dB.p : nullptr; d.rowvec = c.rowvec ? dRV.p : nullptr;
   d.R = c.res ? dR.p : nullptr; d.C = dC.p;
   d.lda = lda; d.ldw = ldw; d.ldr = ldr; d.ldc = ldc; d.ldrv = ldrv;
@@ -186,8 +188,9 @@ static void run_gemm_case(const GemmCase& c) {
     for (int n = 0; n < Nout; ++n) {
       double v;
       if (c.act == PFD_ACT_GEGLU) {
-        const int blk = n / 32, j = n % 32;
-        const double x = pre[(size_t)m * N + blk * 64 + j], g = pre[(size_t)m * N + blk * 64 + 32 + j];
+        const int gr = (N % 160 == 0) ? 40 : 32;  // packing granularity of the kernel that serves this N
+        const int blk = n / gr, j = n % gr;
+        const double x = pre[(size_t)m * N + blk * 2 * gr + j], g = pre[(size_t)m * N + blk * 2 * gr + gr + j];
         v = x * act_ref(g, PFD_ACT_GELU);
       } else {
         v = act_ref(pre[(size_t)m * N + n], c.act);
@@ -519,8 +522,10 @@ static void bench_gemm(const char* label, int M, int N, int K, int ksize, int B,
   if (conv) { M = B * H * H; K = ksize * ksize * Cin; }
   auto A = rand_h(conv ? (size_t)B * H * H * Cin : (size_t)M * K), W = rand_h((size_t)N * K, 0.05f), bias = rand_h(N);
   Dev<h16> dA(A), dW(W), dB(bias), dC((size_t)M * N);
+  Dev<float> dWS((size_t)16 << 20);
   PfdGemmDesc d;
   memset(&d, 0, sizeof(d));
+  d.ws = dWS.p; d.ws_bytes = (size_t)64 << 20;
   d.A = dA.p; d.W = dW.p; d.bias = dB.p; d.C = dC.p;
   d.lda = conv ? Cin : K; d.ldw = K; d.ldc = N; d.M = M; d.N = N; d.K = K; d.rows_per_rv = 1;
   d.ksize = ksize; d.stride = 1; d.pad = ksize / 2; d.B = B; d.H = H; d.Wd = H; d.Cin = Cin; d.Ho = H; d.Wo = H;
@@ -587,6 +592,21 @@ int main(int argc, char** argv) {
     run_gemm_case({0, 64, 0, 0, true, false, false, false, 0, 8, 3, 2, 0, 0, 1, 9, 9, 64});             // pad 0, stride 2, ld+8
     run_gemm_case({0, 80, 0, 0, true, false, false, false, 0, 0, 1, 1, 0, 0, 2, 6, 6, 128});            // 1x1 as conv
 
+    // wide-tile LDS-DMA kernel (N % 160 == 0): variants 256x160 / 128x160 / 64x160, split-K, conv gather
+    for (int v : {0, 5400, 3400, 3200}) {
+      run_gemm_case({300, 320, 192, PFD_ACT_SILU, true, true, true, false, v});
+      run_gemm_case({77, 160, 64, 0, true, false, false, false, v, 8});
+      GemmCase c{0, 320, 0, 0, true, true, true, false, v, 0, 3, 1, 1, 0, 2, 9, 7, 64};
+      run_gemm_case(c);
+    }
+    run_gemm_case({520, 160, 1024, PFD_ACT_GELU, true, true, true, false, 3204});   // 64x160 tiles, split-K 4
+    run_gemm_case({130, 320, 2048, 0, true, true, false, false, 5403});             // 256x160, split-K 3
+    run_gemm_case({200, 320, 128, PFD_ACT_GEGLU, true, false, false, false, 0});     // GEGLU, 40-row packing
+    run_gemm_case({0, 160, 0, PFD_ACT_SILU, true, false, false, false, 0, 0, 3, 2, 1, 0, 2, 10, 8, 128});  // stride 2
+    run_gemm_case({0, 160, 0, 0, true, true, false, false, 3402, 0, 3, 1, 1, 1, 1, 5, 6, 128});           // upsample + split
+    run_gemm_case({0, 320, 0, 0, true, false, false, false, 0, 8, 3, 2, 0, 0, 1, 9, 9, 64});               // pad 0, ld+8
+    run_gemm_case({0, 160, 0, 0, true, false, false, false, 0, 0, 1, 1, 0, 0, 2, 6, 6, 128});              // 1x1 as conv
+
     run_attn_case(2, 2, 128, 128, 40, true);
     run_attn_case(1, 2, 200, 148, 40, false);
     run_attn_case(2, 2, 64, 64, 80, true);
@@ -618,9 +638,18 @@ int main(int argc, char** argv) {
 
   if (bench || only_bench) {
     // UNet-shaped problems at C2 (UNet batch 8)
-    for (int t : {22, 21, 12, 11}) {
+    for (int t : {22, 5400, 3400, 0}) {
       bench_gemm("conv3x3 320->320 @64^2", 0, 320, 0, 3, 8, 64, 320, t);
     }
+    for (int t : {5400, 5402, 5403, 3402, 0}) bench_gemm("conv3x3 640->640 @32^2", 0, 640, 0, 3, 8, 32, 640, t);
+    for (int t : {5400, 5402, 0}) bench_gemm("conv3x3 1920->640 @32^2", 0, 640, 0, 3, 8, 32, 1920, t);
+    for (int t : {3400, 3200, 3402, 3404, 3202, 0}) bench_gemm("conv3x3 1280->1280 @16^2", 0, 1280, 0, 3, 8, 16, 1280, t);
+    for (int t : {3200, 3204, 3208, 3404, 3408, 0}) bench_gemm("conv3x3 1280->1280 @8^2", 0, 1280, 0, 3, 8, 8, 1280, t);
+    for (int t : {5400, 3400, 0}) bench_gemm("linear qkv 320->960 @64^2", 32768, 960, 320, 0, 0, 0, 0, t);
+    for (int t : {5400, 3400, 0}) bench_gemm("linear 1280->320 @64^2", 32768, 320, 1280, 0, 0, 0, 0, t);
+    for (int t : {5400, 3400, 0}) bench_gemm("linear 320->2560 @64^2", 32768, 2560, 320, 0, 0, 0, 0, t);
+    for (int t : {5400, 3400, 3200, 0}) bench_gemm("linear 1280->10240 @16^2", 2048, 10240, 1280, 0, 0, 0, 0, t);
+    bench_gemm("square-ish 8192x5120x4096", 8192, 5120, 4096, 0, 0, 0, 0, 5400);
     for (int t : {22, 21}) {
       bench_gemm("conv3x3 640->640 @32^2", 0, 640, 0, 3, 8, 32, 640, t);
       bench_gemm("conv3x3 1280->1280 @16^2", 0, 1280, 0, 3, 8, 16, 1280, t);

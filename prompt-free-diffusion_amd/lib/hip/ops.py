@@ -27,6 +27,18 @@ def _ptr(t):
     return t.data_ptr() if t is not None else None
 
 
+_WS = {}
+_WS_BYTES = 96 << 20
+
+
+def _workspace(device):
+    """per-device fp32 scratch for split-K GEMMs (single-stream use; stable address for hipGraphs)"""
+    ws = _WS.get(device)
+    if ws is None:
+        ws = _WS[device] = torch.empty(_WS_BYTES, dtype=torch.uint8, device=device)
+    return ws
+
+
 def _chk16(t, what):
     if t.dtype != torch.float16:
         raise TypeError(f"{what}: expected float16, got {t.dtype}")
@@ -77,6 +89,7 @@ def gemm(a, w, *, bias=None, rowvec=None, rows_per_rv=1, res=None, act=ACT_NONE,
     d.M, d.N, d.K = M, N, K
     d.rows_per_rv, d.act, d.bias_per_row = rows_per_rv, act, 1 if bias_per_row else 0
     d.ksize = 0
+    d.ws, d.ws_bytes = _workspace(a.device).data_ptr(), _WS_BYTES
     lib = _lib()
     rc = lib.pfd_gemm_f16_ex(_byref(d), tile, _stream()) if tile else lib.pfd_gemm_f16(_byref(d), _stream())
     _b.check(rc, f"pfd_gemm_f16 M{M} N{N} K{K}")
@@ -118,6 +131,7 @@ def conv(x, w, ksize, *, stride=1, pad=None, ups=False, bias=None, rowvec=None, 
     d.rows_per_rv, d.act, d.bias_per_row = Ho * Wo, act, 0
     d.ksize, d.stride, d.pad, d.ups = ksize, stride, pad, 1 if ups else 0
     d.B, d.H, d.Wd, d.Cin, d.Ho, d.Wo = B, H, W_, Cin, Ho, Wo
+    d.ws, d.ws_bytes = _workspace(x.device).data_ptr(), _WS_BYTES
     lib = _lib()
     rc = lib.pfd_gemm_f16_ex(_byref(d), tile, _stream()) if tile else lib.pfd_gemm_f16(_byref(d), _stream())
     _b.check(rc, f"pfd_gemm_f16(conv) M{M} N{N} K{K}")

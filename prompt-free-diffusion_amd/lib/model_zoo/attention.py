@@ -69,7 +69,8 @@ def as_context_kv(context):
 
 class GEGLU(nn.Module, L._Packed):
     """proj: Linear(dim_in, 2*dim_out); y = x * gelu(gate).  The packed weight interleaves x/gate
-    rows in blocks of 32 so both halves of an output column sit in one GEMM tile."""
+    rows (blocks of 40 for the wide-tile kernel, 32 otherwise) so both halves of an output column
+    sit in one GEMM tile."""
 
     def __init__(self, dim_in, dim_out):
         super().__init__()
@@ -81,8 +82,9 @@ class GEGLU(nn.Module, L._Packed):
             n = self.dim_out
             w = L._dev16(self.proj.weight)
             b = L._dev16(self.proj.bias)
-            wi = torch.stack([w[:n].view(n // 32, 32, -1), w[n:].view(n // 32, 32, -1)], 1).reshape(2 * n, -1)
-            bi = torch.stack([b[:n].view(n // 32, 32), b[n:].view(n // 32, 32)], 1).reshape(2 * n)
+            gr = 40 if (2 * n) % 160 == 0 else 32  # packing granularity of the kernel serving this N (pfd_hip.h)
+            wi = torch.stack([w[:n].view(n // gr, gr, -1), w[n:].view(n // gr, gr, -1)], 1).reshape(2 * n, -1)
+            bi = torch.stack([b[:n].view(n // gr, gr), b[n:].view(n // gr, gr)], 1).reshape(2 * n)
             return wi.contiguous(), bi.contiguous()
         return self._packed("geglu", build, self.proj.weight, self.proj.bias)
 

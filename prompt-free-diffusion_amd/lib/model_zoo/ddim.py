@@ -86,24 +86,6 @@ class DDIMSampler(object):
         return self.ddim_sampling(shape, x_info=x_info, c_info=c_info, noise_dropout=noise_dropout,
                                   temperature=temperature, log_every_t=log_every_t)
 
-    # ---------------------------------------------------------------------------------------
-    def _prepare_request(self, c_info, bs):
-        """step-invariant work: CFG context batch, its K/V^T projections, ControlNet hint features"""
-        scale = c_info['unconditional_guidance_scale']
-        uc = c_info.get('unconditional_conditioning', None)
-        cond = c_info['conditioning']
-        cfg = not ((scale == 1.) or (uc is None))
-        if cfg:
-            c_in = torch.cat([uc, cond])  # uncond first, like ddim.py:147
-        else:
-            c_in = cond
-        c_info['c'] = c_in
-        ctx = self.model.prepare_context(c_in)
-        control = c_info.get('control', None)
-        if control is not None and hasattr(self.model, 'ctl'):
-            control = self.model.ctl.prepare_hint(control)
-        return cfg, ctx, control
-
     @torch.no_grad()
     def ddim_sampling(self, shape, x_info, c_info, noise_dropout=0., temperature=1., log_every_t=100,
                       callback=None):
@@ -124,36 +106,106 @@ class DDIMSampler(object):
             x = torch.randn(shape, device=device, dtype=dtype).to(torch.float32)
         x = x.contiguous()
 
-        cfg, ctx, control = self._prepare_request(c_info, bs)
+        scale = c_info['unconditional_guidance_scale']
+        uc = c_info.get('unconditional_conditioning', None)
+        cond = c_info['conditioning']
+        cfg = not ((scale == 1.) or (uc is None))
+        c_in = torch.cat([uc, cond]) if cfg else cond   # uncond first, like ddim.py:147
+        c_info['c'] = c_in
+        control = c_info.get('control', None)
+        hint = None
+        if control is not None and hasattr(model, 'ctl'):
+            hint = model.ctl.prepare_hint(control).feat    # step/sample-invariant: once per request
         nb = 2 if cfg else 1
-        coef = self._coef_table(c_info['unconditional_guidance_scale'])
+        coef = self._coef_table(scale)
         time_range = np.flip(timesteps)
         total_steps = timesteps.shape[0]
         # all step timestamps at once on the device: [total_steps, nb*bs] int64
         t_table = torch.as_tensor(np.ascontiguousarray(time_range), device=device).long()[:, None].repeat(1, nb * bs)
         x_type, c_type = x_info['type'], c_info['type']
+        stochastic = bool(np.any(np.asarray(self.ddim_sigmas) != 0.))
 
-        intermediates = {'pred_xt': [], 'pred_x0': []}
-        xin = ops.to_nhwc(x, rep=nb)
-        pred_x0 = None
-        for i in range(total_steps):
-            index = total_steps - i - 1
-            eps = model.apply_model_nhwc(x_type, xin, t_table[i], c_type, ctx, control=control)
-            noise = None
-            if self.ddim_sigmas[index] != 0.:
-                noise = noise_like(x) * temperature
-                if noise_dropout > 0.:
-                    noise = torch.nn.functional.dropout(noise, p=noise_dropout)
-                noise = noise.contiguous()
-            x, pred_x0, xin = ops.cfg_ddim_step(eps, nb, x, coef[index], noise=noise, want_next=True)
-            if index % log_every_t == 0 or index == total_steps - 1:
-                intermediates['pred_xt'].append(x.to(dtype))
-                intermediates['pred_x0'].append(pred_x0.to(dtype))
-            if callback is not None:
-                callback(i)
-        out = x.to(dtype)
+        def run_loop(x, c_in, hint):
+            """the whole trajectory as a pure function of device tensors (capturable as one hipGraph)"""
+            from .controlnet import PreparedHint
+            ctx = model.prepare_context(c_in)
+            ctl = PreparedHint(hint) if hint is not None else None
+            inter_xt, inter_x0 = [], []
+            xin = ops.to_nhwc(x, rep=nb)
+            for i in range(total_steps):
+                index = total_steps - i - 1
+                eps = model.apply_model_nhwc(x_type, xin, t_table[i], c_type, ctx, control=ctl)
+                noise = None
+                if self.ddim_sigmas[index] != 0.:
+                    noise = noise_like(x) * temperature
+                    if noise_dropout > 0.:
+                        noise = torch.nn.functional.dropout(noise, p=noise_dropout)
+                    noise = noise.contiguous()
+                x, pred_x0, xin = ops.cfg_ddim_step(eps, nb, x, coef[index], noise=noise, want_next=True)
+                if index % log_every_t == 0 or index == total_steps - 1:
+                    inter_xt.append(x)
+                    inter_x0.append(pred_x0)
+                if callback is not None:
+                    callback(i)
+            return x, inter_xt, inter_x0
+
+        use_graph = self.use_graph and not stochastic and callback is None and x.is_cuda
+        if use_graph:
+            key = (tuple(x.shape), tuple(c_in.shape), None if hint is None else tuple(hint.shape), total_steps,
+                   float(scale), nb, x_type, c_type, int(log_every_t), hash(np.asarray(timesteps).tobytes()),
+                   self._weights_signature())
+            ent = self._graphs.get(key)
+            if ent is None:
+                if len(self._graphs) >= 4:
+                    self._graphs.clear()
+                ent = self._capture(run_loop, x, c_in, hint, (coef, t_table))
+                self._graphs[key] = ent
+            g, sx, sc, sh, outs, _keep = ent
+            sx.copy_(x)
+            sc.copy_(c_in)
+            if sh is not None:
+                sh.copy_(hint)
+            g.replay()
+            xf, ixt, ix0 = outs
+            xf, ixt, ix0 = xf.clone(), [t.clone() for t in ixt], [t.clone() for t in ix0]
+        else:
+            xf, ixt, ix0 = run_loop(x, c_in, hint)
+        intermediates = {'pred_xt': [t.to(dtype) for t in ixt], 'pred_x0': [t.to(dtype) for t in ix0]}
+        out = xf.to(dtype)
         x_info['x'] = out
         return out, intermediates
+
+    # ---- hipGraph plumbing (launch-bound loop: ~700 kernel launches per step) -------------------
+    use_graph = False
+    _graphs = None
+
+    def enable_graph(self, on=True):
+        """Replay the whole DDIM trajectory as one captured hipGraph (eta = 0 only).  The graph is
+        keyed by shapes / step count / guidance scale / the identity+version of every model
+        parameter, so a weight hot-swap (app.py:139-177) re-captures instead of replaying stale
+        packed weights.  Static input buffers are owned by the sampler."""
+        self.use_graph = bool(on)
+        if self._graphs is None:
+            self._graphs = {}
+
+    def _weights_signature(self):
+        return hash(tuple((p.data_ptr(), p._version) for p in self.model.parameters()))
+
+    def _capture(self, run_loop, x, c_in, hint, keep):
+        from ..hip import binding
+        binding.prof_enable(False)  # event timing cannot be captured
+        sx, sc = x.clone(), c_in.clone()
+        sh = hint.clone() if hint is not None else None
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):     # warm-up outside capture: packs weights, sizes the allocator
+            run_loop(sx, sc, sh)
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            outs = run_loop(sx, sc, sh)
+        return g, sx, sc, sh, outs, keep
 
     @torch.no_grad()
     def p_sample_ddim(self, x_info, c_info, t, index, repeat_noise=False, use_original_steps=False,

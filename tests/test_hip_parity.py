@@ -207,3 +207,28 @@ def test_weight_hot_swap_invalidates_packed_cache(net, golden):
     back = net.apply_model({'type': 'image', 'x': x}, t, {'type': 'image', 'c': c})
     assert float((changed - base).abs().max()) > 1e-3
     assert float((back - base).abs().max()) == 0.0
+
+
+def test_hipgraph_replay_matches_eager(net, golden):
+    """the captured-trajectory path must give the eager result and follow new inputs on replay"""
+    from lib.model_zoo.ddim import DDIMSampler
+    cond = T(golden["see.ctx"]).cuda().half()
+
+    def run(sampler, seed):
+        xT = torch.randn([2, 4, 8, 8], generator=torch.Generator().manual_seed(seed))
+        c = cond.repeat(2, 1, 1)
+        x_info = {'type': 'image', 'xt': xT.cuda()}
+        c_info = {'type': 'image', 'conditioning': c, 'unconditional_conditioning': torch.zeros_like(c),
+                  'unconditional_guidance_scale': 2.0}
+        x, inter = sampler.sample(steps=4, shape=[2, 4, 8, 8], x_info=x_info, c_info=c_info, eta=0., verbose=False)
+        return x, inter
+
+    eager = DDIMSampler(net)
+    graphed = DDIMSampler(net)
+    graphed.enable_graph(True)
+    for seed in (1, 2, 1):
+        xe, ie = run(eager, seed)
+        xg, ig = run(graphed, seed)
+        assert torch.equal(xe, xg), seed
+        assert len(ie['pred_x0']) == len(ig['pred_x0']) and torch.equal(ie['pred_x0'][-1], ig['pred_x0'][-1])
+    assert len(graphed._graphs) == 1
