@@ -5,15 +5,26 @@
 //     S^T[kv, q] = sum_d K[kv, d] Q[q, d]        A = K tile (LDS), B = Q (registers)
 //     O^T[d,  q] = sum_kv V^T[d, kv] P^T[kv, q]   A = V^T tile (LDS), B = P^T (registers)
 // A 32x32 S^T accumulator has col = q = lane&31 and rows kv = (r&3) + 8(r>>2) + 4(lane>>5):
-// one q column is split over lanes l and l^32, so the row max / row sum need exactly one
-// cross-lane exchange.  Registers 8b..8b+7 of that accumulator are, for 16-kv block b, the
-// 8 values an MFMA B operand wants -- in the k order pi(hi, j) = (j&3) + 8(j>>2) + 4hi.  MFMA
-// only needs A and B to agree on which k a (lane-group, j) slot means, so the V^T A operand
-// is read in the same pi order: two 8-byte LDS reads per fragment, no permutation of P.
+// one q column is split over lanes l and l^32, so the row max needs exactly one cross-lane
+// exchange.  Registers 8b..8b+7 of that accumulator are, for 16-kv block b, the 8 values an MFMA
+// B operand wants -- in the k order pi(hi, j) = (j&3) + 8(j>>2) + 4hi.  MFMA only needs A and B
+// to agree on which k a (lane-group, j) slot means, so the V^T A operand is read in the same pi
+// order: two 8-byte LDS reads per fragment, no permutation of P.
 // V arrives already transposed from its producer GEMM (see pfd_hip.h), K row-major.
 //
-// Block = 4 waves x 32 query rows; KV tile = 64 keys; per tile per wave:
-// 2*DQK/16 + 4*DV/32 MFMAs (DQK = D rounded to 16, DV = D rounded to 32).
+// Block = 4 waves x 32 query rows; KV tile = 64 keys, two LDS stages: the global loads of tile
+// t+1 are issued (to registers) before the MFMAs of tile t and written to the other stage after
+// them -- one barrier per tile, HBM/L2 latency hidden under compute.
+//
+// The path is VALU-bound at head dim 40 (160 MFMA flops per score vs ~4 VALU ops), so the softmax
+// is kept to max / fma / v_exp / cvt per score:
+//   * scores stay raw; p = exp2(s*c - m*c) with c = scale*log2(e) is one fma + one v_exp_f32;
+//   * the row sum costs nothing when the V^T tile has padding rows (D = 40, 80): row D of the LDS
+//     tile is set to 1.0, so O^T[D, q] accumulates sum_kv P -- with exactly the fp16-rounded P that
+//     multiplies V, and it is rescaled with the rest of the accumulator;
+//   * the accumulator is rescaled only when some row of the wave actually raised its running max
+//     (exact: alpha == 1 otherwise).
+// Per tile per wave: 2*DQK/16 + 4*DV/32 MFMAs (DQK = D rounded to 16, DV = D rounded to 32).
 #include "pfd_common.h"
 
 namespace {
@@ -39,17 +50,30 @@ __global__ __launch_bounds__(256) void attention_kernel(const AttnParams p) {
   constexpr int K_LD = DQK + 8;  // halfs; (DQK+8)*2 B is an odd multiple of 16 B for D in {40,80,96,160}
   constexpr int NS = DQK / 16;
   constexpr int ND = DV / 32;
-  __shared__ __attribute__((aligned(16))) half_t Ks[KV_TILE * K_LD];
-  __shared__ __attribute__((aligned(16))) half_t Vts[DV * VT_LD];
+  constexpr bool SUM_MFMA = DV > D;       // a spare V^T row carries the softmax denominator
+  constexpr int KCH = D / 8;              // 16-B chunks per K row
+  constexpr int K_CHUNKS = KV_TILE * KCH; // per tile
+  constexpr int V_CHUNKS = D * 8;
+  constexpr int K_PT = (K_CHUNKS + 255) / 256;
+  constexpr int V_PT = (V_CHUNKS + 255) / 256;
+  constexpr int K_TILE_HALFS = KV_TILE * K_LD;
+  constexpr int V_TILE_HALFS = DV * VT_LD;
+  __shared__ __attribute__((aligned(16))) half_t Ks[2 * K_TILE_HALFS];
+  __shared__ __attribute__((aligned(16))) half_t Vts[2 * V_TILE_HALFS];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l31 = lane & 31, hi = lane >> 5;
   const int h = blockIdx.y, b = blockIdx.z;
   const int q_row = blockIdx.x * 128 + wave * 32 + l31;
 
-  // zero the LDS padding once (columns D..DQK of K, rows D..DV of V^T)
-  for (int i = tid; i < KV_TILE * K_LD; i += 256) Ks[i] = (half_t)0.f;
-  for (int i = tid; i < DV * VT_LD; i += 256) Vts[i] = (half_t)0.f;
+  // zero the LDS padding once (columns D..DQK of K, rows D..DV of V^T); row D of V^T = 1 (row sums)
+  for (int i = tid; i < 2 * K_TILE_HALFS; i += 256) Ks[i] = (half_t)0.f;
+  for (int i = tid; i < 2 * V_TILE_HALFS; i += 256) Vts[i] = (half_t)0.f;
+  __syncthreads();
+  if (SUM_MFMA) {
+    for (int i = tid; i < 2 * KV_TILE; i += 256)
+      Vts[(i >> 6) * V_TILE_HALFS + D * VT_LD + (i & 63)] = (half_t)1.f;
+  }
 
   // Q fragments: B operand, col = q = lane&31, k = d
   half8_t qf[NS];
@@ -70,26 +94,33 @@ __global__ __launch_bounds__(256) void attention_kernel(const AttnParams p) {
   for (int i = 0; i < ND; ++i)
 #pragma unroll
     for (int r = 0; r < 16; ++r) o_acc[i][r] = 0.f;
-  float m_run = -INFINITY, l_run = 0.f;
+  float m_run = -INFINITY, l_run = 0.f;  // m_run: running max of the RAW scores
 
   const half_t* kbase = p.K + (long)b * p.k_bs + h * D;
   const half_t* vbase = p.Vt + (long)h * D * p.ldvt + (long)b * p.vt_bs;
-  constexpr int KCH = D / 8;  // 16-B chunks per K row
+  const float c = p.scale_log2;
 
-  for (int kv0 = 0; kv0 < p.Nk; kv0 += KV_TILE) {
-    __syncthreads();  // previous tile fully consumed (also orders the zero fill on entry)
-    for (int c = tid; c < KV_TILE * KCH; c += 256) {
-      const int row = c / KCH, cc = c - row * KCH;
-      uint4 v = make_uint4(0, 0, 0, 0);
-      if (kv0 + row < p.Nk) v = *reinterpret_cast<const uint4*>(kbase + (long)(kv0 + row) * p.ldk + cc * 8);
-      *reinterpret_cast<uint4*>(Ks + row * K_LD + cc * 8) = v;
+  // two staging register sets: tile t+1 and tile t+2 are in flight while tile t is computed
+  // (an L2-hit K/V load takes longer than one tile of MFMA+softmax work)
+  constexpr bool DEEP = D <= 48;  // wider heads have no registers to spare (and far fewer tiles)
+  uint4 kregA[K_PT], vregA[V_PT], kregB[DEEP ? K_PT : 1], vregB[DEEP ? V_PT : 1];
+  auto load_tile = [&](uint4* kreg, uint4* vreg, int kv0) {
+#pragma unroll
+    for (int j = 0; j < K_PT; ++j) {
+      const int ch = tid + 256 * j;
+      const int row = ch / KCH, cc = ch - row * KCH;
+      kreg[j] = make_uint4(0, 0, 0, 0);
+      if (ch < K_CHUNKS && kv0 + row < p.Nk)
+        kreg[j] = *reinterpret_cast<const uint4*>(kbase + (long)(kv0 + row) * p.ldk + cc * 8);
     }
-    for (int c = tid; c < D * 8; c += 256) {
-      const int d = c >> 3, cc = c & 7;
+#pragma unroll
+    for (int j = 0; j < V_PT; ++j) {
+      const int ch = tid + 256 * j;
+      const int d = ch >> 3, cc = ch & 7;
       const int kv = kv0 + cc * 8;
       Pack16 v;
       v.u = make_uint4(0, 0, 0, 0);
-      if (kv < p.Nk) {
+      if (ch < V_CHUNKS && kv < p.Nk) {
         v.u = *reinterpret_cast<const uint4*>(vbase + (long)d * p.ldvt + kv);
         if (kv + 8 > p.Nk) {
 #pragma unroll
@@ -97,11 +128,35 @@ __global__ __launch_bounds__(256) void attention_kernel(const AttnParams p) {
             if (kv + e >= p.Nk) v.e[e] = (half_t)0.f;
         }
       }
-      uint2* dst = reinterpret_cast<uint2*>(Vts + d * VT_LD + cc * 8);
-      dst[0] = make_uint2(v.u.x, v.u.y);
-      dst[1] = make_uint2(v.u.z, v.u.w);
+      vreg[j] = v.u;
     }
-    __syncthreads();
+  };
+  auto store_tile = [&](const uint4* kreg, const uint4* vreg, int stage) {
+    half_t* Kd = Ks + stage * K_TILE_HALFS;
+    half_t* Vd = Vts + stage * V_TILE_HALFS;
+#pragma unroll
+    for (int j = 0; j < K_PT; ++j) {
+      const int ch = tid + 256 * j;
+      const int row = ch / KCH, cc = ch - row * KCH;
+      if (ch < K_CHUNKS) *reinterpret_cast<uint4*>(Kd + row * K_LD + cc * 8) = kreg[j];
+    }
+#pragma unroll
+    for (int j = 0; j < V_PT; ++j) {
+      const int ch = tid + 256 * j;
+      const int d = ch >> 3, cc = ch & 7;
+      if (ch < V_CHUNKS) {
+        uint2* dst = reinterpret_cast<uint2*>(Vd + d * VT_LD + cc * 8);
+        dst[0] = make_uint2(vreg[j].x, vreg[j].y);
+        dst[1] = make_uint2(vreg[j].z, vreg[j].w);
+      }
+    }
+  };
+
+  const int ntiles = (p.Nk + KV_TILE - 1) / KV_TILE;
+  auto compute_tile = [&](int t, int stage) {
+    const int kv0 = t * KV_TILE;
+    const half_t* Kt = Ks + stage * K_TILE_HALFS;
+    const half_t* Vt = Vts + stage * V_TILE_HALFS;
 
     // ---- S^T = K . Q^T for the two 32-key halves of the tile ----
     float16_t st[2];
@@ -109,56 +164,59 @@ __global__ __launch_bounds__(256) void attention_kernel(const AttnParams p) {
     for (int u = 0; u < 2; ++u) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) st[u][r] = 0.f;
-      const half_t* kp = Ks + (u * 32 + l31) * K_LD + hi * 8;
+      const half_t* kp = Kt + (u * 32 + l31) * K_LD + hi * 8;
 #pragma unroll
       for (int s = 0; s < NS; ++s) {
         const half8_t kf = *reinterpret_cast<const half8_t*>(kp + s * 16);
         st[u] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[s], st[u], 0, 0, 0);
       }
     }
-    // ---- online softmax over this tile's 64 keys (log2 domain) ----
-    float mx = -INFINITY;
-    const bool tail = kv0 + KV_TILE > p.Nk;
+    // ---- online softmax over this tile's 64 keys ----
+    if (kv0 + KV_TILE > p.Nk) {  // ragged last tile: keys past Nk never win the max nor add weight
+#pragma unroll
+      for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          if (kv0 + u * 32 + mfma32_row(r, hi) >= p.Nk) st[u][r] = -INFINITY;
+    }
+    float mx = st[0][0];
 #pragma unroll
     for (int u = 0; u < 2; ++u)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        float v = st[u][r] * p.scale_log2;
-        if (tail && kv0 + u * 32 + mfma32_row(r, hi) >= p.Nk) v = -INFINITY;
-        st[u][r] = v;
-        mx = fmaxf(mx, v);
-      }
+      for (int r = 0; r < 16; ++r) mx = fmaxf(mx, st[u][r]);
     mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
     const float m_new = fmaxf(m_run, mx);  // finite: every tile holds at least one valid key
-    const float alpha = exp2f(m_run - m_new);
+    if (__any(m_new > m_run)) {            // wave-uniform: rescale only when some row's max moved
+      const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c);
+      l_run *= alpha;
+#pragma unroll
+      for (int i = 0; i < ND; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o_acc[i][r] *= alpha;
+      m_run = m_new;
+    }
+    const float mc = m_run * c;
     float rs = 0.f;
-#pragma unroll
-    for (int u = 0; u < 2; ++u)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const float e = exp2f(st[u][r] - m_new);
-        st[u][r] = e;
-        rs += e;
-      }
-    rs += __shfl_xor(rs, 32, 64);
-    l_run = l_run * alpha + rs;
-    m_run = m_new;
-#pragma unroll
-    for (int i = 0; i < ND; ++i)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) o_acc[i][r] *= alpha;
-
-    // ---- P^T to f16 B fragments; O^T += V^T . P^T ----
     half8_t pf[2][2];
 #pragma unroll
     for (int u = 0; u < 2; ++u)
 #pragma unroll
       for (int bb = 0; bb < 2; ++bb)
 #pragma unroll
-        for (int j = 0; j < 8; ++j) pf[u][bb][j] = (half_t)st[u][bb * 8 + j];
+        for (int j = 0; j < 8; ++j) {
+          const float e = __builtin_amdgcn_exp2f(fmaf(st[u][bb * 8 + j], c, -mc));
+          if (!SUM_MFMA) rs += e;
+          pf[u][bb][j] = (half_t)e;
+        }
+    if (!SUM_MFMA) {
+      rs += __shfl_xor(rs, 32, 64);
+      l_run += rs;
+    }
+
+    // ---- O^T += V^T . P^T ----
 #pragma unroll
     for (int i = 0; i < ND; ++i) {
-      const half_t* vp = Vts + (i * 32 + l31) * VT_LD + 4 * hi;
+      const half_t* vp = Vt + (i * 32 + l31) * VT_LD + 4 * hi;
 #pragma unroll
       for (int u = 0; u < 2; ++u)
 #pragma unroll
@@ -171,9 +229,46 @@ __global__ __launch_bounds__(256) void attention_kernel(const AttnParams p) {
           o_acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf[u][bb], o_acc[i], 0, 0, 0);
         }
     }
+  };
+
+  load_tile(kregA, vregA, 0);
+  store_tile(kregA, vregA, 0);
+  if (DEEP) {
+    if (ntiles > 1) load_tile(kregB, vregB, KV_TILE);  // tile 1 -> set B, lands during tile 0
+    __syncthreads();
+    for (int t = 0; t < ntiles; t += 2) {
+      // even tile t (stage 0): tile t+1 is in flight in set B; start tile t+2 into set A
+      if (t + 2 < ntiles) load_tile(kregA, vregA, (t + 2) * KV_TILE);
+      compute_tile(t, 0);
+      if (t + 1 < ntiles) store_tile(kregB, vregB, 1);
+      __syncthreads();
+      if (t + 1 >= ntiles) break;
+      // odd tile t+1 (stage 1): tile t+2 is in flight in set A; start tile t+3 into set B
+      if (t + 3 < ntiles) load_tile(kregB, vregB, (t + 3) * KV_TILE);
+      compute_tile(t + 1, 1);
+      if (t + 2 < ntiles) store_tile(kregA, vregA, 0);
+      __syncthreads();
+    }
+  } else {
+    __syncthreads();
+    for (int t = 0; t < ntiles; ++t) {
+      const int stage = t & 1;
+      if (t + 1 < ntiles) load_tile(kregA, vregA, (t + 1) * KV_TILE);  // in flight during this tile's MFMAs
+      compute_tile(t, stage);
+      if (t + 1 < ntiles) store_tile(kregA, vregA, stage ^ 1);
+      __syncthreads();
+    }
   }
 
   // ---- epilogue: O[q, d] = O^T[d, q] / l ----
+  if (SUM_MFMA) {
+    // row D of O^T = sum_kv P: tile D/32, local row D%32 -> register r with mfma32_row(r, hi') = D%32
+    constexpr int lr = D % 32;
+    constexpr int src_hi = (lr >> 2) & 1;
+    constexpr int reg = (lr & 3) + 4 * (lr >> 3);
+    const float v = o_acc[D / 32][reg];
+    l_run = __shfl(v, src_hi * 32 + l31, 64);
+  }
   if (q_row < p.Nq) {
     const float inv = 1.0f / l_run;
     half_t* op = p.O + (long)b * p.o_bs + (long)q_row * p.ldo + h * D;

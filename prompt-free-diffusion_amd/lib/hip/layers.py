@@ -82,7 +82,7 @@ class Conv2d(nn.Conv2d, _Packed):
     def _pk(self):
         return self._packed("w", lambda: (pack_conv_weight(self.weight), pack_vec(self.bias)), self.weight, self.bias)
 
-    def hip(self, x, *, ups=False, rowvec=None, res=None, act=ACT_NONE, out=None, out_hw=None):
+    def hip(self, x, *, ups=False, rowvec=None, res=None, act=ACT_NONE, out=None, out_hw=None, rows_per_rv=None):
         w, b = self._pk()
         k, s, p = self.kernel_size[0], self.stride[0], self.padding[0]
         cin = self.in_channels
@@ -91,11 +91,12 @@ class Conv2d(nn.Conv2d, _Packed):
                 B, H, W_, _ = x.shape
                 o2 = None if out is None else out.view(-1, out.shape[-1])
                 r2 = None if res is None else res.reshape(-1, res.shape[-1])
-                y = ops.gemm(x.reshape(-1, cin), w, bias=b, rowvec=rowvec, rows_per_rv=H * W_, res=r2, act=act,
+                y = ops.gemm(x.reshape(-1, cin), w, bias=b, rowvec=rowvec,
+                             rows_per_rv=H * W_ if rows_per_rv is None else rows_per_rv, res=r2, act=act,
                              out=o2)
                 return y.view(B, H, W_, self.out_channels)
             return ops.conv(x, w, k, stride=s, pad=p, ups=ups, bias=b, rowvec=rowvec, res=res, act=act, out=out,
-                            out_hw=out_hw)
+                            out_hw=out_hw, rows_per_rv=rows_per_rv)
         if ups:
             raise NotImplementedError("narrow-channel conv with fused upsample")
         r2 = None if res is None else res.reshape(-1, res.shape[-1])

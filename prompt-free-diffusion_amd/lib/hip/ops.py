@@ -97,7 +97,7 @@ def gemm(a, w, *, bias=None, rowvec=None, rows_per_rv=1, res=None, act=ACT_NONE,
 
 
 def conv(x, w, ksize, *, stride=1, pad=None, ups=False, bias=None, rowvec=None, res=None, act=ACT_NONE,
-         out=None, tile=0, out_hw=None):
+         out=None, tile=0, out_hw=None, rows_per_rv=None):
     """Implicit-GEMM convolution of an NHWC image x[B,H,W,Cin] (Cin % 64 == 0) with packed
     weights w[N, ksize*ksize*Cin]; returns [B,Ho,Wo,N].  rowvec: [B, N] per-sample vector."""
     _chk16(x, "conv x")
@@ -128,7 +128,7 @@ def conv(x, w, ksize, *, stride=1, pad=None, ups=False, bias=None, rowvec=None, 
     d.ldr = _rows(res)[2] if res is not None else 0
     d.ldrv = _rows(rowvec)[2] if rowvec is not None else 0
     d.M, d.N, d.K = M, N, K
-    d.rows_per_rv, d.act, d.bias_per_row = Ho * Wo, act, 0
+    d.rows_per_rv, d.act, d.bias_per_row = (Ho * Wo if rows_per_rv is None else rows_per_rv), act, 0
     d.ksize, d.stride, d.pad, d.ups = ksize, stride, pad, 1 if ups else 0
     d.B, d.H, d.Wd, d.Cin, d.Ho, d.Wo = B, H, W_, Cin, Ho, Wo
     d.ws, d.ws_bytes = _workspace(x.device).data_ptr(), _WS_BYTES

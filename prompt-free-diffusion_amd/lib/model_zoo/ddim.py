@@ -130,11 +130,15 @@ class DDIMSampler(object):
             from .controlnet import PreparedHint
             ctx = model.prepare_context(c_in)
             ctl = PreparedHint(hint) if hint is not None else None
+            # every ResBlock's time-embedding projection for ALL steps in one GEMM (t is the same for
+            # every sample of a step): [total_steps, sum Cout]
+            emb_all, _ = model.diffuser[x_type].emb_projections(t_table[:, 0].contiguous())
             inter_xt, inter_x0 = [], []
             xin = ops.to_nhwc(x, rep=nb)
             for i in range(total_steps):
                 index = total_steps - i - 1
-                eps = model.apply_model_nhwc(x_type, xin, t_table[i], c_type, ctx, control=ctl)
+                eps = model.apply_model_nhwc(x_type, xin, t_table[i], c_type, ctx, control=ctl,
+                                             emb_table=emb_all[i:i + 1])
                 noise = None
                 if self.ddim_sigmas[index] != 0.:
                     noise = noise_like(x) * temperature

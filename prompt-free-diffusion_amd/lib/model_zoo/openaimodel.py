@@ -46,10 +46,12 @@ class TimestepBlock(nn.Module):
 class TimestepEmbedSequential(nn.Sequential, TimestepBlock):
     """Children get the time embedding / the context according to their kind."""
 
-    def hip(self, x, semb, context=None, x2=None):
+    def hip(self, x, semb, context=None, x2=None, emb=None):
+        """semb: SiLU(time embedding) [B, 4C] or None when `emb` = (table [rows, sumC], {id(block): col}, shared)
+        already holds every ResBlock's emb_layers output (UNetModel2D_Next.emb_projections)"""
         for layer in self:
             if isinstance(layer, ResBlock):
-                x, x2 = layer.hip(x, semb, x2=x2), None
+                x, x2 = layer.hip(x, semb, x2=x2, emb=emb), None
             elif isinstance(layer, SpatialTransformer):
                 x = layer.hip(x, context)
             elif isinstance(layer, nn.Sequential):  # UNet head: GN -> SiLU -> conv
@@ -135,15 +137,24 @@ class ResBlock(TimestepBlock):
         else:
             self.skip_connection = L.Conv2d(channels, self.out_channels, 1)
 
-    def hip(self, x, semb, x2=None):
+    def hip(self, x, semb, x2=None, emb=None):
         """x (and optional x2, the skip tensor of a virtual channel concat [x | x2]): NHWC fp16;
-        semb: SiLU(time embedding) [B, emb_channels] fp16."""
+        semb: SiLU(time embedding) [B, emb_channels] fp16; emb: precomputed projections (see
+        TimestepEmbedSequential.hip)."""
         C1 = x.shape[-1]
         C2 = 0 if x2 is None else x2.shape[-1]
         assert C1 + C2 == self.channels
         hn = self.in_layers[0].hip(x, x2, silu=True)                      # [B,H,W,C1+C2]
-        e = self.emb_layers[1].hip(semb)                                   # [B, Cout]
-        h = self.in_layers[2].hip(hn, rowvec=e)                            # conv + bias + emb
+        rows_per_rv = None
+        if emb is not None:
+            table, cols, shared = emb
+            c0 = cols[id(self)]
+            e = table[:, c0:c0 + self.out_channels]                        # view, row stride sumC
+            if shared:                                                     # one timestep for the whole batch
+                rows_per_rv = 1 << 30
+        else:
+            e = self.emb_layers[1].hip(semb)                               # [B, Cout]
+        h = self.in_layers[2].hip(hn, rowvec=e, rows_per_rv=rows_per_rv)   # conv + bias + emb
         h = self.out_layers[0].hip(h, silu=True)
         skip = self.skip_connection
         if isinstance(skip, nn.Identity):
@@ -167,7 +178,7 @@ class ResBlock(TimestepBlock):
 
 
 @register('openai_unet_2d_next')
-class UNetModel2D_Next(nn.Module):
+class UNetModel2D_Next(nn.Module, L._Packed):
     def __init__(self, in_channels, model_channels, out_channels, num_res_blocks, attention_resolutions,
                  context_dim, dropout=0, channel_mult=(1, 2, 4, 8), conv_resample=True, use_checkpoint=False,
                  num_heads=8, num_head_channels=None, parts=['global', 'data', 'context']):
@@ -305,25 +316,53 @@ class UNetModel2D_Next(nn.Module):
         h = self.time_embed[0].hip(t_emb, act=ops.ACT_SILU)
         return self.time_embed[2].hip(h, act=ops.ACT_SILU)
 
-    def hip(self, x, timesteps, context, control=None, context_net=None):
+    def _emb_pack(self):
+        """all 22 ResBlock `emb_layers` Linears as ONE packed weight [sum Cout, 4C] (+ bias, column map)"""
+        blocks = [m for seq in self.data_blocks for m in seq if isinstance(m, ResBlock)]
+        params = [b.emb_layers[1].weight for b in blocks] + [b.emb_layers[1].bias for b in blocks]
+
+        def build():
+            w = torch.cat([L._dev16(b.emb_layers[1].weight) for b in blocks], 0).contiguous()
+            bias = torch.cat([L._dev16(b.emb_layers[1].bias) for b in blocks], 0).contiguous()
+            cols, off = {}, 0
+            for b in blocks:
+                cols[id(b)] = off
+                off += b.out_channels
+            return w, bias, cols
+        return self._packed("emb_cat", build, *params)
+
+    def emb_projections(self, timesteps):
+        """[len(timesteps), sum Cout] = every ResBlock's `emb_layers(emb)` for the given timesteps in
+        one GEMM (the reference runs 22 SiLU+Linear pairs per forward, openaimodel.py:217-223, :262)"""
+        w, bias, cols = self._emb_pack()
+        return ops.gemm(self.silu_time_embedding(timesteps), w, bias=bias), cols
+
+    def hip(self, x, timesteps, context, control=None, context_net=None, emb_table=None):
         """The forward that pfd.apply_model defines (pfd.py:314-365, :466-528), NHWC fp16 in/out.
         control: list of 13 NHWC residuals from ControlNet (popped from the end) or None.
-        context_net: the UNet that owns the context blocks (defaults to self)."""
+        context_net: the UNet that owns the context blocks (defaults to self).
+        emb_table: optional [1, sum Cout] row of `emb_projections` valid for EVERY sample of the
+        batch (the sampler precomputes all steps at once); otherwise computed here per sample."""
         cnet = self if context_net is None else context_net
-        semb = self.silu_time_embedding(timesteps)
+        if emb_table is not None:
+            emb = (emb_table, self._emb_pack()[2], True)
+        else:
+            table, cols = self.emb_projections(timesteps)
+            emb = (table, cols, False)
+        semb = None
         d_iter, c_iter = iter(self.data_blocks), iter(cnet.context_blocks)
         ccs = list(control) if control is not None else None
         hs = []
         h = x
         for ltype in self.i_order:
             if ltype == 'd':
-                h = next(d_iter).hip(h, semb)
+                h = next(d_iter).hip(h, semb, emb=emb)
             elif ltype == 'c':
                 h = next(c_iter).hip(h, semb, context)
             else:
                 hs.append(h)
         for ltype in self.m_order:
-            h = next(d_iter).hip(h, semb) if ltype == 'd' else next(c_iter).hip(h, semb, context)
+            h = next(d_iter).hip(h, semb, emb=emb) if ltype == 'd' else next(c_iter).hip(h, semb, context)
         if ccs is not None:
             h = ops.add(h, ccs.pop())
         skip = None
@@ -333,7 +372,7 @@ class UNetModel2D_Next(nn.Module):
                 if ccs is not None:
                     skip = ops.add(skip, ccs.pop())
             elif ltype == 'd':
-                h, skip = next(d_iter).hip(h, semb, x2=skip), None
+                h, skip = next(d_iter).hip(h, semb, x2=skip, emb=emb), None
             else:
                 h = next(c_iter).hip(h, semb, context)
         return h

@@ -154,14 +154,15 @@ class PromptFreeDiffusion(nn.Module):
         return None
 
     @torch.no_grad()
-    def apply_model_nhwc(self, x_type, x_nhwc, timesteps, c_type, context, control=None):
+    def apply_model_nhwc(self, x_type, x_nhwc, timesteps, c_type, context, control=None, emb_table=None):
         """x_nhwc fp16 [B,h,w,C]; context ContextKV; -> eps NHWC fp16"""
         unet = self.diffuser[x_type]
         gnet = unet if self.global_layer_ptr is None else self.diffuser[self.global_layer_ptr]
         if gnet is not unet:
             raise NotImplementedError("separate global-layer diffuser")
         ccs = self._control_residuals(x_nhwc, timesteps, context, control)
-        return unet.hip(x_nhwc, timesteps, context, control=ccs, context_net=self.diffuser[c_type])
+        return unet.hip(x_nhwc, timesteps, context, control=ccs, context_net=self.diffuser[c_type],
+                        emb_table=emb_table)
 
     @torch.no_grad()
     def apply_model(self, x_info, timesteps, c_info):
