@@ -60,7 +60,7 @@ __device__ __forceinline__ void glds16(const void* src, void* lds_dst) {
                                    (__attribute__((address_space(3))) void*)lds_dst, 16, 0, 0);
 }
 
-template <int WAVES_M, int WMB, bool CONV>
+template <int WAVES_M, int WMB, bool CONV, int NSTAGE>
 __global__ __launch_bounds__(WAVES_M * 128) void gemm160_kernel(const G160Params p) {
   constexpr int NW = WAVES_M * 2;
   constexpr int NT = NW * 64;
@@ -70,7 +70,8 @@ __global__ __launch_bounds__(WAVES_M * 128) void gemm160_kernel(const G160Params
   constexpr int A_PER_WAVE = A_INSTR / NW;         // 4, 4, 2
   constexpr int B_PER_WAVE = (B_INSTR + NW - 1) / NW;
   constexpr int STAGE = (BM + BN) * ROWB;
-  constexpr int MAIN_BYTES = 2 * STAGE;
+  constexpr int MAIN_BYTES = NSTAGE * STAGE;
+  static_assert(MAIN_BYTES <= 160 * 1024, "operand ring exceeds the 160 KiB LDS");
   constexpr int EPI_BYTES = NW * EP_WAVE_BYTES;
   constexpr int SMEM = MAIN_BYTES > EPI_BYTES ? MAIN_BYTES : EPI_BYTES;
   static_assert(A_INSTR % NW == 0, "A tile must split evenly over the waves");
@@ -203,6 +204,9 @@ __global__ __launch_bounds__(WAVES_M * 128) void gemm160_kernel(const G160Params
   const int a_row0 = wm * WMB * 16 * ROWB;
   const int b_row0 = BM * ROWB + wn * 80 * ROWB;
 
+  // (A 3-/4-stage LDS ring with counted vmcnt waits was A/B-tested against this 2-stage loop in one run:
+  //  conv 64^2 893 -> 803 TF, conv 32^2 743 -> 540, qkv 480 -> 457 -- slower everywhere, so it was dropped;
+  //  profiles/r01_selftest_ring_ab.log.)
   if (kt_begin < kt_end) {
     issue(0, kt_begin);
     __builtin_amdgcn_s_waitcnt(0);  // vmcnt(0): tile 0 landed
@@ -233,9 +237,6 @@ __global__ __launch_bounds__(WAVES_M * 128) void gemm160_kernel(const G160Params
   float* Es = reinterpret_cast<float*>(smem + wave * EP_WAVE_BYTES);
   const bool geglu = p.act == PFD_ACT_GEGLU;
   const bool raw = p.splits > 1;
-  const bool vec_ok = ((p.ldc & 7) == 0) && (p.R == nullptr || (p.ldr & 7) == 0) &&
-                      ((reinterpret_cast<uintptr_t>(p.C) & 15) == 0) &&
-                      (p.R == nullptr || (reinterpret_cast<uintptr_t>(p.R) & 15) == 0);
 #pragma unroll
   for (int h = 0; h < WMB / 2; ++h) {
 #pragma unroll
@@ -254,46 +255,59 @@ __global__ __launch_bounds__(WAVES_M * 128) void gemm160_kernel(const G160Params
               *reinterpret_cast<const float4_t*>(Es + rr * EP_LD + cc * 4);
       }
     } else if (geglu) {
-      for (int idx = lane; idx < 32 * 5; idx += 64) {
+      // loads first (all items), then math: one exposed latency per pass instead of one per item
+      Pack16 bx[3], bg[3];
+#pragma unroll
+      for (int t = 0; t < 3; ++t) {
+        const int idx = lane + 64 * t;
+        const int rr = idx / 5, cc = idx - rr * 5;
+        const int nx = n0 + wn * 80 + cc * 8;  // packed-weight row of the x half; gate = +40
+        bx[t].u = bg[t].u = make_uint4(0, 0, 0, 0);
+        if (p.bias && idx < 160) {
+          bx[t].u = *reinterpret_cast<const uint4*>(p.bias + nx);
+          bg[t].u = *reinterpret_cast<const uint4*>(p.bias + nx + 40);
+        }
+      }
+#pragma unroll
+      for (int t = 0; t < 3; ++t) {
+        const int idx = lane + 64 * t;
         const int rr = idx / 5, cc = idx - rr * 5;
         const int m = mrow0 + rr;
-        if (m >= p.M) continue;
-        const int nx = n0 + wn * 80 + cc * 8;  // packed-weight row of the x half; gate = +40
-        Pack16 bx, bg, o;
-        bx.u = bg.u = make_uint4(0, 0, 0, 0);
-        if (p.bias) {
-          bx.u = *reinterpret_cast<const uint4*>(p.bias + nx);
-          bg.u = *reinterpret_cast<const uint4*>(p.bias + nx + 40);
-        }
+        if (idx >= 160 || m >= p.M) continue;
+        Pack16 o;
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-          const float xv = Es[rr * EP_LD + cc * 8 + e] + (float)bx.e[e];
-          const float gv = Es[rr * EP_LD + 40 + cc * 8 + e] + (float)bg.e[e];
+          const float xv = Es[rr * EP_LD + cc * 8 + e] + (float)bx[t].e[e];
+          const float gv = Es[rr * EP_LD + 40 + cc * 8 + e] + (float)bg[t].e[e];
           o.e[e] = (half_t)(xv * pfd_gelu(gv));
         }
         *reinterpret_cast<uint4*>(p.C + (long)m * p.ldc + (n0 >> 1) + wn * 40 + cc * 8) = o.u;
       }
     } else {
-      for (int idx = lane; idx < 32 * 10; idx += 64) {
+      Pack16 lb[5], lv[5], lr[5];
+#pragma unroll
+      for (int t = 0; t < 5; ++t) {
+        const int idx = lane + 64 * t;
+        const int rr = idx / 10, cc = idx - rr * 10;
+        const int m = mrow0 + rr;
+        const int n = n0 + wn * 80 + cc * 8;
+        lb[t].u = lv[t].u = lr[t].u = make_uint4(0, 0, 0, 0);
+        if (m < p.M) {
+          if (p.bias) lb[t].u = *reinterpret_cast<const uint4*>(p.bias + n);
+          if (p.rowvec) lv[t].u = *reinterpret_cast<const uint4*>(p.rowvec + (long)(m / p.rows_per_rv) * p.ldrv + n);
+          if (p.R) lr[t].u = *reinterpret_cast<const uint4*>(p.R + (long)m * p.ldr + n);
+        }
+      }
+#pragma unroll
+      for (int t = 0; t < 5; ++t) {
+        const int idx = lane + 64 * t;
         const int rr = idx / 10, cc = idx - rr * 10;
         const int m = mrow0 + rr;
         if (m >= p.M) continue;
         const int n = n0 + wn * 80 + cc * 8;
         float v[8];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = Es[rr * EP_LD + cc * 8 + e];
-        if (p.bias) {
-          Pack16 b;
-          b.u = *reinterpret_cast<const uint4*>(p.bias + n);
-#pragma unroll
-          for (int e = 0; e < 8; ++e) v[e] += (float)b.e[e];
-        }
-        if (p.rowvec) {
-          Pack16 b;
-          b.u = *reinterpret_cast<const uint4*>(p.rowvec + (long)(m / p.rows_per_rv) * p.ldrv + n);
-#pragma unroll
-          for (int e = 0; e < 8; ++e) v[e] += (float)b.e[e];
-        }
+        for (int e = 0; e < 8; ++e) v[e] = Es[rr * EP_LD + cc * 8 + e] + (float)lb[t].e[e] + (float)lv[t].e[e];
         if (p.act == PFD_ACT_GELU) {
 #pragma unroll
           for (int e = 0; e < 8; ++e) v[e] = pfd_gelu(v[e]);
@@ -304,24 +318,10 @@ __global__ __launch_bounds__(WAVES_M * 128) void gemm160_kernel(const G160Params
 #pragma unroll
           for (int e = 0; e < 8; ++e) v[e] = pfd_silu(v[e]);
         }
-        if (vec_ok) {
-          if (p.R) {
-            Pack16 r;
-            r.u = *reinterpret_cast<const uint4*>(p.R + (long)m * p.ldr + n);
+        Pack16 o;
 #pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] += (float)r.e[e];
-          }
-          Pack16 o;
-#pragma unroll
-          for (int e = 0; e < 8; ++e) o.e[e] = (half_t)v[e];
-          *reinterpret_cast<uint4*>(p.C + (long)m * p.ldc + n) = o.u;
-        } else {
-          for (int e = 0; e < 8; ++e) {
-            float x = v[e];
-            if (p.R) x += (float)p.R[(long)m * p.ldr + n + e];
-            p.C[(long)m * p.ldc + n + e] = (half_t)x;
-          }
-        }
+        for (int e = 0; e < 8; ++e) o.e[e] = (half_t)(v[e] + (float)lr[t].e[e]);
+        *reinterpret_cast<uint4*>(p.C + (long)m * p.ldc + n) = o.u;
       }
     }
   }
@@ -366,7 +366,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const G160Params p) 
   }
 }
 
-template <int WAVES_M, int WMB>
+template <int WAVES_M, int WMB, int NSTAGE = 2>
 int launch160(G160Params& p, int bucket, hipStream_t s) {
   constexpr int BM = WAVES_M * WMB * 16;
   p.tiles_m = (p.M + BM - 1) / BM;
@@ -382,9 +382,9 @@ int launch160(G160Params& p, int bucket, hipStream_t s) {
     pfd_prof_begin(bucket, 2.0 * p.M * p.N * p.K, a_bytes + 2.0 * p.N * p.K + 2.0 * p.M * n_out * (p.R ? 2 : 1), s);
   }
   if (p.ksize > 0)
-    hipLaunchKernelGGL((gemm160_kernel<WAVES_M, WMB, true>), grid, dim3(WAVES_M * 128), 0, s, p);
+    hipLaunchKernelGGL((gemm160_kernel<WAVES_M, WMB, true, NSTAGE>), grid, dim3(WAVES_M * 128), 0, s, p);
   else
-    hipLaunchKernelGGL((gemm160_kernel<WAVES_M, WMB, false>), grid, dim3(WAVES_M * 128), 0, s, p);
+    hipLaunchKernelGGL((gemm160_kernel<WAVES_M, WMB, false, NSTAGE>), grid, dim3(WAVES_M * 128), 0, s, p);
   if (p.splits > 1) {
     const long nvec = (long)p.M * (p.N / 8);
     int g = (int)((nvec + 255) / 256);
@@ -405,6 +405,7 @@ int pfd_gemm160_try(const PfdGemmDesc* d, int variant, int splits, hipStream_t s
   if (d->act == PFD_ACT_GEGLU && (d->rowvec || d->R)) return 1;
   if ((d->ldc & 7) || (reinterpret_cast<uintptr_t>(d->C) & 15)) return 1;
   if (d->bias && (reinterpret_cast<uintptr_t>(d->bias) & 15)) return 1;
+  if (d->R && ((d->ldr & 7) || (reinterpret_cast<uintptr_t>(d->R) & 15))) return 1;
   if (d->rowvec && ((d->ldrv & 7) || (reinterpret_cast<uintptr_t>(d->rowvec) & 15))) return 1;
   G160Params p;
   p.A = (const half_t*)d->A; p.W = (const half_t*)d->W; p.bias = (const half_t*)d->bias;
@@ -431,17 +432,19 @@ int pfd_gemm160_try(const PfdGemmDesc* d, int variant, int splits, hipStream_t s
     splits = 1;
     const long tl = tiles(bm);
     const int nk = p.K / BK;
-    if (p.act != PFD_ACT_GEGLU && d->ws && variant == 44 && tl < 200 && nk >= 32 &&
+    if (p.act != PFD_ACT_GEGLU && d->ws && variant == 44 && tl < 200 && nk >= 48 &&
         (size_t)2 * p.M * p.N * 4 <= d->ws_bytes) {
       splits = 2;  // 128 tiles of 256x160: two K halves fill the chip (758 vs 579 TF at 640->640 @32^2)
     } else if (p.act != PFD_ACT_GEGLU && d->ws && variant != 44 && tl < 256) {
       splits = (int)((512 + tl - 1) / tl);
       if (splits > 8) splits = 8;
-      while (splits > 1 && nk / splits < 8) --splits;
+      while (splits > 1 && nk / splits < 24) --splits;  // the slab round trip must stay small vs the K loop
       while (splits > 1 && (size_t)splits * p.M * p.N * 4 > d->ws_bytes) --splits;
     }
   }
   if (splits > 1 && (!d->ws || (size_t)splits * p.M * p.N * 4 > d->ws_bytes || p.act == PFD_ACT_GEGLU)) splits = 1;
+  // short-K problems that did not qualify for split-K: rather 256 small tiles than 128 blocks on 256 CUs
+  if (auto_variant && variant == 24 && splits == 1 && tiles(128) < 200 && tiles(64) > tiles(128)) variant = 22;
   p.splits = splits;
   const int conv = p.ksize > 0 ? 1 : 0;
   switch (variant) {

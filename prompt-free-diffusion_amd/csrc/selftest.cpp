@@ -638,9 +638,13 @@ int main(int argc, char** argv) {
 
   if (bench || only_bench) {
     // UNet-shaped problems at C2 (UNet batch 8)
-    for (int t : {22, 5400, 3400, 0}) {
-      bench_gemm("conv3x3 320->320 @64^2", 0, 320, 0, 3, 8, 64, 320, t);
-    }
+    for (int rep = 0; rep < 2; ++rep)
+      for (int t : {5400, 3400}) {
+        bench_gemm("conv3x3 320->320 @64^2", 0, 320, 0, 3, 8, 64, 320, t);
+        bench_gemm("linear qkv 320->960 @64^2", 32768, 960, 320, 0, 0, 0, 0, t);
+        bench_gemm("linear 1280->320 @64^2", 32768, 320, 1280, 0, 0, 0, 0, t);
+        bench_gemm("conv3x3 640->640 @32^2", 0, 640, 0, 3, 8, 32, 640, t);
+      }
     for (int t : {5400, 5402, 5403, 3402, 0}) bench_gemm("conv3x3 640->640 @32^2", 0, 640, 0, 3, 8, 32, 640, t);
     for (int t : {5400, 5402, 0}) bench_gemm("conv3x3 1920->640 @32^2", 0, 640, 0, 3, 8, 32, 1920, t);
     for (int t : {3400, 3200, 3402, 3404, 3202, 0}) bench_gemm("conv3x3 1280->1280 @16^2", 0, 1280, 0, 3, 8, 16, 1280, t);
