@@ -63,8 +63,16 @@ __global__ __launch_bounds__(256) void attention_kernel(const AttnParams p) {
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l31 = lane & 31, hi = lane >> 5;
-  const int h = blockIdx.y, b = blockIdx.z;
-  const int q_row = blockIdx.x * 128 + wave * 32 + l31;
+  // 1-D grid, XCD-aware: block id -> (sample*head, q block) such that all q blocks of one head run
+  // on ONE XCD (block b lands on XCD b % 8) and share that L2's copy of the head's K/V.  Without
+  // it every XCD fetches its own copy: 357 MB instead of 63 MB per launch at N = 4096 (PMC
+  // FETCH_SIZE, profiles/r01_pmc_traffic_per_shape.md).  Placement is speed only.
+  const int nqb = (p.Nq + 127) / 128;
+  const int lin = xcd_remap(blockIdx.x, gridDim.x);
+  const int bh = lin / nqb;
+  const int qb = lin - bh * nqb;
+  const int b = bh / p.H, h = bh - b * p.H;
+  const int q_row = qb * 128 + wave * 32 + l31;
 
   // zero the LDS padding once (columns D..DQK of K, rows D..DV of V^T); row D of V^T = 1 (row sums)
   for (int i = tid; i < 2 * K_TILE_HALFS; i += 256) Ks[i] = (half_t)0.f;
@@ -289,7 +297,7 @@ __global__ __launch_bounds__(256) void attention_kernel(const AttnParams p) {
 
 template <int D>
 int launch(const AttnParams& p, hipStream_t s) {
-  dim3 grid((p.Nq + 127) / 128, p.H, p.B);
+  dim3 grid(((p.Nq + 127) / 128) * p.H * p.B);
   const bool prof = pfd_prof_on();
   if (prof)
     pfd_prof_begin(8, 4.0 * p.B * p.H * (double)p.Nq * p.Nk * D,

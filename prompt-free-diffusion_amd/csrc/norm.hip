@@ -88,49 +88,48 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(GnSrc s, int HW, int G, i
   }
 }
 
-__global__ __launch_bounds__(256) void gn_finalize_kernel(const float* __restrict__ partial, int nchunks, int G,
-                                                         float count, float eps, float* __restrict__ stats) {
-  // one block per sample; thread (part, g) sums chunks part, part+P, ... then an LDS tree over parts
-  __shared__ float ra[256], rq[256];
-  const int b = blockIdx.x, tid = threadIdx.x;
-  const int P = 256 / G;  // G <= 64 -> P >= 4
-  const int g = tid % G, part = tid / G;
-  float a = 0.f, q = 0.f;
-  if (part < P) {
-    for (int k = part; k < nchunks; k += P) {
-      const float2 v = *reinterpret_cast<const float2*>(partial + (((long)b * nchunks + k) * G + g) * 2);
-      a += v.x;
-      q += v.y;
-    }
-  }
-  ra[tid] = a;
-  rq[tid] = q;
-  __syncthreads();
-  if (tid < G) {
-    for (int k = 1; k < P; ++k) {
-      a += ra[k * G + tid];
-      q += rq[k * G + tid];
-    }
-    const float mean = a / count;
-    const float var = fmaxf(q / count - mean * mean, 0.f);
-    stats[((long)b * G + tid) * 2] = mean;
-    stats[((long)b * G + tid) * 2 + 1] = rsqrtf(var + eps);
-  }
-}
-
 __global__ __launch_bounds__(256) void gn_apply_kernel(GnSrc s, const half_t* __restrict__ gamma,
                                                        const half_t* __restrict__ beta,
-                                                       const float* __restrict__ stats, half_t* __restrict__ y,
-                                                       long ldy, int HW, int G, int rows_per_chunk, int act) {
+                                                       const float* __restrict__ partial, half_t* __restrict__ y,
+                                                       long ldy, int HW, int G, int rows_per_chunk, int act,
+                                                       int nchunks, float count, float eps) {
   __shared__ float sc[4096], sh[4096];
+  __shared__ float ra[256], rq[256], gmean[GN_MAX_G], grstd[GN_MAX_G];
   const int C = s.C1 + s.C2;
   const int nvec = C / 8;
   const int cpg = C / G;
   const int b = blockIdx.y, chunk = blockIdx.x, tid = threadIdx.x;
+  // finalize in the prologue (was a separate 5 us launch): every block reduces the nchunks x G
+  // partial sums of ITS sample (<= 64 KB, L2 resident) -- thread (part, g) sums chunks part, part+P, ...
+  {
+    const int P = 256 / G;
+    const int g = tid % G, part = tid / G;
+    float a = 0.f, q = 0.f;
+    if (part < P) {
+      for (int k = part; k < nchunks; k += P) {
+        const float2 v = *reinterpret_cast<const float2*>(partial + (((long)b * nchunks + k) * G + g) * 2);
+        a += v.x;
+        q += v.y;
+      }
+    }
+    ra[tid] = a;
+    rq[tid] = q;
+    __syncthreads();
+    if (tid < G) {
+      for (int k = 1; k < P; ++k) {
+        a += ra[k * G + tid];
+        q += rq[k * G + tid];
+      }
+      const float mean = a / count;
+      gmean[tid] = mean;
+      grstd[tid] = rsqrtf(fmaxf(q / count - mean * mean, 0.f) + eps);
+    }
+    __syncthreads();
+  }
   for (int c = tid; c < C; c += 256) {
     const int g = c / cpg;
-    const float mean = stats[((long)b * G + g) * 2];
-    const float rstd = stats[((long)b * G + g) * 2 + 1];
+    const float mean = gmean[g];
+    const float rstd = grstd[g];
     const float w = rstd * (float)gamma[c];
     sc[c] = w;
     sh[c] = (float)beta[c] - mean * w;
@@ -314,8 +313,9 @@ extern "C" int pfd_groupnorm_f16(const void* x1, int32_t C1, int64_t ldx1, const
   GnSrc src{(const half_t*)x1, (const half_t*)x2, ldx1, ldx2, C1, C2};
   const int nvec = C / 8;
   const int RT = nvec < 256 ? 256 / nvec : 1;
-  // aim for ~1024 blocks over the chip, at least 4 row sweeps per block
-  int nchunks = (1024 + B - 1) / B;
+  // aim for ~512 blocks over the chip, at least 4 row sweeps per block (every apply block re-reduces
+  // its sample's nchunks x G partials, so nchunks stays moderate)
+  int nchunks = (512 + B - 1) / B;
   const int max_by_rows = (HW + RT * 4 - 1) / (RT * 4);
   if (nchunks > max_by_rows) nchunks = max_by_rows;
   if (nchunks > GN_MAX_CHUNKS) nchunks = GN_MAX_CHUNKS;
@@ -323,14 +323,12 @@ extern "C" int pfd_groupnorm_f16(const void* x1, int32_t C1, int64_t ldx1, const
   const int rpc = (HW + nchunks - 1) / nchunks;
   nchunks = (HW + rpc - 1) / rpc;
   float* partial = (float*)ws;
-  float* stats = partial + (size_t)B * GN_MAX_CHUNKS * GN_MAX_G * 2;
   const bool prof = pfd_prof_on();
   if (prof) pfd_prof_begin(10, 8.0 * B * HW * C, 6.0 * B * HW * C, s);  // 2B stats read + 2B read + 2B write
   hipLaunchKernelGGL(gn_stats_kernel, dim3(nchunks, B), dim3(256), 0, s, src, HW, G, rpc, partial);
-  hipLaunchKernelGGL(gn_finalize_kernel, dim3(B), dim3(256), 0, s, partial, nchunks, G,
-                     (float)HW * (float)(C / G), eps, stats);
   hipLaunchKernelGGL(gn_apply_kernel, dim3(nchunks, B), dim3(256), 0, s, src, (const half_t*)gamma,
-                     (const half_t*)beta, stats, (half_t*)y, (long)ldy, HW, G, rpc, act);
+                     (const half_t*)beta, partial, (half_t*)y, (long)ldy, HW, G, rpc, act, nchunks,
+                     (float)HW * (float)(C / G), eps);
   if (prof) pfd_prof_end(s);
   return pfd_check_launch("pfd_groupnorm_f16");
 }
