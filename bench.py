@@ -83,6 +83,7 @@ def main():
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch N>1 with: python -m torch.distributed.run --nnodes=1 --nproc-per-node N "
                              "--master-addr 127.0.0.1 --master-port P bench.py --gpus N ...")
+    local = local % max(1, torch.cuda.device_count())
     torch.cuda.set_device(local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -98,9 +99,9 @@ def main():
     image = torch.rand((1, 3, args.height, args.width), generator=torch.Generator().manual_seed(1234))
     n_global = args.batch * world
 
-    def step(i):
+    def step(i, gather=True):
         img, _ = pipe.generate(image, n_global, args.height, args.width, steps=args.ddim_steps, scale=args.scale,
-                               eta=0.0, seed=20 + i, gather=True)
+                               eta=0.0, seed=20 + i, gather=gather)
         return img
 
     for i in range(args.warmup):
@@ -130,7 +131,7 @@ def main():
         # instrumented batch (identical kernels, shapes and data path; not part of `value`)
         pipe.sampler.enable_graph(False)
         binding.prof_enable(True)
-        step(999)
+        step(999, gather=False)   # rank-0 only: must not enter the collective
         torch.cuda.synchronize()
         prof, prof_steps, prof_where = binding.prof_read(), 1, "instrumented eager replica of one timed step"
         pipe.sampler.enable_graph(True)

@@ -6,6 +6,7 @@ Layout convention of the whole product path: activations are fp16, token-major /
 reference API boundary (ops.to_nhwc / ops.to_nchw).
 """
 import ctypes as C
+import os
 
 import torch
 
@@ -37,6 +38,18 @@ def _workspace(device):
     if ws is None:
         ws = _WS[device] = torch.empty(_WS_BYTES, dtype=torch.uint8, device=device)
     return ws
+
+
+_TRACE = os.environ.get("PFD_TRACE_GEMM")
+
+
+def _trace(d):
+    """PFD_TRACE_GEMM=<file>: append one line per GEMM/conv launch (shape replay for tools/selftest --replay,
+    used to measure HBM traffic with rocprofv3 --pmc on a torch-free process)"""
+    with open(_TRACE, "a") as f:
+        f.write(" ".join(str(int(v)) for v in (
+            d.M, d.N, d.K, d.act, d.bias is not None, d.rowvec is not None, d.R is not None, d.bias_per_row,
+            d.ksize, d.stride, d.pad, d.ups, d.B, d.H, d.Wd, d.Cin, d.Ho, d.Wo, d.rows_per_rv)) + "\n")
 
 
 def _chk16(t, what):
@@ -90,6 +103,8 @@ def gemm(a, w, *, bias=None, rowvec=None, rows_per_rv=1, res=None, act=ACT_NONE,
     d.rows_per_rv, d.act, d.bias_per_row = rows_per_rv, act, 1 if bias_per_row else 0
     d.ksize = 0
     d.ws, d.ws_bytes = _workspace(a.device).data_ptr(), _WS_BYTES
+    if _TRACE:
+        _trace(d)
     lib = _lib()
     rc = lib.pfd_gemm_f16_ex(_byref(d), tile, _stream()) if tile else lib.pfd_gemm_f16(_byref(d), _stream())
     _b.check(rc, f"pfd_gemm_f16 M{M} N{N} K{K}")
@@ -132,6 +147,8 @@ def conv(x, w, ksize, *, stride=1, pad=None, ups=False, bias=None, rowvec=None, 
     d.ksize, d.stride, d.pad, d.ups = ksize, stride, pad, 1 if ups else 0
     d.B, d.H, d.Wd, d.Cin, d.Ho, d.Wo = B, H, W_, Cin, Ho, Wo
     d.ws, d.ws_bytes = _workspace(x.device).data_ptr(), _WS_BYTES
+    if _TRACE:
+        _trace(d)
     lib = _lib()
     rc = lib.pfd_gemm_f16_ex(_byref(d), tile, _stream()) if tile else lib.pfd_gemm_f16(_byref(d), _stream())
     _b.check(rc, f"pfd_gemm_f16(conv) M{M} N{N} K{K}")

@@ -1,0 +1,36 @@
+#!/usr/bin/env python
+"""Record the GEMM/conv launch list of ONE UNet forward at BASELINE config C2 (512x512, batch 4 -> UNet batch 8)
+into profiles/unet_c2_gemm_shapes.txt (PFD_TRACE_GEMM).  `selftest --replay` relaunches exactly these shapes in a
+torch-free process so rocprofv3 --pmc can count their HBM traffic (PMC on the python process crashes rocprofv3 here)."""
+import os
+import sys
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+out = os.path.join(REPO, "profiles", "unet_c2_gemm_shapes.txt")
+if os.path.exists(out):
+    os.remove(out)
+os.environ["PFD_TRACE_GEMM"] = out
+os.environ.setdefault("PFD_QUIET", "1")
+sys.path.insert(0, os.path.join(REPO, "prompt-free-diffusion_amd"))
+import torch  # noqa: E402
+from lib.hip import ops  # noqa: E402
+from lib.pipeline import build_model  # noqa: E402
+
+net = build_model('pfd_seecoder', device='cuda', fp16=True)
+B = 8
+x = torch.randn(B, 4, 64, 64, device='cuda')
+c = torch.randn(B, 148, 768, device='cuda', dtype=torch.float16)
+t = torch.full((B,), 981, device='cuda', dtype=torch.long)
+ctx = net.prepare_context(c)
+unet = net.diffuser['image']
+emb_all, _ = unet.emb_projections(t[:1])
+xin = ops.to_nhwc(x)
+for k, v in list(ctx._kv.items()):
+    pass
+# warm the context K/V cache and packed weights outside the recorded forward
+net.apply_model_nhwc('image', xin, t, 'image', ctx, emb_table=emb_all)
+torch.cuda.synchronize()
+open(out, "w").close()
+net.apply_model_nhwc('image', xin, t, 'image', ctx, emb_table=emb_all)
+torch.cuda.synchronize()
+print("wrote", out, sum(1 for _ in open(out)), "launches")
