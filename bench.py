@@ -69,10 +69,16 @@ def main():
     ap.add_argument("--width", type=int, default=512)
     ap.add_argument("--ddim-steps", type=int, default=50)
     ap.add_argument("--scale", type=float, default=2.0)
+    ap.add_argument("--config", default="c2", choices=["c2", "c3", "c5"],
+                    help="BASELINE.json config: c2 = headline (default); c3 = + ControlNet + SeeCoder-PA; "
+                         "c5 = 768x768, 30 (->31) steps, batch 2, non-zero unconditional context")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-prof", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="launch the DDIM loop eagerly instead of one hipGraph")
     args = ap.parse_args()
+    if args.config == "c5":
+        args.height = args.width = 768
+        args.ddim_steps, args.batch = 30, 2
 
     import torch
     import torch.distributed as dist
@@ -93,15 +99,28 @@ def main():
     from lib.pipeline import PromptFreePipeline, build_model
     import contextlib
     with contextlib.redirect_stdout(sys.stderr):   # constructors print (like the reference's); keep stdout = the JSON line
-        net = build_model('pfd_seecoder', device=f'cuda:{local}', fp16=True)
+        net = build_model('pfd_seecoder_with_controlnet' if args.config == "c3" else 'pfd_seecoder',
+                          device=f'cuda:{local}', fp16=True)
+        if args.config == "c3":   # SeeCoder-PA: attach the position-aware MLP like app.py:166-177
+            from lib.model_zoo.seecoder import PPE_MLP
+            pe = PPE_MLP(freq_num=20, freq_max=None, out_channel=768, mlp_layer=3)
+            torch.nn.init.normal_(pe.mlp[-1].weight, std=768 ** -0.5)
+            net.ctx['image'].qtransformer.pe_layer = pe.half().to(f'cuda:{local}')
     pipe = PromptFreePipeline(net, rank=rank, world_size=world)
     pipe.sampler.enable_graph(not args.no_graph)
     image = torch.rand((1, 3, args.height, args.width), generator=torch.Generator().manual_seed(1234))
     n_global = args.batch * world
+    gen = torch.Generator().manual_seed(4321)
+    control = torch.rand((1, 3, args.height, args.width), generator=gen) if args.config == "c3" else None
+    uncond = None
+    if args.config == "c5":  # SeeCoder-Anime: fixed [77,768] unconditional context zero-padded to 148 (app.py:238-241)
+        ug = torch.zeros((1, 148, 768), dtype=torch.float16)
+        ug[:, :77] = (torch.randn((1, 77, 768), generator=gen) - 0.1).half()
+        uncond = ug.repeat(args.batch, 1, 1).to(f'cuda:{local}')
 
     def step(i, gather=True):
         img, _ = pipe.generate(image, n_global, args.height, args.width, steps=args.ddim_steps, scale=args.scale,
-                               eta=0.0, seed=20 + i, gather=gather)
+                               eta=0.0, seed=20 + i, gather=gather, control=control, uncond=uncond)
         return img
 
     for i in range(args.warmup):
@@ -145,14 +164,15 @@ def main():
     if rank == 0:
         ddim_real = len(pipe.sampler.ddim_timesteps)
         res = {
-            "metric": "images/sec @512x512 50-step DDIM, SD-v1.5+SeeCoder",
+            "metric": f"images/sec @{args.height}x{args.width} {args.ddim_steps}-step DDIM, SD-v1.5+SeeCoder",
             "value": n_global * args.steps / dt,
             "unit": "images/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f16", "data": "synthetic",
-            "config": {"workload": f"SD-v1.5 UNet + seecoder-v1-0, {args.height}x{args.width}, "
+            "config": {"workload": f"[{args.config}] SD-v1.5 UNet + seecoder-v1-0"
+                                   f"{' + ControlNet + PPE_MLP' if args.config == 'c3' else ''}, {args.height}x{args.width}, "
                                    f"{args.ddim_steps}-step DDIM ({ddim_real} real steps), CFG {args.scale}, fp16, "
                                    f"batch={args.batch}/GPU, 1 SeeCoder encode + VAE decode per batch",
                        "global_batch": n_global, "parallelism": f"dp{world}"},
