@@ -108,35 +108,40 @@ __global__ __launch_bounds__(256) void attention_kernel(const AttnParams p) {
   const half_t* vbase = p.Vt + (long)h * D * p.ldvt + (long)b * p.vt_bs;
   const float c = p.scale_log2;
 
-  // two staging register sets: tile t+1 and tile t+2 are in flight while tile t is computed
-  // (an L2-hit K/V load takes longer than one tile of MFMA+softmax work)
-  constexpr bool DEEP = D <= 48;  // wider heads have no registers to spare (and far fewer tiles)
-  uint4 kregA[K_PT], vregA[V_PT], kregB[DEEP ? K_PT : 1], vregB[DEEP ? V_PT : 1];
+  // one staging register set: tile t+1 is loaded (global -> registers) while tile t is computed and is
+  // written to the other LDS stage afterwards.  Rows / key chunks past Nk are CLAMPED to valid
+  // addresses rather than predicated per row (their scores are masked to -inf, so P = 0).
+  uint4 kregA[K_PT], vregA[V_PT];
+  const int v_last = max(0, ((p.Nk + 7) & ~7) - 8);
   auto load_tile = [&](uint4* kreg, uint4* vreg, int kv0) {
 #pragma unroll
     for (int j = 0; j < K_PT; ++j) {
       const int ch = tid + 256 * j;
       const int row = ch / KCH, cc = ch - row * KCH;
       kreg[j] = make_uint4(0, 0, 0, 0);
-      if (ch < K_CHUNKS && kv0 + row < p.Nk)
-        kreg[j] = *reinterpret_cast<const uint4*>(kbase + (long)(kv0 + row) * p.ldk + cc * 8);
+      if (ch < K_CHUNKS)
+        kreg[j] = *reinterpret_cast<const uint4*>(kbase + (long)min(kv0 + row, p.Nk - 1) * p.ldk + cc * 8);
     }
 #pragma unroll
     for (int j = 0; j < V_PT; ++j) {
       const int ch = tid + 256 * j;
       const int d = ch >> 3, cc = ch & 7;
-      const int kv = kv0 + cc * 8;
-      Pack16 v;
-      v.u = make_uint4(0, 0, 0, 0);
-      if (ch < V_CHUNKS && kv < p.Nk) {
-        v.u = *reinterpret_cast<const uint4*>(vbase + (long)d * p.ldvt + kv);
-        if (kv + 8 > p.Nk) {
+      vreg[j] = make_uint4(0, 0, 0, 0);
+      if (ch < V_CHUNKS)   // key chunks past Nk are clamped (their P is 0); the ragged tile zeroes them below
+        vreg[j] = *reinterpret_cast<const uint4*>(vbase + (long)d * p.ldvt + min(kv0 + cc * 8, v_last));
+    }
+    if (kv0 + KV_TILE > p.Nk) {  // ragged last tile only (wave-uniform)
 #pragma unroll
-          for (int e = 0; e < 8; ++e)
-            if (kv + e >= p.Nk) v.e[e] = (half_t)0.f;
+      for (int j = 0; j < V_PT; ++j) {
+        const int valid = p.Nk - (kv0 + ((tid + 256 * j) & 7) * 8);  // valid halfs in this 8-chunk
+        unsigned w[4] = {vreg[j].x, vreg[j].y, vreg[j].z, vreg[j].w};
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int v2 = valid - 2 * q;
+          w[q] = v2 >= 2 ? w[q] : (v2 == 1 ? (w[q] & 0xFFFFu) : 0u);
         }
+        vreg[j] = make_uint4(w[0], w[1], w[2], w[3]);
       }
-      vreg[j] = v.u;
     }
   };
   auto store_tile = [&](const uint4* kreg, const uint4* vreg, int stage) {
@@ -241,31 +246,13 @@ __global__ __launch_bounds__(256) void attention_kernel(const AttnParams p) {
 
   load_tile(kregA, vregA, 0);
   store_tile(kregA, vregA, 0);
-  if (DEEP) {
-    if (ntiles > 1) load_tile(kregB, vregB, KV_TILE);  // tile 1 -> set B, lands during tile 0
+  __syncthreads();
+  for (int t = 0; t < ntiles; ++t) {
+    const int stage = t & 1;
+    if (t + 1 < ntiles) load_tile(kregA, vregA, (t + 1) * KV_TILE);  // in flight during this tile's MFMAs
+    compute_tile(t, stage);
+    if (t + 1 < ntiles) store_tile(kregA, vregA, stage ^ 1);
     __syncthreads();
-    for (int t = 0; t < ntiles; t += 2) {
-      // even tile t (stage 0): tile t+1 is in flight in set B; start tile t+2 into set A
-      if (t + 2 < ntiles) load_tile(kregA, vregA, (t + 2) * KV_TILE);
-      compute_tile(t, 0);
-      if (t + 1 < ntiles) store_tile(kregB, vregB, 1);
-      __syncthreads();
-      if (t + 1 >= ntiles) break;
-      // odd tile t+1 (stage 1): tile t+2 is in flight in set A; start tile t+3 into set B
-      if (t + 3 < ntiles) load_tile(kregB, vregB, (t + 3) * KV_TILE);
-      compute_tile(t + 1, 1);
-      if (t + 2 < ntiles) store_tile(kregA, vregA, 0);
-      __syncthreads();
-    }
-  } else {
-    __syncthreads();
-    for (int t = 0; t < ntiles; ++t) {
-      const int stage = t & 1;
-      if (t + 1 < ntiles) load_tile(kregA, vregA, (t + 1) * KV_TILE);  // in flight during this tile's MFMAs
-      compute_tile(t, stage);
-      if (t + 1 < ntiles) store_tile(kregA, vregA, stage ^ 1);
-      __syncthreads();
-    }
   }
 
   // ---- epilogue: O[q, d] = O^T[d, q] / l ----
