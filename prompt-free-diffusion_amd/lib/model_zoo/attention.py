@@ -49,6 +49,11 @@ class ContextKV:
         ctx[:, :Nk] = context.to(torch.float16)
         self.ctx2d = ctx.view(B * self.Nkp, Cd)
         self._kv = {}
+        # number of LEADING batch entries whose context is all zero (set by the sampler for the
+        # unconditional half of a CFG batch, app.py:236): for those rows K = V = 0, so cross-attention
+        # returns exactly to_out.bias and the q / attention / out-projection work is skipped
+        # (SURVEY 8a exact saving (i); verified bit-identical in tests/test_hip_parity.py)
+        self.zero_lead = 0
 
     def get(self, attn):
         ent = self._kv.get(id(attn))
@@ -151,10 +156,23 @@ class CrossAttention(nn.Module, L._Packed):
             o = ops.attention(qk, qk[:, Cd:], vt, B, H, N, N, D, self.scale, ldq=2 * Cd, ldk=2 * Cd,
                               ldvt=B * Np, q_bs=N * 2 * Cd, k_bs=N * 2 * Cd, vt_bs=Np)
         else:
-            q = self.to_q.hip(x)
             k, vt = context.get(self)
             if context.B != B:
                 raise ValueError(f"context batch {context.B} != activation batch {B}")
+            z = context.zero_lead
+            if 0 < z < B and res is not None:
+                # rows of the first z samples: x + bias; the remaining samples: the real thing
+                Bc = B - z
+                out = torch.empty_like(res)
+                w_o, b_o = self.to_out[0]._pk()
+                ops.add_rowvec(res[:z * N], b_o, out=out[:z * N])
+                q = self.to_q.hip(x[z * N:])
+                o = ops.attention(q, k[z * context.Nkp:], vt[:, z * context.Nkp:], Bc, H, N, context.Nk, D,
+                                  self.scale, ldq=Cd, ldk=Cd, ldvt=B * context.Nkp, q_bs=N * Cd,
+                                  k_bs=context.Nkp * Cd, vt_bs=context.Nkp)
+                self.to_out[0].hip(o, res=res[z * N:], out=out[z * N:])
+                return out
+            q = self.to_q.hip(x)
             o = ops.attention(q, k, vt, B, H, N, context.Nk, D, self.scale, ldq=Cd, ldk=Cd,
                               ldvt=B * context.Nkp, q_bs=N * Cd, k_bs=context.Nkp * Cd, vt_bs=context.Nkp)
         return self.to_out[0].hip(o, res=res)
@@ -184,7 +202,13 @@ class BasicTransformerBlock(nn.Module):
 
     def hip(self, x, B, N, context):
         x = self.attn1.hip(self.norm1.hip(x), B, N, context if self.disable_self_attn else None, res=x)
-        x = self.attn2.hip(self.norm2.hip(x), B, N, context, res=x)
+        z = getattr(context, 'zero_lead', 0) if context is not None else 0
+        if 0 < z < B:   # LayerNorm only feeds to_q: skip it for the zero-context samples too
+            xn = torch.empty_like(x)
+            self.norm2.hip(x[z * N:], out=xn[z * N:])
+            x = self.attn2.hip(xn, B, N, context, res=x)
+        else:
+            x = self.attn2.hip(self.norm2.hip(x), B, N, context, res=x)
         x = self.ff.hip(self.norm3.hip(x), res=x)
         return x
 

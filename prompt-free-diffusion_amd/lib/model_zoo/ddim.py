@@ -112,6 +112,9 @@ class DDIMSampler(object):
         cfg = not ((scale == 1.) or (uc is None))
         c_in = torch.cat([uc, cond]) if cfg else cond   # uncond first, like ddim.py:147
         c_info['c'] = c_in
+        # all-zero unconditional context (SeeCoder / SeeCoder-PA, app.py:236): its cross-attention is
+        # exactly `x + to_out.bias`; one host sync per request decides
+        zero_lead = bs if (cfg and self.zero_uncond_shortcut and not bool(uc.any())) else 0
         control = c_info.get('control', None)
         hint = None
         if control is not None and hasattr(model, 'ctl'):
@@ -129,6 +132,7 @@ class DDIMSampler(object):
             """the whole trajectory as a pure function of device tensors (capturable as one hipGraph)"""
             from .controlnet import PreparedHint
             ctx = model.prepare_context(c_in)
+            ctx.zero_lead = zero_lead
             ctl = PreparedHint(hint) if hint is not None else None
             # every ResBlock's time-embedding projection for ALL steps in one GEMM (t is the same for
             # every sample of a step): [total_steps, sum Cout]
@@ -156,7 +160,7 @@ class DDIMSampler(object):
         use_graph = self.use_graph and not stochastic and callback is None and x.is_cuda
         if use_graph:
             key = (tuple(x.shape), tuple(c_in.shape), None if hint is None else tuple(hint.shape), total_steps,
-                   float(scale), nb, x_type, c_type, int(log_every_t), hash(np.asarray(timesteps).tobytes()),
+                   float(scale), nb, x_type, c_type, int(log_every_t), zero_lead, hash(np.asarray(timesteps).tobytes()),
                    self._weights_signature())
             ent = self._graphs.get(key)
             if ent is None:
@@ -182,6 +186,7 @@ class DDIMSampler(object):
     # ---- hipGraph plumbing (launch-bound loop: ~700 kernel launches per step) -------------------
     use_graph = False
     _graphs = None
+    zero_uncond_shortcut = True
 
     def enable_graph(self, on=True):
         """Replay the whole DDIM trajectory as one captured hipGraph (eta = 0 only).  The graph is

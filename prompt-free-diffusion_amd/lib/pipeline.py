@@ -78,15 +78,20 @@ class PromptFreePipeline:
 
     @torch.no_grad()
     def generate(self, image, n_global, height, width, steps=50, scale=2.0, eta=0.0, seed=20, control=None,
-                 uncond=None, decode=True, gather=False, verbose=False):
+                 uncond=None, decode=True, gather=False, verbose=False, timings=None):
         """returns (images [n_local|n_global, 3, H, W] in [0,1] or latents, latents [n_local,4,h,w])"""
         P, r = self.world_size, self.rank
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)] if timings is not None else None
+        if ev:
+            ev[0].record()
         xT = shard_xT(n_global, height, width, seed, r, P)
         n = xT.shape[0]
         dev = self.net.device
         cond, zeros = self.encode_reference(image.to(dev), n)
         if uncond is None:
             uncond = zeros
+        if ev:
+            ev[1].record()
         x_info = {'type': 'image', 'xt': xT.to(dev)}
         c_info = {'type': 'image', 'conditioning': cond, 'unconditional_conditioning': uncond,
                   'unconditional_guidance_scale': scale}
@@ -94,9 +99,16 @@ class PromptFreePipeline:
             c_info['control'] = control.to(dev)
         x, _ = self.sampler.sample(steps=steps, shape=list(xT.shape), x_info=x_info, c_info=c_info, eta=eta,
                                    verbose=verbose)
+        if ev:
+            ev[2].record()
         if not decode:
             return x, x
         img = self.net.vae_decode(x, 'image')
+        if ev:
+            ev[3].record()
+            torch.cuda.synchronize()
+            timings.update(ctx_encode_ms=ev[0].elapsed_time(ev[1]), ddim_loop_ms=ev[1].elapsed_time(ev[2]),
+                           vae_decode_ms=ev[2].elapsed_time(ev[3]))
         if gather:
             img = all_gather_batch(img, P)
         return img, x

@@ -232,3 +232,26 @@ def test_hipgraph_replay_matches_eager(net, golden):
         assert torch.equal(xe, xg), seed
         assert len(ie['pred_x0']) == len(ig['pred_x0']) and torch.equal(ie['pred_x0'][-1], ig['pred_x0'][-1])
     assert len(graphed._graphs) == 1
+
+
+def test_zero_uncond_shortcut_is_exact(net, golden):
+    """skipping cross-attention for the all-zero unconditional context must be bit-identical"""
+    from lib.model_zoo.ddim import DDIMSampler
+    cond = T(golden["see.ctx"]).cuda().half().repeat(2, 1, 1)
+
+    def run(shortcut, uncond):
+        s = DDIMSampler(net)
+        s.zero_uncond_shortcut = shortcut
+        xT = torch.randn([2, 4, 8, 8], generator=torch.Generator().manual_seed(3))
+        c_info = {'type': 'image', 'conditioning': cond, 'unconditional_conditioning': uncond,
+                  'unconditional_guidance_scale': 2.0}
+        x, _ = s.sample(steps=4, shape=[2, 4, 8, 8], x_info={'type': 'image', 'xt': xT.cuda()}, c_info=c_info,
+                        eta=0., verbose=False)
+        return x
+
+    zeros = torch.zeros_like(cond)
+    assert torch.equal(run(True, zeros), run(False, zeros))
+    nz = zeros.clone()
+    nz[:, 0, 0] = 1.0          # not all zero -> the shortcut must not trigger
+    assert torch.equal(run(True, nz), run(False, nz))
+    assert not torch.equal(run(True, nz), run(True, zeros))
