@@ -60,6 +60,105 @@ __device__ __forceinline__ void glds16(const void* src, void* lds_dst) {
                                    (__attribute__((address_space(3))) void*)lds_dst, 16, 0, 0);
 }
 
+// Epilogue shared by the wide-tile kernels: each wave stages 32 x 80 fp32 results through its private LDS
+// region (the operand ring is dead by now) and emits whole 16-byte row segments.
+template <int WMB>
+__device__ __forceinline__ void epilogue160(const float4_t (&acc)[WMB][5], const G160Params& p, char* smem, int wave,
+                                            int lane, int m0, int n0, int wm, int wn, int split) {
+  const int l15 = lane & 15, g = lane >> 4;
+  float* Es = reinterpret_cast<float*>(smem + wave * EP_WAVE_BYTES);
+  const bool geglu = p.act == PFD_ACT_GEGLU;
+  const bool raw = p.splits > 1;
+#pragma unroll
+  for (int h = 0; h < WMB / 2; ++h) {
+#pragma unroll
+    for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+      for (int j = 0; j < 5; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) Es[(ii * 16 + 4 * g + r) * EP_LD + j * 16 + l15] = acc[2 * h + ii][j][r];
+    const int mrow0 = m0 + wm * WMB * 16 + h * 32;
+    if (raw) {
+      for (int idx = lane; idx < 32 * 20; idx += 64) {  // 20 float4 per row
+        const int rr = idx / 20, cc = idx - rr * 20;
+        const int m = mrow0 + rr;
+        if (m < p.M)
+          *reinterpret_cast<float4_t*>(p.ws + ((long)split * p.M + m) * p.N + n0 + wn * 80 + cc * 4) =
+              *reinterpret_cast<const float4_t*>(Es + rr * EP_LD + cc * 4);
+      }
+    } else if (geglu) {
+      // loads first (all items), then math: one exposed latency per pass instead of one per item
+      Pack16 bx[3], bg[3];
+#pragma unroll
+      for (int t = 0; t < 3; ++t) {
+        const int idx = lane + 64 * t;
+        const int rr = idx / 5, cc = idx - rr * 5;
+        const int nx = n0 + wn * 80 + cc * 8;  // packed-weight row of the x half; gate = +40
+        bx[t].u = bg[t].u = make_uint4(0, 0, 0, 0);
+        if (p.bias && idx < 160) {
+          bx[t].u = *reinterpret_cast<const uint4*>(p.bias + nx);
+          bg[t].u = *reinterpret_cast<const uint4*>(p.bias + nx + 40);
+        }
+      }
+#pragma unroll
+      for (int t = 0; t < 3; ++t) {
+        const int idx = lane + 64 * t;
+        const int rr = idx / 5, cc = idx - rr * 5;
+        const int m = mrow0 + rr;
+        if (idx >= 160 || m >= p.M) continue;
+        Pack16 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float xv = Es[rr * EP_LD + cc * 8 + e] + (float)bx[t].e[e];
+          const float gv = Es[rr * EP_LD + 40 + cc * 8 + e] + (float)bg[t].e[e];
+          o.e[e] = (half_t)(xv * pfd_gelu(gv));
+        }
+        *reinterpret_cast<uint4*>(p.C + (long)m * p.ldc + (n0 >> 1) + wn * 40 + cc * 8) = o.u;
+      }
+    } else {
+      Pack16 lb[5], lv[5], lr[5];
+#pragma unroll
+      for (int t = 0; t < 5; ++t) {
+        const int idx = lane + 64 * t;
+        const int rr = idx / 10, cc = idx - rr * 10;
+        const int m = mrow0 + rr;
+        const int n = n0 + wn * 80 + cc * 8;
+        lb[t].u = lv[t].u = lr[t].u = make_uint4(0, 0, 0, 0);
+        if (m < p.M) {
+          if (p.bias) lb[t].u = *reinterpret_cast<const uint4*>(p.bias + n);
+          if (p.rowvec) lv[t].u = *reinterpret_cast<const uint4*>(p.rowvec + (long)(m / p.rows_per_rv) * p.ldrv + n);
+          if (p.R) lr[t].u = *reinterpret_cast<const uint4*>(p.R + (long)m * p.ldr + n);
+        }
+      }
+#pragma unroll
+      for (int t = 0; t < 5; ++t) {
+        const int idx = lane + 64 * t;
+        const int rr = idx / 10, cc = idx - rr * 10;
+        const int m = mrow0 + rr;
+        if (m >= p.M) continue;
+        const int n = n0 + wn * 80 + cc * 8;
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = Es[rr * EP_LD + cc * 8 + e] + (float)lb[t].e[e] + (float)lv[t].e[e];
+        if (p.act == PFD_ACT_GELU) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] = pfd_gelu(v[e]);
+        } else if (p.act == PFD_ACT_RELU) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
+        } else if (p.act == PFD_ACT_SILU) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] = pfd_silu(v[e]);
+        }
+        Pack16 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o.e[e] = (half_t)(v[e] + (float)lr[t].e[e]);
+        *reinterpret_cast<uint4*>(p.C + (long)m * p.ldc + n) = o.u;
+      }
+    }
+  }
+}
+
 template <int WAVES_M, int WMB, bool CONV, int NSTAGE>
 __global__ __launch_bounds__(WAVES_M * 128) void gemm160_kernel(const G160Params p) {
   constexpr int NW = WAVES_M * 2;
@@ -233,98 +332,157 @@ __global__ __launch_bounds__(WAVES_M * 128) void gemm160_kernel(const G160Params
     }
   }
 
-  // ---- epilogue ----
-  float* Es = reinterpret_cast<float*>(smem + wave * EP_WAVE_BYTES);
-  const bool geglu = p.act == PFD_ACT_GEGLU;
-  const bool raw = p.splits > 1;
+  epilogue160<WMB>(acc, p, smem, wave, lane, m0, n0, wm, wn, split);
+}
+
+// ------------------------------------------------------------------------------------------------
+// 3x3 / stride 1 / pad 1 convolution, "patch" form.  The LDS-DMA path sustains only ~50-70 GB/s per CU
+// (profiles/r01_gemm_ablation_loads_vs_mfma.log), so the implicit-GEMM kernel above -- which re-stages
+// the A tile for every one of the nine taps, 53 KB per K step -- is DMA-bound at ~36 % MFMA
+// utilisation.  Here the block stages the input PATCH of its 256 output pixels (TH = 256/W full image
+// rows plus a one-pixel halo, <= 400 pixels x 64 channels = 50 KB) ONCE per 64-channel block and all
+// nine taps read their A fragments from it at shifted LDS rows; only the 20 KB weight tile moves per
+// K step (25.5 KB per step on average, 2.1x less DMA traffic).  Padding = zero-page source rows.
+// Same 4 x 2 wave layout, fragment swizzle, epilogue and split-K (over channel blocks) as above.
+// Requires W in {16, 32, 64}, H % (256/W) == 0.
+// ------------------------------------------------------------------------------------------------
+constexpr int PATCH_ROWS = 400;
+
+__global__ __launch_bounds__(512) void conv3x3_patch_kernel(const G160Params p) {
+  constexpr int NW = 8, WMB = 4;
+  constexpr int PATCH_BYTES = PATCH_ROWS * ROWB;  // 51200
+  constexpr int WT_BYTES = BN * ROWB;             // 20480
+  constexpr int OFF_W = 2 * PATCH_BYTES;
+  constexpr int MAIN_BYTES = OFF_W + 2 * WT_BYTES;  // 143360
+  constexpr int EPI_BYTES = NW * EP_WAVE_BYTES;
+  constexpr int SMEM = MAIN_BYTES > EPI_BYTES ? MAIN_BYTES : EPI_BYTES;
+  constexpr int P_INSTR = PATCH_ROWS / 8;   // 50 DMA instructions per patch
+  constexpr int P_SLOTS = (P_INSTR + NW - 1) / NW;  // 7 per wave
+  __shared__ __attribute__((aligned(1024))) char smem[SMEM];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int l15 = lane & 15, g = lane >> 4;
+  const int nblk = p.tiles_m * p.tiles_n;
+  const int t = xcd_remap(blockIdx.x, nblk);
+  const int tile_m = t / p.tiles_n;
+  const int tile_n = t - tile_m * p.tiles_n;
+  const int m0 = tile_m * 256;
+  const int n0 = tile_n * BN;
+  const int split = blockIdx.z;
+  const int ncb = p.Cin / BK;
+  const int cb_begin = split * p.kt_per_split;
+  const int cb_end = min(ncb, cb_begin + p.kt_per_split);
+
+  const int W = p.Wd, H = p.H;
+  const int TH = 256 / W, PW = W + 2;
+  const int hw = H * W;
+  const int b = m0 / hw;
+  const int y0 = (m0 - b * hw) / W;
+  const int prow_count = (TH + 2) * PW;
+  const half_t* img = p.A + (long)b * hw * p.lda;
+
+  // patch staging: instruction q = wave + 8*j covers LDS rows q*8 .. q*8+7 (one input pixel each)
+  const int srow = lane >> 3, cpos = lane & 7;
+  const half_t* pp[P_SLOTS];
 #pragma unroll
-  for (int h = 0; h < WMB / 2; ++h) {
+  for (int j = 0; j < P_SLOTS; ++j) {
+    const int r = (wave + NW * j) * 8 + srow;
+    const int py = r / PW, px = r - py * PW;
+    const int y = y0 - 1 + py, x = px - 1;
+    const int c = cpos ^ ((r >> 1) & 7);
+    const bool ok = r < prow_count && y >= 0 && y < H && x >= 0 && x < W;
+    pp[j] = ok ? img + ((long)y * W + x) * p.lda + c * 8 : nullptr;
+  }
+  // weight tile staging (as in gemm160_kernel)
+  const half_t* wp[3];
 #pragma unroll
-    for (int ii = 0; ii < 2; ++ii)
+  for (int j = 0; j < 3; ++j) {
+    const int q = wave + NW * j;
+    const int r = q * 8 + srow;
+    const int c = cpos ^ ((r >> 1) & 7);
+    wp[j] = p.W + (long)(n0 + (q < 20 ? r : 0)) * p.ldw + c * 8;
+  }
+  auto issue_patch_slot = [&](int buf, int cb, int j) {
+    const int q = wave + NW * j;
+    if (q < P_INSTR) glds16(pp[j] ? pp[j] + cb * BK : g_zero_page, smem + buf * PATCH_BYTES + q * 1024);
+  };
+  auto issue_w = [&](int stage, int tap, int cb) {
+    const int k0 = tap * p.Cin + cb * BK;
 #pragma unroll
-      for (int j = 0; j < 5; ++j)
+    for (int j = 0; j < 3; ++j) {
+      const int q = wave + NW * j;
+      if (q < 20) glds16(wp[j] + k0, smem + OFF_W + stage * WT_BYTES + q * 1024);
+    }
+  };
+
+  // A fragment rows: output pixel (wm*64 + i*16 + l15) of the tile -> patch row of its (0,0) tap
+  int rbase[WMB];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) Es[(ii * 16 + 4 * g + r) * EP_LD + j * 16 + l15] = acc[2 * h + ii][j][r];
-    const int mrow0 = m0 + wm * WMB * 16 + h * 32;
-    if (raw) {
-      for (int idx = lane; idx < 32 * 20; idx += 64) {  // 20 float4 per row
-        const int rr = idx / 20, cc = idx - rr * 20;
-        const int m = mrow0 + rr;
-        if (m < p.M)
-          *reinterpret_cast<float4_t*>(p.ws + ((long)split * p.M + m) * p.N + n0 + wn * 80 + cc * 4) =
-              *reinterpret_cast<const float4_t*>(Es + rr * EP_LD + cc * 4);
-      }
-    } else if (geglu) {
-      // loads first (all items), then math: one exposed latency per pass instead of one per item
-      Pack16 bx[3], bg[3];
+  for (int i = 0; i < WMB; ++i) {
+    const int ql = wm * 64 + i * 16;
+    const int ty = ql / W, tx = ql - ty * W;
+    rbase[i] = ty * PW + tx + l15;
+  }
+  const int sw = (l15 >> 1) & 7;
+  const int boff0 = wn * 80 * ROWB + l15 * ROWB + (((0 + g) ^ sw) << 4);
+  const int boff1 = wn * 80 * ROWB + l15 * ROWB + (((4 + g) ^ sw) << 4);
+
+  float4_t acc[WMB][5];
 #pragma unroll
-      for (int t = 0; t < 3; ++t) {
-        const int idx = lane + 64 * t;
-        const int rr = idx / 5, cc = idx - rr * 5;
-        const int nx = n0 + wn * 80 + cc * 8;  // packed-weight row of the x half; gate = +40
-        bx[t].u = bg[t].u = make_uint4(0, 0, 0, 0);
-        if (p.bias && idx < 160) {
-          bx[t].u = *reinterpret_cast<const uint4*>(p.bias + nx);
-          bg[t].u = *reinterpret_cast<const uint4*>(p.bias + nx + 40);
+  for (int i = 0; i < WMB; ++i)
+#pragma unroll
+    for (int j = 0; j < 5; ++j) acc[i][j] = (float4_t){0.f, 0.f, 0.f, 0.f};
+
+  if (cb_begin < cb_end) {
+#pragma unroll
+    for (int j = 0; j < P_SLOTS; ++j) issue_patch_slot(0, cb_begin, j);
+    issue_w(0, 0, cb_begin);
+    __builtin_amdgcn_s_waitcnt(0);
+    __syncthreads();
+    int stage = 0;
+    for (int cb = cb_begin; cb < cb_end; ++cb) {
+      const int pbuf = (cb - cb_begin) & 1;
+      const char* patch = smem + pbuf * PATCH_BYTES;
+      int toff = 0;  // ky*PW + kx
+#pragma nounroll
+      for (int ky = 0; ky < 3; ++ky) {
+#pragma nounroll
+        for (int kx = 0; kx < 3; ++kx) {
+          const int tap = ky * 3 + kx;
+          // next weight tile, and one slot of the next channel block's patch
+          if (tap < 8) issue_w(stage ^ 1, tap + 1, cb);
+          else if (cb + 1 < cb_end) issue_w(stage ^ 1, 0, cb + 1);
+          if (cb + 1 < cb_end && tap < P_SLOTS) issue_patch_slot(pbuf ^ 1, cb + 1, tap);
+          const char* wt = smem + OFF_W + stage * WT_BYTES;
+#pragma unroll
+          for (int ks = 0; ks < 2; ++ks) {
+            half8_t af[WMB], bf[5];
+#pragma unroll
+            for (int i = 0; i < WMB; ++i) {
+              const int r = rbase[i] + toff;
+              af[i] = *reinterpret_cast<const half8_t*>(patch + r * ROWB + (((ks * 4 + g) ^ ((r >> 1) & 7)) << 4));
+            }
+            const int bo = ks ? boff1 : boff0;
+#pragma unroll
+            for (int j = 0; j < 5; ++j) bf[j] = *reinterpret_cast<const half8_t*>(wt + bo + j * 16 * ROWB);
+#pragma unroll
+            for (int i = 0; i < WMB; ++i)
+#pragma unroll
+              for (int j = 0; j < 5; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[i], bf[j], acc[i][j], 0, 0, 0);
+          }
+          __syncthreads();  // carries vmcnt(0)
+          stage ^= 1;
+          toff += 1;
         }
-      }
-#pragma unroll
-      for (int t = 0; t < 3; ++t) {
-        const int idx = lane + 64 * t;
-        const int rr = idx / 5, cc = idx - rr * 5;
-        const int m = mrow0 + rr;
-        if (idx >= 160 || m >= p.M) continue;
-        Pack16 o;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          const float xv = Es[rr * EP_LD + cc * 8 + e] + (float)bx[t].e[e];
-          const float gv = Es[rr * EP_LD + 40 + cc * 8 + e] + (float)bg[t].e[e];
-          o.e[e] = (half_t)(xv * pfd_gelu(gv));
-        }
-        *reinterpret_cast<uint4*>(p.C + (long)m * p.ldc + (n0 >> 1) + wn * 40 + cc * 8) = o.u;
-      }
-    } else {
-      Pack16 lb[5], lv[5], lr[5];
-#pragma unroll
-      for (int t = 0; t < 5; ++t) {
-        const int idx = lane + 64 * t;
-        const int rr = idx / 10, cc = idx - rr * 10;
-        const int m = mrow0 + rr;
-        const int n = n0 + wn * 80 + cc * 8;
-        lb[t].u = lv[t].u = lr[t].u = make_uint4(0, 0, 0, 0);
-        if (m < p.M) {
-          if (p.bias) lb[t].u = *reinterpret_cast<const uint4*>(p.bias + n);
-          if (p.rowvec) lv[t].u = *reinterpret_cast<const uint4*>(p.rowvec + (long)(m / p.rows_per_rv) * p.ldrv + n);
-          if (p.R) lr[t].u = *reinterpret_cast<const uint4*>(p.R + (long)m * p.ldr + n);
-        }
-      }
-#pragma unroll
-      for (int t = 0; t < 5; ++t) {
-        const int idx = lane + 64 * t;
-        const int rr = idx / 10, cc = idx - rr * 10;
-        const int m = mrow0 + rr;
-        if (m >= p.M) continue;
-        const int n = n0 + wn * 80 + cc * 8;
-        float v[8];
-#pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = Es[rr * EP_LD + cc * 8 + e] + (float)lb[t].e[e] + (float)lv[t].e[e];
-        if (p.act == PFD_ACT_GELU) {
-#pragma unroll
-          for (int e = 0; e < 8; ++e) v[e] = pfd_gelu(v[e]);
-        } else if (p.act == PFD_ACT_RELU) {
-#pragma unroll
-          for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
-        } else if (p.act == PFD_ACT_SILU) {
-#pragma unroll
-          for (int e = 0; e < 8; ++e) v[e] = pfd_silu(v[e]);
-        }
-        Pack16 o;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) o.e[e] = (half_t)(v[e] + (float)lr[t].e[e]);
-        *reinterpret_cast<uint4*>(p.C + (long)m * p.ldc + n) = o.u;
+        toff += PW - 3;
       }
     }
   }
+  epilogue160<WMB>(acc, p, smem, wave, lane, m0, n0, wm, wn, split);
 }
 
 // sum the split-K slabs and apply the epilogue (bias, row vector, activation, residual)
@@ -395,6 +553,28 @@ int launch160(G160Params& p, int bucket, hipStream_t s) {
   return pfd_check_launch("pfd_gemm_f16(wide)");
 }
 
+int launch_patch(G160Params& p, hipStream_t s) {
+  p.tiles_m = p.M / 256;
+  p.tiles_n = p.N / BN;
+  const int ncb = p.Cin / BK;
+  p.kt_per_split = (ncb + p.splits - 1) / p.splits;   // channel blocks per split
+  p.splits = (ncb + p.kt_per_split - 1) / p.kt_per_split;
+  dim3 grid(p.tiles_m * p.tiles_n, 1, p.splits);
+  const bool prof = pfd_prof_on();
+  if (prof)
+    pfd_prof_begin(19, 2.0 * p.M * p.N * p.K,
+                   2.0 * p.B * p.H * p.Wd * p.Cin + 2.0 * p.N * p.K + 2.0 * p.M * p.N * (p.R ? 2 : 1), s);
+  hipLaunchKernelGGL(conv3x3_patch_kernel, grid, dim3(512), 0, s, p);
+  if (p.splits > 1) {
+    const long nvec = (long)p.M * (p.N / 8);
+    int g = (int)((nvec + 255) / 256);
+    if (g > 2048) g = 2048;
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(g), dim3(256), 0, s, p);
+  }
+  if (prof) pfd_prof_end(s);
+  return pfd_check_launch("pfd_gemm_f16(conv3x3 patch)");
+}
+
 }  // namespace
 
 // Called by pfd_gemm_f16_ex (gemm_conv.hip).  Returns 1 if the problem is not for this path.
@@ -421,6 +601,26 @@ int pfd_gemm160_try(const PfdGemmDesc* d, int variant, int splits, hipStream_t s
   p.kt_per_split = 0;
   const int tn = p.N / BN;
   auto tiles = [&](int bm) { return (long)((p.M + bm - 1) / bm) * tn; };
+  // 3x3 / s1 / p1 convolution on a 16-, 32- or 64-wide image: the patch kernel (variant 0 or 99)
+  if ((variant == 0 || variant == 99) && p.ksize == 3 && p.stride == 1 && p.pad == 1 && !p.ups &&
+      (p.Wd == 16 || p.Wd == 32 || p.Wd == 64) && p.Ho == p.H && p.Wo == p.Wd && p.H % (256 / p.Wd) == 0 &&
+      p.M % 256 == 0 && p.act != PFD_ACT_GEGLU) {
+    const int ncb = p.Cin / BK;
+    if (splits == 0) {
+      splits = 1;
+      const long tl = tiles(256);
+      if (d->ws && tl < 200) {
+        splits = (int)((256 + tl - 1) / tl);
+        if (splits > 8) splits = 8;
+        while (splits > 1 && ncb / splits < 2) --splits;
+        while (splits > 1 && (size_t)splits * p.M * p.N * 4 > d->ws_bytes) --splits;
+      }
+    }
+    if (splits > 1 && (!d->ws || (size_t)splits * p.M * p.N * 4 > d->ws_bytes)) splits = 1;
+    p.splits = splits;
+    return launch_patch(p, s) < 0 ? PFD_ELAUNCH : 0;
+  }
+  if (variant == 99) return 1;
   const bool auto_variant = variant == 0;
   if (auto_variant) {
     // measured on MI355X (profiles/r01_selftest_kernels_b.log): the 256x160 tile wins whenever it

@@ -646,6 +646,11 @@ int main(int argc, char** argv) {
       GemmCase c{0, 320, 0, 0, true, true, true, false, v, 0, 3, 1, 1, 0, 2, 9, 7, 64};
       run_gemm_case(c);
     }
+    // patch conv kernel: W in {16,32,64}, whole image rows per tile, halo zero padding, split over channel blocks
+    run_gemm_case({0, 160, 0, PFD_ACT_SILU, true, true, true, false, 10900, 0, 3, 1, 1, 0, 2, 16, 16, 64});
+    run_gemm_case({0, 320, 0, 0, true, true, false, false, 10900, 0, 3, 1, 1, 0, 1, 32, 32, 128});
+    run_gemm_case({0, 160, 0, 0, true, false, true, false, 10902, 0, 3, 1, 1, 0, 1, 64, 64, 128});
+    run_gemm_case({0, 320, 0, 0, true, false, false, false, 0, 0, 3, 1, 1, 0, 3, 16, 16, 192});
     run_gemm_case({520, 160, 1024, PFD_ACT_GELU, true, true, true, false, 3204});   // 64x160 tiles, split-K 4
     run_gemm_case({130, 320, 2048, 0, true, true, false, false, 5403});             // 256x160, split-K 3
     run_gemm_case({200, 320, 128, PFD_ACT_GEGLU, true, false, false, false, 0});     // GEGLU, 40-row packing
@@ -685,7 +690,13 @@ int main(int argc, char** argv) {
 
   if (bench || only_bench) {
     // UNet-shaped problems at C2 (UNet batch 8)
-    for (int rep = 0; rep < 2; ++rep)
+    for (int t : {5400, 10900, 5400, 10900}) {   // gather conv vs patch conv
+      bench_gemm("PATCH conv3x3 320->320 @64^2", 0, 320, 0, 3, 8, 64, 320, t);
+      bench_gemm("PATCH conv3x3 960->320 @64^2", 0, 320, 0, 3, 8, 64, 960, t);
+      bench_gemm("PATCH conv3x3 640->640 @32^2", 0, 640, 0, 3, 8, 32, 640, t == 5400 ? 5402 : t);
+      bench_gemm("PATCH conv3x3 1280->1280 @16^2", 0, 1280, 0, 3, 8, 16, 1280, t == 5400 ? 3404 : t);
+    }
+    for (int rep = 0; rep < 1; ++rep)
       for (int t : {5400, 3400}) {
         bench_gemm("conv3x3 320->320 @64^2", 0, 320, 0, 3, 8, 64, 320, t);
         bench_gemm("linear qkv 320->960 @64^2", 32768, 960, 320, 0, 0, 0, 0, t);
