@@ -159,7 +159,7 @@ __device__ __forceinline__ void epilogue160(const float4_t (&acc)[WMB][5], const
   }
 }
 
-template <int WAVES_M, int WMB, bool CONV, int NSTAGE>
+template <int WAVES_M, int WMB, bool CONV, int KPB>
 __global__ __launch_bounds__(WAVES_M * 128) void gemm160_kernel(const G160Params p) {
   constexpr int NW = WAVES_M * 2;
   constexpr int NT = NW * 64;
@@ -169,7 +169,7 @@ __global__ __launch_bounds__(WAVES_M * 128) void gemm160_kernel(const G160Params
   constexpr int A_PER_WAVE = A_INSTR / NW;         // 4, 4, 2
   constexpr int B_PER_WAVE = (B_INSTR + NW - 1) / NW;
   constexpr int STAGE = (BM + BN) * ROWB;
-  constexpr int MAIN_BYTES = NSTAGE * STAGE;
+  constexpr int MAIN_BYTES = 2 * KPB * STAGE;
   static_assert(MAIN_BYTES <= 160 * 1024, "operand ring exceeds the 160 KiB LDS");
   constexpr int EPI_BYTES = NW * EP_WAVE_BYTES;
   constexpr int SMEM = MAIN_BYTES > EPI_BYTES ? MAIN_BYTES : EPI_BYTES;
@@ -306,29 +306,42 @@ __global__ __launch_bounds__(WAVES_M * 128) void gemm160_kernel(const G160Params
   // (A 3-/4-stage LDS ring with counted vmcnt waits was A/B-tested against this 2-stage loop in one run:
   //  conv 64^2 893 -> 803 TF, conv 32^2 743 -> 540, qkv 480 -> 457 -- slower everywhere, so it was dropped;
   //  profiles/r01_selftest_ring_ab.log.)
+  // KPB K tiles are staged and consumed per barrier: small tiles (64x160, 128x160) are bound by the
+  // ~1 us DMA round trip per barrier interval, not by bytes, so two tiles per interval halve that cost
   if (kt_begin < kt_end) {
-    issue(0, kt_begin);
-    __builtin_amdgcn_s_waitcnt(0);  // vmcnt(0): tile 0 landed
+#pragma unroll
+    for (int sub = 0; sub < KPB; ++sub)
+      if (kt_begin + sub < kt_end) issue(sub, kt_begin + sub);
+    __builtin_amdgcn_s_waitcnt(0);  // vmcnt(0): first tiles landed
     __syncthreads();
-    for (int kt = kt_begin; kt < kt_end; ++kt) {
-      const int stage = (kt - kt_begin) & 1;
-      if (kt + 1 < kt_end) issue(stage ^ 1, kt + 1);
-      const char* base = smem + stage * STAGE;
+    int stage = 0;
+    for (int kt = kt_begin; kt < kt_end; kt += KPB) {
 #pragma unroll
-      for (int ks = 0; ks < 2; ++ks) {
-        const int off = ks ? off_k1 : off_k0;
-        half8_t af[WMB], bf[5];
+      for (int sub = 0; sub < KPB; ++sub)
+        if (kt + KPB + sub < kt_end) issue((stage ^ 1) * KPB + sub, kt + KPB + sub);
 #pragma unroll
-        for (int i = 0; i < WMB; ++i) af[i] = *reinterpret_cast<const half8_t*>(base + a_row0 + i * 16 * ROWB + off);
+      for (int sub = 0; sub < KPB; ++sub) {
+        if (kt + sub >= kt_end) break;
+        const char* base = smem + (stage * KPB + sub) * STAGE;
 #pragma unroll
-        for (int j = 0; j < 5; ++j) bf[j] = *reinterpret_cast<const half8_t*>(base + b_row0 + j * 16 * ROWB + off);
+        for (int ks = 0; ks < 2; ++ks) {
+          const int off = ks ? off_k1 : off_k0;
+          half8_t af[WMB], bf[5];
 #pragma unroll
-        for (int i = 0; i < WMB; ++i)
+          for (int i = 0; i < WMB; ++i)
+            af[i] = *reinterpret_cast<const half8_t*>(base + a_row0 + i * 16 * ROWB + off);
 #pragma unroll
           for (int j = 0; j < 5; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[i], bf[j], acc[i][j], 0, 0, 0);
+            bf[j] = *reinterpret_cast<const half8_t*>(base + b_row0 + j * 16 * ROWB + off);
+#pragma unroll
+          for (int i = 0; i < WMB; ++i)
+#pragma unroll
+            for (int j = 0; j < 5; ++j)
+              acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[i], bf[j], acc[i][j], 0, 0, 0);
+        }
       }
-      __syncthreads();  // carries vmcnt(0): the next tile has landed, this one is consumed
+      __syncthreads();  // carries vmcnt(0): the next tiles have landed, these are consumed
+      stage ^= 1;
     }
   }
 
@@ -524,7 +537,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const G160Params p) 
   }
 }
 
-template <int WAVES_M, int WMB, int NSTAGE = 2>
+template <int WAVES_M, int WMB, int KPB = 1>
 int launch160(G160Params& p, int bucket, hipStream_t s) {
   constexpr int BM = WAVES_M * WMB * 16;
   p.tiles_m = (p.M + BM - 1) / BM;
@@ -540,9 +553,9 @@ int launch160(G160Params& p, int bucket, hipStream_t s) {
     pfd_prof_begin(bucket, 2.0 * p.M * p.N * p.K, a_bytes + 2.0 * p.N * p.K + 2.0 * p.M * n_out * (p.R ? 2 : 1), s);
   }
   if (p.ksize > 0)
-    hipLaunchKernelGGL((gemm160_kernel<WAVES_M, WMB, true, NSTAGE>), grid, dim3(WAVES_M * 128), 0, s, p);
+    hipLaunchKernelGGL((gemm160_kernel<WAVES_M, WMB, true, KPB>), grid, dim3(WAVES_M * 128), 0, s, p);
   else
-    hipLaunchKernelGGL((gemm160_kernel<WAVES_M, WMB, false, NSTAGE>), grid, dim3(WAVES_M * 128), 0, s, p);
+    hipLaunchKernelGGL((gemm160_kernel<WAVES_M, WMB, false, KPB>), grid, dim3(WAVES_M * 128), 0, s, p);
   if (p.splits > 1) {
     const long nvec = (long)p.M * (p.N / 8);
     int g = (int)((nvec + 255) / 256);
@@ -622,35 +635,41 @@ int pfd_gemm160_try(const PfdGemmDesc* d, int variant, int splits, hipStream_t s
   }
   if (variant == 99) return 1;
   const bool auto_variant = variant == 0;
+  const int nk_all = p.K / BK;
   if (auto_variant) {
-    // measured on MI355X (profiles/r01_selftest_kernels_b.log): the 256x160 tile wins whenever it
-    // yields >= ~100 blocks; below that 128x160 tiles with split-K up to 512 blocks
-    variant = tiles(256) >= 96 ? 44 : 24;
+    // measured on MI355X with COLD weights (the 1.7 GB of other layers evict every W between two uses;
+    // profiles/r01_gemm_cold_cache.log): the 256x160 tile when it fills the chip; two K halves of it for
+    // long-K problems with ~128 tiles; short K (<= 24 tiles of 64) is bound by the per-barrier DMA round
+    // trip, so it wants as many small blocks as possible (64x160); otherwise 128x160 tiles + split-K.
+    if (tiles(256) >= 200) variant = 44;
+    else if (tiles(256) >= 96 && nk_all >= 48) variant = 44;
+    else if (nk_all <= 24) variant = 22;
+    else variant = 24;
   }
-  const int bm = variant == 44 ? 256 : variant == 24 ? 128 : 64;
+  const int bm = variant == 44 ? 256 : (variant == 24 || variant == 25) ? 128 : 64;
   if (splits == 0) {
     splits = 1;
     const long tl = tiles(bm);
-    const int nk = p.K / BK;
+    const int nk = nk_all;
     if (p.act != PFD_ACT_GEGLU && d->ws && variant == 44 && tl < 200 && nk >= 48 &&
         (size_t)2 * p.M * p.N * 4 <= d->ws_bytes) {
       splits = 2;  // 128 tiles of 256x160: two K halves fill the chip (758 vs 579 TF at 640->640 @32^2)
-    } else if (p.act != PFD_ACT_GEGLU && d->ws && variant != 44 && tl < 256) {
+    } else if (p.act != PFD_ACT_GEGLU && d->ws && variant == 24 && tl < 256) {
       splits = (int)((512 + tl - 1) / tl);
       if (splits > 8) splits = 8;
-      while (splits > 1 && nk / splits < 24) --splits;  // the slab round trip must stay small vs the K loop
+      while (splits > 1 && nk / splits < 16) --splits;  // the slab round trip must stay small vs the K loop
       while (splits > 1 && (size_t)splits * p.M * p.N * 4 > d->ws_bytes) --splits;
     }
   }
   if (splits > 1 && (!d->ws || (size_t)splits * p.M * p.N * 4 > d->ws_bytes || p.act == PFD_ACT_GEGLU)) splits = 1;
-  // short-K problems that did not qualify for split-K: rather 256 small tiles than 128 blocks on 256 CUs
-  if (auto_variant && variant == 24 && splits == 1 && tiles(128) < 200 && tiles(64) > tiles(128)) variant = 22;
   p.splits = splits;
   const int conv = p.ksize > 0 ? 1 : 0;
   switch (variant) {
     case 44: return launch160<4, 4>(p, 12 + 4 * conv, s) < 0 ? PFD_ELAUNCH : 0;
     case 24: return launch160<2, 4>(p, 13 + 4 * conv, s) < 0 ? PFD_ELAUNCH : 0;
     case 22: return launch160<2, 2>(p, 14 + 4 * conv, s) < 0 ? PFD_ELAUNCH : 0;
+    case 25: return launch160<2, 4, 2>(p, 13 + 4 * conv, s) < 0 ? PFD_ELAUNCH : 0;  // two K tiles per barrier
+    case 23: return launch160<2, 2, 2>(p, 14 + 4 * conv, s) < 0 ? PFD_ELAUNCH : 0;
     default: return PFD_EINVAL;
   }
 }
