@@ -34,7 +34,7 @@ extern "C" {
 #define PFD_ESHAPE (-2)   /* shape outside what the kernels are built for           */
 #define PFD_ELAUNCH (-3)  /* hipGetLastError() != hipSuccess after the launch       */
 
-#define PFD_ABI_VERSION 2
+#define PFD_ABI_VERSION 3
 
 typedef void* pfd_stream_t; /* hipStream_t */
 
@@ -96,6 +96,17 @@ typedef struct PfdGemmDesc {
    * library never allocates.  NULL / 0 = never split.  Must not be shared by concurrent streams. */
   void* ws;
   size_t ws_bytes;
+  /* optional transposed tail (ABI 3): with Ct != NULL the output columns n >= n_split are not
+   * written to C but, transposed, to Ct[(n - n_split) * ldct + m] (+ bias[n] only).  This is how the
+   * self-attention q | k | v projection (attention.py:169-176) is ONE launch over the shared
+   * activation: q | k land token-major in C, v lands as the V^T [inner, tokens] operand
+   * pfd_attention_f16 consumes.  Wide-tile path only: plain GEMM (ksize == 0), N % 160 == 0,
+   * n_split % 160 == 0, ldct % 8 == 0, Ct 16-byte aligned, act == NONE, rowvec == R == NULL,
+   * bias_per_row == 0; anything else is PFD_ESHAPE (there is no slow path behind it). */
+  void* Ct;
+  int64_t ldct;
+  int32_t n_split;
+  int32_t reserved0;
 } PfdGemmDesc;
 int pfd_gemm_f16(const PfdGemmDesc* d, pfd_stream_t stream);
 /* Same, with the kernel variant forced (tests and tuning only); 0 = the library's heuristic.

@@ -308,11 +308,13 @@ extern "C" int pfd_gemm_f16_ex(const PfdGemmDesc* d, int32_t tile, pfd_stream_t 
     if ((long)d->B * d->Ho * d->Wo != d->M) return PFD_EINVAL;
     if (d->stride < 1) return PFD_EINVAL;
   }
+  if (d->Ct && (d->act != PFD_ACT_NONE || d->rowvec || d->R || d->bias_per_row || (tile != 0 && tile < 1000)))
+    return PFD_EINVAL;
   if (tile == 0 || tile >= 1000) {  // wide-tile LDS-DMA path (N % 160 == 0)
     const int enc = tile >= 1000 ? tile - 1000 : 0;
     const int rc = pfd_gemm160_try(d, enc / 100, enc % 100, (hipStream_t)stream);
     if (rc <= 0) return rc;
-    if (tile >= 1000) return PFD_ESHAPE;  // forced but not applicable
+    if (tile >= 1000 || d->Ct) return PFD_ESHAPE;  // forced (or transposed tail) but not applicable
   }
   GemmParams p;
   p.A = (const half_t*)d->A;

@@ -47,6 +47,9 @@ struct G160Params {
   const half_t* R;
   half_t* C;
   float* ws;  // split-K slabs [splits][M][N] fp32
+  half_t* Ct;  // transposed tail: columns >= n_split -> Ct[(n - n_split) * ldct + m]
+  long ldct;
+  int n_split;
   long lda, ldw, ldr, ldc, ldrv;
   int M, N, K;
   int rows_per_rv, act;
@@ -78,7 +81,28 @@ __device__ __forceinline__ void epilogue160(const float4_t (&acc)[WMB][5], const
 #pragma unroll
         for (int r = 0; r < 4; ++r) Es[(ii * 16 + 4 * g + r) * EP_LD + j * 16 + l15] = acc[2 * h + ii][j][r];
     const int mrow0 = m0 + wm * WMB * 16 + h * 32;
-    if (raw) {
+    if (p.Ct && n0 >= p.n_split) {
+      // transposed tail (tile-uniform): column c of the staged 32 x 80 block becomes 32 consecutive
+      // halves of row (n - n_split) of Ct -- four 16-byte segments, one per lane
+#pragma unroll
+      for (int t = 0; t < 5; ++t) {
+        const int idx = lane + 64 * t;
+        const int c = idx >> 2, rc = idx & 3;
+        const int n = n0 + wn * 80 + c;
+        const int m = mrow0 + rc * 8;
+        if (m >= p.M) continue;
+        const float bv = p.bias ? (float)p.bias[n] : 0.f;
+        Pack16 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o.e[e] = (half_t)(Es[(rc * 8 + e) * EP_LD + c] + bv);
+        half_t* dst = p.Ct + (long)(n - p.n_split) * p.ldct + m;
+        if (m + 8 <= p.M) {
+          *reinterpret_cast<uint4*>(dst) = o.u;
+        } else {
+          for (int e = 0; e < p.M - m; ++e) dst[e] = o.e[e];
+        }
+      }
+    } else if (raw) {
       for (int idx = lane; idx < 32 * 20; idx += 64) {  // 20 float4 per row
         const int rr = idx / 20, cc = idx - rr * 20;
         const int m = mrow0 + rr;
@@ -159,7 +183,7 @@ __device__ __forceinline__ void epilogue160(const float4_t (&acc)[WMB][5], const
   }
 }
 
-template <int WAVES_M, int WMB, bool CONV, int KPB>
+template <int WAVES_M, int WMB, bool CONV, int NBUF>
 __global__ __launch_bounds__(WAVES_M * 128) void gemm160_kernel(const G160Params p) {
   constexpr int NW = WAVES_M * 2;
   constexpr int NT = NW * 64;
@@ -169,7 +193,9 @@ __global__ __launch_bounds__(WAVES_M * 128) void gemm160_kernel(const G160Params
   constexpr int A_PER_WAVE = A_INSTR / NW;         // 4, 4, 2
   constexpr int B_PER_WAVE = (B_INSTR + NW - 1) / NW;
   constexpr int STAGE = (BM + BN) * ROWB;
-  constexpr int MAIN_BYTES = 2 * KPB * STAGE;
+  constexpr int MAIN_BYTES = NBUF * STAGE;
+  constexpr int DEPTH = NBUF - 1;  // K tiles in flight ahead of the one being consumed
+  static_assert(NBUF == 2 || B_INSTR % NW == 0, "counted vmcnt needs the same DMA count in every wave");
   static_assert(MAIN_BYTES <= 160 * 1024, "operand ring exceeds the 160 KiB LDS");
   constexpr int EPI_BYTES = NW * EP_WAVE_BYTES;
   constexpr int SMEM = MAIN_BYTES > EPI_BYTES ? MAIN_BYTES : EPI_BYTES;
@@ -303,46 +329,49 @@ __global__ __launch_bounds__(WAVES_M * 128) void gemm160_kernel(const G160Params
   const int a_row0 = wm * WMB * 16 * ROWB;
   const int b_row0 = BM * ROWB + wn * 80 * ROWB;
 
-  // (A 3-/4-stage LDS ring with counted vmcnt waits was A/B-tested against this 2-stage loop in one run:
-  //  conv 64^2 893 -> 803 TF, conv 32^2 743 -> 540, qkv 480 -> 457 -- slower everywhere, so it was dropped;
-  //  profiles/r01_selftest_ring_ab.log.)
-  // KPB K tiles are staged and consumed per barrier: small tiles (64x160, 128x160) are bound by the
-  // ~1 us DMA round trip per barrier interval, not by bytes, so two tiles per interval halve that cost
+  // Operand ring of NBUF stages, DEPTH = NBUF-1 K tiles in flight.  NBUF = 2 is the throughput form
+  // (one tile ahead; a deeper ring A/B-tested slower on the big warm problems: conv 64^2 893 -> 803 TF,
+  // profiles/r01_selftest_ring_ab.log).  Problems that fill the chip only once (<= 256 blocks) and stream
+  // COLD weights are bound by the DMA round trip per K tile instead (~1.9 us per tile on the 8^2 convs),
+  // so they run NBUF = 4-5 with a counted vmcnt wait: only the oldest tile has to have landed.
   if (kt_begin < kt_end) {
+    constexpr int PER_STEP = A_PER_WAVE + B_PER_WAVE;
+    constexpr int KEEP = PER_STEP * (DEPTH - 1);  // DMA instructions that may stay outstanding
+    static_assert(KEEP < 64, "vmcnt is 6 bits");
+    constexpr int WAIT_KEEP = (KEEP & 15) | ((KEEP >> 4) << 14) | (7 << 4) | (15 << 8);
 #pragma unroll
-    for (int sub = 0; sub < KPB; ++sub)
-      if (kt_begin + sub < kt_end) issue(sub, kt_begin + sub);
-    __builtin_amdgcn_s_waitcnt(0);  // vmcnt(0): first tiles landed
-    __syncthreads();
-    int stage = 0;
-    for (int kt = kt_begin; kt < kt_end; kt += KPB) {
+    for (int s = 0; s < DEPTH; ++s)
+      if (kt_begin + s < kt_end) issue(s, kt_begin + s);
+    int buf = 0;
+    for (int kt = kt_begin; kt < kt_end; ++kt) {
+      if (NBUF > 2 && kt + DEPTH - 1 < kt_end) __builtin_amdgcn_s_waitcnt(WAIT_KEEP);
+      else __builtin_amdgcn_s_waitcnt(0);
+      __syncthreads();  // tile kt visible to all waves; everyone is done with the buffer of tile kt-1
+      if (kt + DEPTH < kt_end) {
+        int nb = buf + DEPTH;
+        if (nb >= NBUF) nb -= NBUF;
+        issue(nb, kt + DEPTH);
+      }
+      const char* base = smem + buf * STAGE;
 #pragma unroll
-      for (int sub = 0; sub < KPB; ++sub)
-        if (kt + KPB + sub < kt_end) issue((stage ^ 1) * KPB + sub, kt + KPB + sub);
+      for (int ks = 0; ks < 2; ++ks) {
+        const int off = ks ? off_k1 : off_k0;
+        half8_t af[WMB], bf[5];
 #pragma unroll
-      for (int sub = 0; sub < KPB; ++sub) {
-        if (kt + sub >= kt_end) break;
-        const char* base = smem + (stage * KPB + sub) * STAGE;
+        for (int i = 0; i < WMB; ++i)
+          af[i] = *reinterpret_cast<const half8_t*>(base + a_row0 + i * 16 * ROWB + off);
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-          const int off = ks ? off_k1 : off_k0;
-          half8_t af[WMB], bf[5];
+        for (int j = 0; j < 5; ++j)
+          bf[j] = *reinterpret_cast<const half8_t*>(base + b_row0 + j * 16 * ROWB + off);
 #pragma unroll
-          for (int i = 0; i < WMB; ++i)
-            af[i] = *reinterpret_cast<const half8_t*>(base + a_row0 + i * 16 * ROWB + off);
+        for (int i = 0; i < WMB; ++i)
 #pragma unroll
           for (int j = 0; j < 5; ++j)
-            bf[j] = *reinterpret_cast<const half8_t*>(base + b_row0 + j * 16 * ROWB + off);
-#pragma unroll
-          for (int i = 0; i < WMB; ++i)
-#pragma unroll
-            for (int j = 0; j < 5; ++j)
-              acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[i], bf[j], acc[i][j], 0, 0, 0);
-        }
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[i], bf[j], acc[i][j], 0, 0, 0);
       }
-      __syncthreads();  // carries vmcnt(0): the next tiles have landed, these are consumed
-      stage ^= 1;
+      if (++buf == NBUF) buf = 0;
     }
+    __syncthreads();  // the epilogue reuses the ring as staging space
   }
 
   epilogue160<WMB>(acc, p, smem, wave, lane, m0, n0, wm, wn, split);
@@ -537,7 +566,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const G160Params p) 
   }
 }
 
-template <int WAVES_M, int WMB, int KPB = 1>
+template <int WAVES_M, int WMB, int NBUF = 2>
 int launch160(G160Params& p, int bucket, hipStream_t s) {
   constexpr int BM = WAVES_M * WMB * 16;
   p.tiles_m = (p.M + BM - 1) / BM;
@@ -553,9 +582,9 @@ int launch160(G160Params& p, int bucket, hipStream_t s) {
     pfd_prof_begin(bucket, 2.0 * p.M * p.N * p.K, a_bytes + 2.0 * p.N * p.K + 2.0 * p.M * n_out * (p.R ? 2 : 1), s);
   }
   if (p.ksize > 0)
-    hipLaunchKernelGGL((gemm160_kernel<WAVES_M, WMB, true, KPB>), grid, dim3(WAVES_M * 128), 0, s, p);
+    hipLaunchKernelGGL((gemm160_kernel<WAVES_M, WMB, true, NBUF>), grid, dim3(WAVES_M * 128), 0, s, p);
   else
-    hipLaunchKernelGGL((gemm160_kernel<WAVES_M, WMB, false, KPB>), grid, dim3(WAVES_M * 128), 0, s, p);
+    hipLaunchKernelGGL((gemm160_kernel<WAVES_M, WMB, false, NBUF>), grid, dim3(WAVES_M * 128), 0, s, p);
   if (p.splits > 1) {
     const long nvec = (long)p.M * (p.N / 8);
     int g = (int)((nvec + 255) / 256);
@@ -600,7 +629,14 @@ int pfd_gemm160_try(const PfdGemmDesc* d, int variant, int splits, hipStream_t s
   if (d->bias && (reinterpret_cast<uintptr_t>(d->bias) & 15)) return 1;
   if (d->R && ((d->ldr & 7) || (reinterpret_cast<uintptr_t>(d->R) & 15))) return 1;
   if (d->rowvec && ((d->ldrv & 7) || (reinterpret_cast<uintptr_t>(d->rowvec) & 15))) return 1;
+  if (d->Ct) {  // transposed tail: validated by the caller to be a plain, epilogue-free GEMM
+    if (d->ksize > 0 || d->n_split <= 0 || d->n_split >= d->N || d->n_split % BN || (d->ldct & 7) ||
+        (reinterpret_cast<uintptr_t>(d->Ct) & 15))
+      return 1;
+    splits = 1;
+  }
   G160Params p;
+  p.Ct = (half_t*)d->Ct; p.ldct = d->ldct; p.n_split = d->n_split;
   p.A = (const half_t*)d->A; p.W = (const half_t*)d->W; p.bias = (const half_t*)d->bias;
   p.rowvec = (const half_t*)d->rowvec; p.R = (const half_t*)d->R; p.C = (half_t*)d->C;
   p.ws = (float*)d->ws;
@@ -646,7 +682,7 @@ int pfd_gemm160_try(const PfdGemmDesc* d, int variant, int splits, hipStream_t s
     else if (nk_all <= 24) variant = 22;
     else variant = 24;
   }
-  const int bm = variant == 44 ? 256 : (variant == 24 || variant == 25) ? 128 : 64;
+  const int bm = variant == 44 ? 256 : (variant == 24 || variant == 26) ? 128 : 64;
   if (splits == 0) {
     splits = 1;
     const long tl = tiles(bm);
@@ -668,8 +704,8 @@ int pfd_gemm160_try(const PfdGemmDesc* d, int variant, int splits, hipStream_t s
     case 44: return launch160<4, 4>(p, 12 + 4 * conv, s) < 0 ? PFD_ELAUNCH : 0;
     case 24: return launch160<2, 4>(p, 13 + 4 * conv, s) < 0 ? PFD_ELAUNCH : 0;
     case 22: return launch160<2, 2>(p, 14 + 4 * conv, s) < 0 ? PFD_ELAUNCH : 0;
-    case 25: return launch160<2, 4, 2>(p, 13 + 4 * conv, s) < 0 ? PFD_ELAUNCH : 0;  // two K tiles per barrier
-    case 23: return launch160<2, 2, 2>(p, 14 + 4 * conv, s) < 0 ? PFD_ELAUNCH : 0;
+    case 26: return launch160<2, 4, 4>(p, 13 + 4 * conv, s) < 0 ? PFD_ELAUNCH : 0;  // 3 K tiles in flight
+    case 27: return launch160<2, 2, 5>(p, 14 + 4 * conv, s) < 0 ? PFD_ELAUNCH : 0;  // 4 K tiles in flight
     default: return PFD_EINVAL;
   }
 }

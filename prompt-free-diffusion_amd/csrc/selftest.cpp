@@ -108,6 +108,7 @@ struct GemmCase {
   int tile = 0;
   int extra_ld = 0;  // added to every leading dimension
   int ksize = 0, stride = 1, pad = 0, ups = 0, B = 0, H = 0, W = 0, Cin = 0;
+  int n_split = 0;  // > 0: columns >= n_split go transposed to Ct
 };
 
 static void run_gemm_case(const GemmCase& c) {
@@ -143,6 +144,9 @@ static void run_gemm_case(const GemmCase& c) {
   d.M = M; d.N = N; d.K = K; d.rows_per_rv = rows_per_rv; d.act = c.act; d.bias_per_row = c.bias_row;
   d.ksize = c.ksize; d.stride = c.stride; d.pad = c.pad; d.ups = c.ups;
   d.B = c.B; d.H = c.H; d.Wd = c.W; d.Cin = c.Cin; d.Ho = Ho; d.Wo = Wo;
+  const long ldct = (M + 7) / 8 * 8 + 8;
+  Dev<h16> dCt(c.n_split > 0 ? (size_t)(N - c.n_split) * ldct : 8);
+  if (c.n_split > 0) { d.Ct = dCt.p; d.ldct = ldct; d.n_split = c.n_split; }
   const int rc = pfd_gemm_f16_ex(&d, c.tile, nullptr);
   char name[256];
   snprintf(name, sizeof(name), "gemm M%d N%d K%d act%d b%d r%d rv%d br%d tile%d ld+%d %s", M, N, K, c.act,
@@ -185,8 +189,15 @@ static void run_gemm_case(const GemmCase& c) {
   }
   std::vector<double> ref((size_t)M * ldc, 0.0);
   std::vector<h16> gotc((size_t)M * ldc, (h16)0);
+  if (c.n_split > 0) {  // transposed tail: [N - n_split, ldct], pad columns untouched
+    auto gt = dCt.get();
+    std::vector<double> rt(gt.size(), 0.0);
+    for (int n = c.n_split; n < N; ++n)
+      for (int m = 0; m < M; ++m) rt[(size_t)(n - c.n_split) * ldct + m] = pre[(size_t)m * N + n];
+    report((std::string(name) + " [Ct]").c_str(), gt, rt, 4e-3, 3e-3);
+  }
   for (int m = 0; m < M; ++m)
-    for (int n = 0; n < Nout; ++n) {
+    for (int n = 0; n < (c.n_split > 0 ? c.n_split : Nout); ++n) {
       double v;
       if (c.act == PFD_ACT_GEGLU) {
         const int gr = (N % 160 == 0) ? 40 : 32;  // packing granularity of the kernel that serves this N
@@ -202,7 +213,7 @@ static void run_gemm_case(const GemmCase& c) {
     }
   // the pad columns (ld+extra) must stay untouched (zero)
   for (int m = 0; m < M; ++m)
-    for (long n = Nout; n < ldc; ++n) gotc[(size_t)m * ldc + n] = got[(size_t)m * ldc + n];
+    for (long n = c.n_split > 0 ? c.n_split : Nout; n < ldc; ++n) gotc[(size_t)m * ldc + n] = got[(size_t)m * ldc + n];
   report(name, gotc, ref, 4e-3, 3e-3);
 }
 
@@ -566,9 +577,41 @@ static void bench_gn(const char* label, int B, int HW, int C) {
   fflush(stdout);
 }
 
+// Per-launch floor of the runtime: N dependent launches of a kernel with ~no work, in-stream and as one
+// hipGraph -- what every one of the ~500 launches of a UNet pass pays on top of its own duration.
+static void bench_launch_floor() {
+  Dev<h16> a(std::vector<h16>(4096)), b(std::vector<h16>(4096)), c(4096);
+  const int N = 2000;
+  hipStream_t st;
+  HIP_OK(hipStreamCreate(&st));
+  hipEvent_t e0, e1;
+  HIP_OK(hipEventCreate(&e0)); HIP_OK(hipEventCreate(&e1));
+  auto run = [&] { for (int i = 0; i < N; ++i) pfd_add_f16(a.p, b.p, c.p, 4096, st); };
+  run();
+  HIP_OK(hipStreamSynchronize(st));
+  HIP_OK(hipEventRecord(e0, st)); run(); HIP_OK(hipEventRecord(e1, st));
+  HIP_OK(hipEventSynchronize(e1));
+  float ms = 0;
+  HIP_OK(hipEventElapsedTime(&ms, e0, e1));
+  printf("bench launch floor: in-stream      %6.2f us/launch (%d dependent tiny launches)\n", ms * 1e3 / N, N);
+  hipGraph_t g; hipGraphExec_t ge;
+  HIP_OK(hipStreamBeginCapture(st, hipStreamCaptureModeGlobal));
+  run();
+  HIP_OK(hipStreamEndCapture(st, &g));
+  HIP_OK(hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
+  HIP_OK(hipGraphLaunch(ge, st));
+  HIP_OK(hipStreamSynchronize(st));
+  HIP_OK(hipEventRecord(e0, st)); HIP_OK(hipGraphLaunch(ge, st)); HIP_OK(hipEventRecord(e1, st));
+  HIP_OK(hipEventSynchronize(e1));
+  HIP_OK(hipEventElapsedTime(&ms, e0, e1));
+  printf("bench launch floor: hipGraph replay %6.2f us/launch\n", ms * 1e3 / N);
+  HIP_OK(hipGraphExecDestroy(ge)); HIP_OK(hipGraphDestroy(g)); HIP_OK(hipStreamDestroy(st));
+  fflush(stdout);
+}
+
 // --replay <file>: relaunch a recorded GEMM/conv launch list (tools/dump_unet_shapes.py) once each, in
 // order, on random operands -- the torch-free workload rocprofv3 --pmc is pointed at.
-static int replay(const char* path) {
+static int replay(const char* path, bool timed = false, int force_tile = 0) {
   FILE* f = fopen(path, "r");
   if (!f) { printf("cannot open %s\n", path); return 1; }
   std::vector<std::array<long, 19>> rows;
@@ -590,7 +633,21 @@ static int replay(const char* path) {
   Dev<h16> dA(rand_h(maxA)), dW(rand_h(maxW, 0.05f)), dB(rand_h(maxV)), dRV(rand_h(maxC)), dR(rand_h(maxC)), dC(maxC);
   Dev<float> dWS((size_t)24 << 20);
   int bad = 0;
-  for (int rep = 0; rep < 2; ++rep)  // first pass warms caches / code objects, second is the measured one
+  // --replay-time: every launch reads its weights from a fresh slice of a 2 GB pool (as in the UNet,
+  // where 1.7 GB of other layers' weights pass through the caches between two uses of a layer) and is
+  // bracketed by its own pair of events; the table lists, per distinct problem, the time against the
+  // per-problem roofline max(flops / 2.5 PF, algorithmic bytes / 8 TB/s).
+  const size_t pool_elems = timed ? (size_t)1 << 30 : 0;
+  Dev<h16> dPool(pool_elems ? pool_elems : 8);
+  if (timed) HIP_OK(hipMemset(dPool.p, 0x11, pool_elems * 2));
+  size_t pool_off = 0;
+  const int reps = timed ? 4 : 2;
+  std::vector<hipEvent_t> ev(timed ? rows.size() + 1 : 0);
+  for (auto& e : ev) HIP_OK(hipEventCreate(&e));
+  std::vector<double> acc_ms(rows.size(), 0.0);
+  for (int rep = 0; rep < reps; ++rep) {  // first pass warms caches / code objects
+    size_t li = 0;
+    if (timed) HIP_OK(hipEventRecord(ev[0], nullptr));
     for (auto& q : rows) {
       PfdGemmDesc d;
       memset(&d, 0, sizeof(d));
@@ -604,15 +661,58 @@ static int replay(const char* path) {
       const long nout = d.act == PFD_ACT_GEGLU ? d.N / 2 : d.N;
       d.lda = d.ksize > 0 ? d.Cin : d.K; d.ldw = d.K; d.ldc = nout; d.ldr = nout; d.ldrv = d.N;
       d.ws = dWS.p; d.ws_bytes = (size_t)96 << 20;
-      bad += pfd_gemm_f16(&d, nullptr) != 0;
+      if (timed) {
+        const size_t wn = ((size_t)d.N * d.K + 4095) & ~(size_t)4095;
+        if (pool_off + wn > pool_elems) pool_off = 0;
+        d.W = dPool.p + pool_off;
+        pool_off += wn;
+      }
+      if (force_tile == 0 || pfd_gemm_f16_ex(&d, force_tile, nullptr) != 0) bad += pfd_gemm_f16(&d, nullptr) != 0;
+      if (timed) HIP_OK(hipEventRecord(ev[++li], nullptr));
     }
+    HIP_OK(hipDeviceSynchronize());
+    if (timed && rep > 0)
+      for (size_t i = 0; i < rows.size(); ++i) {
+        float ms = 0;
+        HIP_OK(hipEventElapsedTime(&ms, ev[i], ev[i + 1]));
+        acc_ms[i] += ms / (reps - 1);
+      }
+  }
   HIP_OK(hipDeviceSynchronize());
-  printf("replayed %zu launches x2, %d errors\n", rows.size(), bad);
+  printf("replayed %zu launches x%d, %d errors\n", rows.size(), reps, bad);
+  if (timed) {
+    struct Agg { std::array<long, 19> q; int n; double ms; };
+    std::vector<Agg> aggs;
+    for (size_t i = 0; i < rows.size(); ++i) {
+      bool found = false;
+      for (auto& a : aggs) if (a.q == rows[i]) { a.n++; a.ms += acc_ms[i]; found = true; break; }
+      if (!found) aggs.push_back({rows[i], 1, acc_ms[i]});
+    }
+    std::sort(aggs.begin(), aggs.end(), [](const Agg& a, const Agg& b) { return a.ms > b.ms; });
+    double tot = 0, tot_ideal = 0;
+    printf("%7s %6s %6s k s u act rv R | %3s %9s %8s %8s %8s %8s\n", "M", "N", "K", "n", "us/launch", "TF/s", "GB/s", "ideal_us", "sum_ms");
+    for (auto& a : aggs) {
+      const auto& q = a.q;
+      const double M = q[0], N = q[1], K = q[2];
+      const double nout = q[3] == PFD_ACT_GEGLU ? N / 2 : N;
+      const double abytes = q[8] > 0 ? 2.0 * q[12] * q[13] * q[14] * q[15] : 2.0 * M * K;
+      const double bytes = abytes + 2.0 * N * K + 2.0 * M * nout + (q[6] ? 2.0 * M * nout : 0) + (q[5] ? 2.0 * M * N / std::max<double>(1, std::min<long>(q[18], M)) : 0);
+      const double flops = 2.0 * M * N * K;
+      const double us = a.ms / a.n * 1e3;
+      const double ideal = std::max(flops / 2.5e15, bytes / 8e12) * 1e6;
+      tot += a.ms; tot_ideal += ideal * a.n * 1e-3;
+      printf("%7ld %6ld %6ld %ld %ld %ld %3ld %2ld %ld | %3d %9.1f %8.1f %8.1f %8.1f %8.2f\n", q[0], q[1], q[2], q[8], q[9], q[11], q[3], q[5], q[6],
+             a.n, us, flops / us * 1e-6, bytes / us * 1e-3, ideal, a.ms);
+    }
+    printf("total %.2f ms per UNet pass (GEMM/conv only); roofline-ideal %.2f ms\n", tot, tot_ideal);
+  }
   return bad;
 }
 
 int main(int argc, char** argv) {
   if (argc > 2 && !strcmp(argv[1], "--replay")) return replay(argv[2]);
+  if (argc > 1 && !strcmp(argv[1], "--launch-floor")) { bench_launch_floor(); return 0; }
+  if (argc > 2 && !strcmp(argv[1], "--replay-time")) return replay(argv[2], true, argc > 3 ? atoi(argv[3]) : 0);
   const bool bench = argc > 1 && !strcmp(argv[1], "--bench");
   const bool only_bench = argc > 1 && !strcmp(argv[1], "--only-bench");
   hipDeviceProp_t prop;
@@ -654,6 +754,22 @@ int main(int argc, char** argv) {
     run_gemm_case({520, 160, 1024, PFD_ACT_GELU, true, true, true, false, 3204});   // 64x160 tiles, split-K 4
     run_gemm_case({130, 320, 2048, 0, true, true, false, false, 5403});             // 256x160, split-K 3
     run_gemm_case({200, 320, 128, PFD_ACT_GEGLU, true, false, false, false, 0});     // GEGLU, 40-row packing
+    // transposed tail (fused q|k|v projection): all three tile heights, ragged M, bias
+    {
+      GemmCase t{520, 480, 128, 0, false, false, false, false, 0}; t.n_split = 320; run_gemm_case(t);
+      GemmCase u{301, 320, 192, 0, true, false, false, false, 5400}; u.n_split = 160; run_gemm_case(u);
+      GemmCase v{77, 960, 320, 0, false, false, false, false, 3400}; v.n_split = 640; run_gemm_case(v);
+      GemmCase w{130, 480, 64, 0, true, false, false, false, 3200}; w.n_split = 320; run_gemm_case(w);
+    }
+    // deep operand ring (counted vmcnt): K shorter than, equal to and longer than the ring, + split-K, conv
+    run_gemm_case({130, 320, 128, 0, true, true, false, false, 3600});
+    run_gemm_case({300, 160, 256, PFD_ACT_GELU, true, true, true, false, 3700});
+    run_gemm_case({300, 320, 1024, 0, true, true, true, false, 3600});
+    run_gemm_case({77, 160, 1344, 0, true, false, false, false, 3700});
+    run_gemm_case({520, 320, 2048, 0, true, true, false, false, 3604});
+    run_gemm_case({130, 160, 1536, 0, true, false, false, false, 3703});
+    run_gemm_case({0, 320, 0, 0, true, true, false, false, 3602, 0, 3, 1, 1, 0, 2, 8, 8, 256});
+    run_gemm_case({0, 160, 0, PFD_ACT_SILU, true, false, true, false, 3700, 0, 3, 2, 1, 0, 2, 10, 8, 128});
     run_gemm_case({0, 160, 0, PFD_ACT_SILU, true, false, false, false, 0, 0, 3, 2, 1, 0, 2, 10, 8, 128});  // stride 2
     run_gemm_case({0, 160, 0, 0, true, true, false, false, 3402, 0, 3, 1, 1, 1, 1, 5, 6, 128});           // upsample + split
     run_gemm_case({0, 320, 0, 0, true, false, false, false, 0, 8, 3, 2, 0, 0, 1, 9, 9, 64});               // pad 0, ld+8

@@ -14,7 +14,7 @@ import os
 _LIB = None
 _LIB_PATH = os.path.normpath(os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "..", "libpfd_hip.so"))
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 ACT_NONE, ACT_GELU, ACT_RELU, ACT_SILU, ACT_GEGLU = 0, 1, 2, 3, 4
 
@@ -30,6 +30,7 @@ class PfdGemmDesc(C.Structure):
         ("ksize", _i32), ("stride", _i32), ("pad", _i32), ("ups", _i32),
         ("B", _i32), ("H", _i32), ("Wd", _i32), ("Cin", _i32), ("Ho", _i32), ("Wo", _i32),
         ("ws", _vp), ("ws_bytes", _sz),
+        ("Ct", _vp), ("ldct", _i64), ("n_split", _i32), ("reserved0", _i32),
     ]
 
 

@@ -81,8 +81,9 @@ def _rows(t):
 # GEMM / convolution
 # ----------------------------------------------------------------------------------------------
 def gemm(a, w, *, bias=None, rowvec=None, rows_per_rv=1, res=None, act=ACT_NONE, out=None,
-         bias_per_row=False, n=None, k=None, tile=0):
-    """out[M, N] = epi(a[M, K] @ w[N, K]^T); see pfd_gemm_f16 in include/pfd_hip.h."""
+         bias_per_row=False, n=None, k=None, tile=0, out_t=None, n_split=None):
+    """out[M, N] = epi(a[M, K] @ w[N, K]^T); see pfd_gemm_f16 in include/pfd_hip.h.
+    out_t / n_split: columns >= n_split go, transposed, to out_t[N - n_split, M] (wide-tile path only)."""
     _chk16(a, "gemm A")
     _chk16(w, "gemm W")
     M, Ka, lda = _rows(a)
@@ -90,10 +91,17 @@ def gemm(a, w, *, bias=None, rowvec=None, rows_per_rv=1, res=None, act=ACT_NONE,
     N = Nw if n is None else n
     K = min(Ka, Kw) if k is None else k
     n_out = N // 2 if act == ACT_GEGLU else N
+    if out_t is not None:
+        n_out = n_split
     if out is None:
         out = torch.empty((M, n_out), dtype=torch.float16, device=a.device)
     _, _, ldc = _rows(out)
     d = _b.PfdGemmDesc()
+    if out_t is not None:
+        _chk16(out_t, "gemm out_t")
+        if out_t.shape[0] != N - n_split or out_t.shape[1] < M or out_t.stride(1) != 1:
+            raise ValueError(f"gemm: out_t {tuple(out_t.shape)} cannot hold [{N - n_split}, {M}]")
+        d.Ct, d.ldct, d.n_split = out_t.data_ptr(), out_t.stride(0), n_split
     d.A, d.W, d.C = a.data_ptr(), w.data_ptr(), out.data_ptr()
     d.bias, d.rowvec, d.R = _ptr(bias), _ptr(rowvec), _ptr(res)
     d.lda, d.ldw, d.ldc = lda, ldw, ldc

@@ -139,16 +139,28 @@ class CrossAttention(nn.Module, L._Packed):
             "qk", lambda: torch.cat([L._dev16(self.to_q.weight), L._dev16(self.to_k.weight)], 0).contiguous(),
             self.to_q.weight, self.to_k.weight)
 
+    def _pk_qkv(self):
+        return self._packed(
+            "qkv", lambda: torch.cat([L._dev16(self.to_q.weight), L._dev16(self.to_k.weight),
+                                      L._dev16(self.to_v.weight)], 0).contiguous(),
+            self.to_q.weight, self.to_k.weight, self.to_v.weight)
+
     def hip(self, x, B, N, context=None, res=None):
         """x: [B*N, query_dim] tokens (already normalised); context: None (self-attention) or a
         ContextKV; res: residual added by the out-projection epilogue.  -> [B*N, query_dim]"""
         Cd, H, D = self.inner_dim, self.heads, self.dim_head
         if context is None:
-            qk = ops.gemm(x, self._pk_qk())                 # [M, 2*inner]: q | k
-            if N % 8 == 0:
+            if N % 8 == 0 and Cd % 160 == 0 and x.shape[1] % 64 == 0:
+                # one launch over the shared activation: q | k token-major, v transposed (ABI 3)
                 Np = N
+                vt = torch.empty((Cd, B * N), dtype=torch.float16, device=x.device)
+                qk = ops.gemm(x, self._pk_qkv(), out_t=vt, n_split=2 * Cd)
+            elif N % 8 == 0:
+                Np = N
+                qk = ops.gemm(x, self._pk_qk())             # [M, 2*inner]: q | k
                 vt = self.to_v.hip_t(x)                      # [inner, B*N]
             else:  # odd token counts (tiny latents): pad every sample's V^T rows to 16-byte multiples
+                qk = ops.gemm(x, self._pk_qk())
                 Np = (N + 7) // 8 * 8
                 vt = torch.zeros((Cd, B * Np), dtype=torch.float16, device=x.device)
                 for b in range(B):

@@ -44,6 +44,36 @@ def test_gemm_geglu_and_strided_views():
     close(y, big[:, 320:].float() @ w[:, 320:].float().t())
 
 
+@pytest.mark.parametrize("M,C,K", [(64, 320, 320), (200, 640, 640), (1024, 1280, 1280)])
+def test_gemm_transposed_tail_and_fused_qkv(M, C, K):
+    """ABI 3: q | k token-major + v transposed out of one launch == three separate projections."""
+    from lib.hip import ops
+    a, w, b = _dev(M, K), _dev(3 * C, K, scale=K ** -0.5), _dev(3 * C)
+    vt = torch.zeros((C, M + 8), dtype=torch.float16, device="cuda")
+    qk = ops.gemm(a, w, bias=b, out_t=vt[:, :M], n_split=2 * C)
+    ref = a.float() @ w.float().t() + b.float()
+    assert qk.shape == (M, 2 * C)
+    close(qk, ref[:, :2 * C])
+    close(vt[:, :M], ref[:, 2 * C:].t())
+    assert float(vt[:, M:].abs().max()) == 0.0          # pad columns untouched
+    with pytest.raises(Exception):                       # no slow path behind it: N % 160 != 0 is loud
+        ops.gemm(a, w[:3 * 128], out_t=vt[:128, :M], n_split=256)
+
+
+def test_self_attention_fused_projection_matches_split_path():
+    from lib.model_zoo.attention import CrossAttention
+    torch.manual_seed(0)
+    m = CrossAttention(320, heads=8, dim_head=40).half().cuda()
+    x = _dev(2 * 64, 320)
+    y = m.hip(x, 2, 64)
+    xf = x.float().view(2, 64, 320)
+    q, k, v = (F.linear(xf, getattr(m, n).weight.float()).view(2, 64, 8, 40).transpose(1, 2)
+               for n in ("to_q", "to_k", "to_v"))
+    o = F.scaled_dot_product_attention(q, k, v).transpose(1, 2).reshape(2 * 64, 320)
+    ref = F.linear(o, m.to_out[0].weight.float(), m.to_out[0].bias.float())
+    close(y, ref)
+
+
 @pytest.mark.parametrize("cin,cout,k,s,ups,hw", [(64, 96, 3, 1, False, (9, 7)), (128, 64, 3, 2, False, (10, 8)),
                                                   (64, 64, 3, 1, True, (5, 6)), (4, 320, 3, 1, False, (8, 8)),
                                                   (3, 192, 4, 4, False, (10, 13)), (320, 4, 3, 1, False, (8, 8))])
