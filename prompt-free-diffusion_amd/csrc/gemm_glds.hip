@@ -329,6 +329,9 @@ __global__ __launch_bounds__(WAVES_M * 128) void gemm160_kernel(const G160Params
   const int a_row0 = wm * WMB * 16 * ROWB;
   const int b_row0 = BM * ROWB + wn * 80 * ROWB;
 
+  // (Also A/B-tested and dropped: the same 256x160 tile as 4 waves of 128x80 -- 28 % fewer LDS fragment
+  //  bytes per MFMA but one wave per SIMD, so nothing covers the ds_read latency: conv 32^2 106 -> 163 us,
+  //  profiles/r01_gemm_replay_variants.log.)
   // Operand ring of NBUF stages, DEPTH = NBUF-1 K tiles in flight.  NBUF = 2 is the throughput form
   // (one tile ahead; a deeper ring A/B-tested slower on the big warm problems: conv 64^2 893 -> 803 TF,
   // profiles/r01_selftest_ring_ab.log).  Problems that fill the chip only once (<= 256 blocks) and stream
