@@ -230,6 +230,23 @@ def main():
     G["e2e.img"] = net.vae_decode(x_prev, 'image').numpy()
     print("e2e final latent std", float(x_prev.std()))
 
+    # ---- img2img (ddim.py:97-103): x0 noised to ddim step k by q_sample, then k reverse steps.  The
+    # reference draws the noise with torch.randn_like inside q_sample; the harness pins that draw.
+    x0 = seeded_tensor("input.i2i.x0", shape, 1)
+    noise = seeded_tensor("input.i2i.noise", shape, 1)
+    real_randn_like = torch.randn_like
+    torch.randn_like = lambda t, *a, **k: noise.to(dtype=t.dtype)
+    try:
+        xi, inter = sampler.sample(steps=8, shape=shape, x_info={'type': 'image', 'x0': x0.clone(), 'x0_forward_timesteps': 5},
+                                   c_info={'type': 'image', 'conditioning': cond,
+                                           'unconditional_conditioning': torch.zeros_like(cond),
+                                           'unconditional_guidance_scale': 2.0}, eta=0., verbose=False)
+    finally:
+        torch.randn_like = real_randn_like
+    G["i2i.x0"], G["i2i.noise"], G["i2i.out"] = x0.numpy(), noise.numpy(), xi.numpy()
+    G["i2i.pred_x0_last"] = inter['pred_x0'][-1].numpy()
+    print("i2i final latent std", float(xi.std()), "intermediates", len(inter['pred_x0']))
+
     np.savez_compressed(os.path.join(OUT, "golden.npz"), **G)
     print("wrote", os.path.join(OUT, "golden.npz"), "entries:", len(G))
 

@@ -287,6 +287,21 @@ def ddim_step(eps_fn, x, t, cond, uncond, scale, a_t, a_prev, sigma_t, noise=Non
     return x_prev, pred_x0
 
 
+def img2img(eps_fn, x0, noise, cond, uncond, scale, steps, k, eta=0.0):
+    """ddim.py:97-103 + 107-127: q_sample x0 to ddim timestep index k (pfd.py:204-207, noise given),
+    then the k reverse steps over timesteps[:k] with index = k-1-i into the FULL a/a_prev tables."""
+    buf = schedule_buffers()
+    ts, a, ap, sg = ddim_tables(buf["alphas_cumprod"], steps, eta)
+    tk = int(ts[k])
+    x = float(buf["sqrt_alphas_cumprod"][tk]) * x0 + float(buf["sqrt_one_minus_alphas_cumprod"][tk]) * noise
+    pred = None
+    for i, step in enumerate(np.flip(ts[:k])):
+        idx = k - i - 1
+        t = torch.full((x.shape[0],), int(step), dtype=torch.long)
+        x, pred = ddim_step(eps_fn, x, t, cond, uncond, scale, float(a[idx]), float(ap[idx]), float(sg[idx]))
+    return x, pred
+
+
 # ------------------------------------------------------------------------------------------------
 # AutoencoderKL (autokl.py:30-54, autokl_modules.py)
 # ------------------------------------------------------------------------------------------------

@@ -173,6 +173,25 @@ def test_end_to_end_sampler(net, golden):
     check("e2e decoded image", img, golden["e2e.img"], 2e-2)
 
 
+def test_img2img_x0_branch(net, golden, monkeypatch):
+    """x_info['x0'] + 'x0_forward_timesteps' (ddim.py:97-103): q_sample to ddim index 5 of 8, 5 reverse
+    steps.  The reference draws the q_sample noise with randn_like; both sides pin that draw."""
+    from lib.model_zoo.ddim import DDIMSampler
+    noise = T(golden["i2i.noise"]).cuda()
+    monkeypatch.setattr(torch, "randn_like", lambda t, *a, **k: noise.to(dtype=t.dtype, device=t.device))
+    sampler = DDIMSampler(net)
+    cond = T(golden["see.ctx"]).cuda().half()
+    x_info = {'type': 'image', 'x0': T(golden["i2i.x0"]).cuda(), 'x0_forward_timesteps': 5}
+    c_info = {'type': 'image', 'conditioning': cond, 'unconditional_conditioning': torch.zeros_like(cond),
+              'unconditional_guidance_scale': 2.0}
+    x, inter = sampler.sample(steps=8, shape=[1, 4, 8, 8], x_info=x_info, c_info=c_info, eta=0., verbose=False)
+    ref = T(golden["i2i.out"]).double()
+    rel = float((x.double().cpu() - ref).norm() / ref.norm())
+    print(f"[parity] img2img latent rel-L2 {rel:.3e}")
+    assert rel <= 1e-2
+    check("img2img last pred_x0", inter['pred_x0'][-1], golden["i2i.pred_x0_last"])
+
+
 def test_sampler_per_step_api_matches_loop(net, golden):
     """p_sample_ddim (reference calling convention) == the fused loop, and eta > 0 draws noise"""
     from lib.model_zoo.ddim import DDIMSampler

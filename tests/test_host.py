@@ -186,3 +186,63 @@ def test_cabi_rejects_bad_arguments_without_a_gpu():
     assert lib.pfd_attention_f16(ctypes.byref(a), None) == -1
     with pytest.raises(binding.PfdError):
         binding.check(-2, "unit")
+
+
+# ---- checkpoint formats / converters (lib/weights_io.py) --------------------------------------------
+def test_keymaps_match_the_reference_converters(state_spec):
+    """derived sdwebui / diffusers key maps == what tools/model_conversion.py's mover classes emit
+    (tests/golden/keymaps.json, dumped by oracle/make_keymap_golden.py from the reference itself)"""
+    from lib import weights_io as W
+    gold = json.load(open(os.path.join(REPO, "tests", "golden", "keymaps.json")))
+    keys = list(state_spec.keys())
+    uk = [k for k in keys if k.startswith('diffuser.image.')]
+    assert set(map(tuple, W.ldm_unet_keymap(uk, context_name='text'))) == set(map(tuple, gold["sdwebui_unet"]))
+    assert set(map(tuple, W.diffusers_unet_keymap(uk, context_name='text'))) == \
+        set(map(tuple, gold["sdhuggingface_diffuser_to_pfd_mover"]))
+    vk = [k[len('vae.image.'):] for k in keys if k.startswith('vae.image.')]
+    mine = set((a, b, 'unsqueeze_hw') if f else (a, b) for a, b, f in W.diffusers_vae_keymap(vk))
+    assert mine == set(map(tuple, gold["sdhuggingface_vae_to_pfd_mover"]))
+    # the converters move tensors under those maps (and reshape the VAE attention linears to 1x1 convs)
+    sd = {frm: torch.full((2, 2), float(i)) for i, (frm, _, _) in enumerate(W.diffusers_vae_keymap(vk))}
+    out = W.convert_vae(sd, vk)
+    assert set(out) == set(vk) and out['decoder.mid.attn_1.q.weight'].shape == (2, 2, 1, 1)
+
+
+def test_safetensors_hot_swap_is_strict_and_in_place(tmp_path):
+    from safetensors.torch import save_file
+    from lib import weights_io as W
+
+    class Tiny(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.ctx = torch.nn.ModuleDict({'image': torch.nn.Linear(3, 2)})
+            self.diffuser = torch.nn.ModuleDict({'image': torch.nn.ModuleDict(
+                {'context_blocks': torch.nn.ModuleList([torch.nn.Linear(2, 2)]), 'data_blocks': torch.nn.Linear(2, 1)})})
+            self.ctl = torch.nn.Linear(4, 4)
+    net = Tiny().half()
+    before = {k: v.clone() for k, v in net.state_dict().items()}
+    w = net.diffuser['image'].context_blocks[0].weight
+    ptr, ver = w.data_ptr(), w._version
+    # an old-style checkpoint: context blocks stored under diffuser.text (app.py:149-153), fp32 on disk
+    sd = {k.replace('diffuser.image.context_blocks.', 'diffuser.text.context_blocks.'): torch.randn_like(v, dtype=torch.float32)
+          for k, v in net.state_dict().items() if k.startswith('diffuser.')}
+    f = str(tmp_path / "unet.safetensors")
+    save_file(sd, f)
+    assert W.load_diffuser(net, f) == len(sd)
+    assert w.data_ptr() == ptr and w._version > ver and w.dtype == torch.float16      # in place, cache key moved
+    assert torch.equal(w, sd['diffuser.text.context_blocks.0.weight'].half())
+    assert all(torch.equal(net.state_dict()[k], before[k]) for k in before if not k.startswith('diffuser.'))
+    # strictness: a missing key, an unexpected key and a wrong shape all raise and modify nothing
+    snap = {k: v.clone() for k, v in net.state_dict().items()}
+    for broken in ({k: v for k, v in list(sd.items())[1:]}, dict(sd, **{'diffuser.image.extra': torch.zeros(1)}),
+                   dict(sd, **{'diffuser.image.data_blocks.bias': torch.zeros(3)})):
+        save_file(broken, f)
+        with pytest.raises(RuntimeError):
+            W.load_diffuser(net, f)
+        assert all(torch.equal(net.state_dict()[k], snap[k]) for k in snap)
+    # .pth goes through the same path; unknown extensions fail like app.py:91
+    torch.save({k: torch.ones_like(v) for k, v in net.ctl.state_dict().items()}, str(tmp_path / "ctl.pth"))
+    W.load_ctl(net, str(tmp_path / "ctl.pth"))
+    assert float(net.ctl.weight.detach().min()) == 1.0
+    with pytest.raises(AssertionError):
+        W.load_sd_from_file(str(tmp_path / "x.bin"))

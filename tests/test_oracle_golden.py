@@ -122,3 +122,13 @@ def test_end_to_end_trajectory(golden, param_shapes):
         assert rel_err(x, golden["e2e.traj"][i]) < 1e-3
     img = O.vae_decode(sdv, "vae.image.", x)
     assert float((img - T(golden["e2e.img"])).abs().max()) < 2e-3
+
+
+def test_img2img(golden, param_shapes):
+    """x0 branch of the sampler (ddim.py:97-103): 8-step schedule, start from ddim index 5"""
+    sd = seeded_sd(param_shapes, "diffuser.image.")
+    cond = T(golden["see.ctx"])
+    eps_fn = lambda xx, tt, cc: O.unet_apply(sd, "diffuser.image.", xx, tt, cc)  # noqa: E731
+    x, pred = O.img2img(eps_fn, T(golden["i2i.x0"]), T(golden["i2i.noise"]), cond, torch.zeros_like(cond), 2.0, 8, 5)
+    assert rel_err(x, golden["i2i.out"]) < 1e-3
+    assert rel_err(pred, golden["i2i.pred_x0_last"]) < 1e-3
