@@ -229,6 +229,11 @@ int pfd_cfg_ddim_step(const void* eps, int32_t nb, const float* x, const float* 
                       int32_t C, int32_t h, int32_t w, pfd_stream_t stream);
 /* y = a + b (f16, fp32 add), n elements; b may be NULL (copy). */
 int pfd_add_f16(const void* a, const void* b, void* y, int64_t n, pfd_stream_t stream);
+/* y = alpha*a + beta*b (f16 storage, fp32 math), n elements; b may be NULL (y = alpha*a).  The
+ * ratio-weighted sum of the per-context SpatialTransformer outputs of multi-context sampling
+ * (pfd.py:375-380 `h = h + module(x, emb, c) * r`). */
+int pfd_axpby_f16(const void* a, float alpha, const void* b, float beta, void* y, int64_t n,
+                  pfd_stream_t stream);
 /* y[r, c] = x[r, c] + v[c] for a [R, C] f16 matrix (level/positional embeddings,
  * seecoder.py:402,515). */
 int pfd_add_rowvec_f16(const void* x, int64_t ldx, const void* v, void* y, int64_t ldy, int32_t R,

@@ -247,6 +247,22 @@ def main():
     G["i2i.pred_x0_last"] = inter['pred_x0'][-1].numpy()
     print("i2i final latent std", float(xi.std()), "intermediates", len(inter['pred_x0']))
 
+    # ---- multi-context sampling (ddim.py:174-299, pfd.py:366-439): two contexts, ratios 0.7 / 0.3,
+    # 'attention' mixing, 4 steps; the reference draws x_T with torch.randn, pinned by the harness.
+    cond2 = net.ctx_encode(img2, 'image')
+    xT2 = seeded_tensor("input.mc.xT", shape, 1)
+    real_randn = torch.randn
+    torch.randn = lambda *a, **k: xT2.clone()
+    try:
+        c_list = [{'type': 'image', 'conditioning': cc, 'unconditional_conditioning': torch.zeros_like(cc),
+                   'unconditional_guidance_scale': 2.0, 'ratio': rr} for cc, rr in ((cond, 0.7), (cond2, 0.3))]
+        xm, inter = sampler.sample_multicontext(steps=4, shape=shape, x_info={'type': 'image'},
+                                                c_info_list=c_list, eta=0., verbose=False)
+    finally:
+        torch.randn = real_randn
+    G["mc.xT"], G["mc.out"], G["mc.ratios"] = xT2.numpy(), xm.numpy(), np.array([0.7, 0.3])
+    print("multicontext final latent std", float(xm.std()))
+
     np.savez_compressed(os.path.join(OUT, "golden.npz"), **G)
     print("wrote", os.path.join(OUT, "golden.npz"), "entries:", len(G))
 

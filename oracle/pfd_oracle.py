@@ -211,6 +211,9 @@ def unet_apply(sd, prefix, x, t, context, control=None, heads=8, model_channels=
             return conv2d(q.sub("2."), silu(group_norm(q.sub("0."), h, 1e-5)), padding=1)
         q = p.sub(f"context_blocks.{ci[0]}.0.")
         ci[0] += 1
+        if isinstance(context, list):  # multi-context 'attention' mixing (pfd.py:366-380): [(context, ratio)]
+            tot = sum(r for _, r in context)
+            return sum(spatial_transformer(q, h, c, heads) * (r / tot) for c, r in context)
         return spatial_transformer(q, h, context, heads)
 
     ccs = list(control) if control is not None else None
@@ -285,6 +288,13 @@ def ddim_step(eps_fn, x, t, cond, uncond, scale, a_t, a_prev, sigma_t, noise=Non
     if noise is not None:
         x_prev = x_prev + sigma_t * noise
     return x_prev, pred_x0
+
+
+def ddim_step_multicontext(sd, prefix, x, t, conds, unconds, ratios, scale, a_t, a_prev, sigma_t):
+    """ddim.py:243-299: every context is CFG-doubled (uncond first) and the UNet mixes them per layer"""
+    ctx = [(torch.cat([u, c]), r) for c, u, r in zip(conds, unconds, ratios)]
+    eps_fn = lambda xx, tt, cc: unet_apply(sd, prefix, xx, tt, ctx)  # noqa: E731
+    return ddim_step(eps_fn, x, t, conds[0], unconds[0], scale, a_t, a_prev, sigma_t)
 
 
 def img2img(eps_fn, x0, noise, cond, uncond, scale, steps, k, eta=0.0):

@@ -148,6 +148,24 @@ __global__ void add_kernel(const half_t* __restrict__ a, const half_t* __restric
   }
 }
 
+__global__ void axpby_kernel(const half_t* __restrict__ a, float alpha, const half_t* __restrict__ b, float beta,
+                             half_t* __restrict__ y, long n) {
+  const long nv = n / 8;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < nv; i += (long)gridDim.x * blockDim.x) {
+    Pack16 p, q, o;
+    p.u = reinterpret_cast<const uint4*>(a)[i];
+    q.u = make_uint4(0, 0, 0, 0);
+    if (b) q.u = reinterpret_cast<const uint4*>(b)[i];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o.e[e] = (half_t)fmaf(alpha, (float)p.e[e], beta * (float)q.e[e]);
+    reinterpret_cast<uint4*>(y)[i] = o.u;
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (n & 7)) {
+    const long i = nv * 8 + threadIdx.x;
+    y[i] = (half_t)fmaf(alpha, (float)a[i], b ? beta * (float)b[i] : 0.f);
+  }
+}
+
 __global__ void add_rowvec_kernel(const half_t* __restrict__ x, long ldx, const half_t* __restrict__ v,
                                   half_t* __restrict__ y, long ldy, int R, int C) {
   const int nvec = C / 8;
@@ -252,6 +270,17 @@ extern "C" int pfd_add_f16(const void* a, const void* b, void* y, int64_t n, pfd
   hipLaunchKernelGGL(add_kernel, dim3(grid_for(n / 8 + 1, 256)), dim3(256), 0, (hipStream_t)stream,
                      (const half_t*)a, (const half_t*)b, (half_t*)y, (long)n);
   return pfd_check_launch("pfd_add_f16");
+}
+
+extern "C" int pfd_axpby_f16(const void* a, float alpha, const void* b, float beta, void* y, int64_t n,
+                             pfd_stream_t stream) {
+  if (!a || !y || n <= 0) return PFD_EINVAL;
+  if ((reinterpret_cast<uintptr_t>(a) & 15) || (reinterpret_cast<uintptr_t>(y) & 15) ||
+      (b && (reinterpret_cast<uintptr_t>(b) & 15)))
+    return PFD_EINVAL;
+  hipLaunchKernelGGL(axpby_kernel, dim3(grid_for(n / 8 + 1, 256)), dim3(256), 0, (hipStream_t)stream,
+                     (const half_t*)a, alpha, (const half_t*)b, beta, (half_t*)y, (long)n);
+  return pfd_check_launch("pfd_axpby_f16");
 }
 
 extern "C" int pfd_add_rowvec_f16(const void* x, int64_t ldx, const void* v, void* y, int64_t ldy, int32_t R,

@@ -504,6 +504,15 @@ static void run_elementwise() {
     std::vector<double> ref(n + 5, 0.0);
     for (long i = 0; i < n; ++i) ref[i] = (double)a[i] + (double)b[i];
     report(std::string("add_f16 rc=") + std::to_string(rc), got, ref, 1e-3, 1e-3);
+    Dev<h16> dxy(n + 5);
+    rc = pfd_axpby_f16(da.p, 0.7f, db.p, -1.25f, dxy.p, n, nullptr);
+    auto gxy = dxy.get();
+    for (long i = 0; i < n; ++i) ref[i] = 0.7 * (double)a[i] - 1.25 * (double)b[i];
+    report(std::string("axpby_f16 rc=") + std::to_string(rc), gxy, ref, 1e-3, 1e-3);
+    rc = pfd_axpby_f16(da.p, 0.3f, nullptr, 0.f, dxy.p, n, nullptr);
+    gxy = dxy.get();
+    for (long i = 0; i < n; ++i) ref[i] = 0.3 * (double)a[i];
+    report(std::string("axpby_f16 (b = NULL) rc=") + std::to_string(rc), gxy, ref, 1e-3, 1e-3);
     const int R = 37, C = 96;
     auto x = rand_h((size_t)R * C), v = rand_h(C);
     Dev<h16> dx(x), dv(v), dz((size_t)R * C);

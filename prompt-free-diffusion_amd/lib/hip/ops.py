@@ -334,6 +334,18 @@ def add(a, b, out=None):
     return out
 
 
+def axpby(a, alpha, b=None, beta=0.0, out=None):
+    """out = alpha*a + beta*b (b optional)"""
+    _chk16(a, "axpby a")
+    if not a.is_contiguous() or (b is not None and not b.is_contiguous()):
+        raise ValueError("axpby: dense tensors expected")
+    if out is None:
+        out = torch.empty_like(a)
+    _b.check(_lib().pfd_axpby_f16(a.data_ptr(), float(alpha), _ptr(b), float(beta), out.data_ptr(), a.numel(),
+                                  _stream()), "pfd_axpby_f16")
+    return out
+
+
 def add_rowvec(x, v, out=None):
     _chk16(x, "add_rowvec x")
     R, Cc, ldx = _rows(x)

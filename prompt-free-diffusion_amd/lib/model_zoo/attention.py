@@ -13,6 +13,8 @@ fp16 end to end on hand-written gfx950 kernels:
 No `b c h w <-> b (hw) c` rearranges exist (attention.py:361,368): NHWC *is* token-major.
 The score matrix is never materialised (attention.py:188-199 does, 2.1 GB per layer at C2).
 """
+import numpy as np
+import numpy.random as npr
 import torch
 import torch.nn as nn
 
@@ -64,7 +66,36 @@ class ContextKV:
         return ent
 
 
+class ContextMix:
+    """Several contexts mixed at every context layer (pfd.py:366-386 `context_mixing`):
+    'attention': h = sum_i ratio_i * SpatialTransformer_i(x, c_i), ratios normalised to 1;
+    'layer':     one context per layer, drawn with numpy's global RNG `npr.choice(n, p=ratios)`.
+    items: [(net that owns the context blocks, ContextKV, ratio)]."""
+
+    def __init__(self, items, mixing_type='attention'):
+        if mixing_type not in ('attention', 'layer'):
+            raise ValueError(f"unknown mixing_type {mixing_type!r}")
+        self.nets = [n for n, _, _ in items]
+        self.contexts = [as_context_kv(c) for _, c, _ in items]
+        r = np.array([float(r) for _, _, r in items])
+        self.ratios = r / r.sum()
+        self.mixing_type = mixing_type
+
+    def mix(self, modules, h, emb):
+        assert len(modules) == len(self.contexts)
+        if self.mixing_type == 'layer':
+            ni = npr.choice(len(modules), p=self.ratios)
+            return modules[ni].hip(h, emb, self.contexts[ni])
+        out = None
+        for m, c, r in zip(modules, self.contexts, self.ratios):
+            hi = m.hip(h, emb, c)
+            out = ops.axpby(hi, r) if out is None else ops.axpby(hi, r, out, 1.0)
+        return out
+
+
 def as_context_kv(context):
+    if isinstance(context, ContextMix):
+        return context
     if context is None or isinstance(context, ContextKV):
         return context
     if isinstance(context, (list, tuple)):

@@ -183,6 +183,101 @@ class DDIMSampler(object):
         x_info['x'] = out
         return out, intermediates
 
+    # ---- multi-context sampling (ddim.py:174-299) ------------------------------------------------
+    @torch.no_grad()
+    def sample_multicontext(self, steps, shape, x_info, c_info_list, eta=0., temperature=1., noise_dropout=0.,
+                            verbose=True, log_every_t=100):
+        self.make_schedule(ddim_num_steps=steps, ddim_eta=eta, verbose=verbose)
+        if verbose:
+            print(f'Data shape for DDIM sampling is {shape}, eta {eta}')
+        return self.ddim_sampling_multicontext(shape, x_info=x_info, c_info_list=c_info_list,
+                                               noise_dropout=noise_dropout, temperature=temperature,
+                                               log_every_t=log_every_t)
+
+    def _mix_for(self, c_info_list, bs):
+        """validate the shared guidance scale (ddim.py:257-262), build each context's CFG batch (uncond
+        first) and hoist its K / V^T; -> (ContextMix, scale, nb)"""
+        model = self.model
+        scale = None
+        for ci in c_info_list:
+            if scale is None:
+                scale = ci['unconditional_guidance_scale']
+            else:
+                assert scale == ci['unconditional_guidance_scale'], \
+                    "A different unconditional guidance scale between different context is not allowed!"
+            ci['c'] = ci['conditioning'] if scale == 1. else torch.cat([ci['unconditional_conditioning'],
+                                                                        ci['conditioning']])
+        mix = model.prepare_context_mix(c_info_list)
+        if scale != 1. and self.zero_uncond_shortcut:
+            for ci, kv in zip(c_info_list, mix.contexts):
+                kv.zero_lead = bs if not bool(ci['unconditional_conditioning'].any()) else 0
+        return mix, scale, (1 if scale == 1. else 2)
+
+    @torch.no_grad()
+    def ddim_sampling_multicontext(self, shape, x_info, c_info_list, noise_dropout=0., temperature=1.,
+                                   log_every_t=100):
+        model = self.model
+        device = model.device
+        dtype = c_info_list[0]['conditioning'].dtype
+        bs = shape[0]
+        timesteps = self.ddim_timesteps
+        if x_info.get('xt', None) is not None:
+            x = x_info['xt'].to(device=device, dtype=torch.float32)
+        elif x_info.get('x0', None) is not None:
+            x0 = x_info['x0'].to(device=device, dtype=torch.float32)
+            k = x_info['x0_forward_timesteps']
+            ts = torch.as_tensor(np.repeat(timesteps[k], bs)).long().to(device)
+            timesteps = timesteps[:k]
+            x = model.q_sample(x0, ts)
+        else:
+            x = torch.randn(shape, device=device, dtype=dtype).to(torch.float32)
+        x = x.contiguous()
+        mix, scale, nb = self._mix_for(c_info_list, bs)   # context K / V^T: once per request
+        coef = self._coef_table(scale)
+        time_range = np.flip(timesteps)
+        total_steps = timesteps.shape[0]
+        t_table = torch.as_tensor(np.ascontiguousarray(time_range), device=device).long()[:, None].repeat(1, nb * bs)
+        x_type = x_info['type']
+        emb_all, _ = model.diffuser[x_type].emb_projections(t_table[:, 0].contiguous())
+        inter = {'pred_xt': [], 'pred_x0': []}
+        xin = ops.to_nhwc(x, rep=nb)
+        for i in range(total_steps):
+            index = total_steps - i - 1
+            eps = model.apply_model_nhwc(x_type, xin, t_table[i], None, mix, emb_table=emb_all[i:i + 1])
+            noise = None
+            if self.ddim_sigmas[index] != 0.:
+                noise = noise_like(x) * temperature
+                if noise_dropout > 0.:
+                    noise = torch.nn.functional.dropout(noise, p=noise_dropout)
+                noise = noise.contiguous()
+            x, pred_x0, xin = ops.cfg_ddim_step(eps, nb, x, coef[index], noise=noise, want_next=True)
+            if index % log_every_t == 0 or index == total_steps - 1:
+                inter['pred_xt'].append(x.to(dtype))
+                inter['pred_x0'].append(pred_x0.to(dtype))
+        out = x.to(dtype)
+        x_info['x'] = out
+        return out, inter
+
+    @torch.no_grad()
+    def p_sample_ddim_multicontext(self, x_info, c_info_list, t, index, repeat_noise=False,
+                                   use_original_steps=False, noise_dropout=0., temperature=1.):
+        x = x_info['x']
+        mix, scale, nb = self._mix_for(c_info_list, x.shape[0])
+        t_in = torch.cat([t] * nb)
+        if nb == 2:
+            x_info['x'] = torch.cat([x] * 2)      # the reference leaves the doubled batch behind (:271)
+        xf = x.to(torch.float32).contiguous()
+        eps = self.model.apply_model_nhwc(x_info['type'], ops.to_nhwc(xf, rep=nb), t_in, None, mix)
+        coef = self._coef_table(scale, use_original_steps)[index]
+        noise = None
+        sig = (self.ddim_sigmas_for_original_num_steps if use_original_steps else self.ddim_sigmas)[index]
+        if float(sig) != 0.:
+            noise = (noise_like(xf, repeat_noise) * temperature).contiguous()
+            if noise_dropout > 0.:
+                noise = torch.nn.functional.dropout(noise, p=noise_dropout).contiguous()
+        x_prev, pred_x0, _ = ops.cfg_ddim_step(eps, nb, xf, coef, noise=noise, want_next=False)
+        return x_prev.to(x.dtype), pred_x0.to(x.dtype)
+
     # ---- hipGraph plumbing (launch-bound loop: ~700 kernel launches per step) -------------------
     use_graph = False
     _graphs = None

@@ -21,7 +21,7 @@ import torch.nn as nn
 
 from ..hip import layers as L
 from ..hip import ops
-from .attention import SpatialTransformer, as_context_kv
+from .attention import ContextMix, SpatialTransformer, as_context_kv
 from .common.get_model import register
 
 symbol = 'openai'
@@ -350,7 +350,13 @@ class UNetModel2D_Next(nn.Module, L._Packed):
             table, cols = self.emb_projections(timesteps)
             emb = (table, cols, False)
         semb = None
-        d_iter, c_iter = iter(self.data_blocks), iter(cnet.context_blocks)
+        d_iter = iter(self.data_blocks)
+        if isinstance(context, ContextMix):      # multi-context: every context layer mixes n transformers
+            c_iters = [iter(n.context_blocks) for n in context.nets]
+            ctx_layer = lambda hh: context.mix([next(it) for it in c_iters], hh, semb)  # noqa: E731
+        else:
+            c_iter = iter(cnet.context_blocks)
+            ctx_layer = lambda hh: next(c_iter).hip(hh, semb, context)  # noqa: E731
         ccs = list(control) if control is not None else None
         hs = []
         h = x
@@ -358,11 +364,11 @@ class UNetModel2D_Next(nn.Module, L._Packed):
             if ltype == 'd':
                 h = next(d_iter).hip(h, semb, emb=emb)
             elif ltype == 'c':
-                h = next(c_iter).hip(h, semb, context)
+                h = ctx_layer(h)
             else:
                 hs.append(h)
         for ltype in self.m_order:
-            h = next(d_iter).hip(h, semb, emb=emb) if ltype == 'd' else next(c_iter).hip(h, semb, context)
+            h = next(d_iter).hip(h, semb, emb=emb) if ltype == 'd' else ctx_layer(h)
         if ccs is not None:
             h = ops.add(h, ccs.pop())
         skip = None
@@ -374,7 +380,7 @@ class UNetModel2D_Next(nn.Module, L._Packed):
             elif ltype == 'd':
                 h, skip = next(d_iter).hip(h, semb, x2=skip, emb=emb), None
             else:
-                h = next(c_iter).hip(h, semb, context)
+                h = ctx_layer(h)
         return h
 
     def forward(self, x, timesteps, context):

@@ -19,7 +19,7 @@ import torch.nn as nn
 
 from ..hip import ops
 from ..log_service import print_log
-from .attention import ContextKV, as_context_kv
+from .attention import ContextKV, ContextMix, as_context_kv
 from .common.get_model import get_model, register
 from .diffusion_utils import extract_into_tensor, make_beta_schedule
 
@@ -160,9 +160,27 @@ class PromptFreeDiffusion(nn.Module):
         gnet = unet if self.global_layer_ptr is None else self.diffuser[self.global_layer_ptr]
         if gnet is not unet:
             raise NotImplementedError("separate global-layer diffuser")
+        if isinstance(context, ContextMix):
+            if control is not None:
+                raise NotImplementedError("ControlNet with multi-context mixing (the reference has no such path)")
+            return unet.hip(x_nhwc, timesteps, context, emb_table=emb_table)
         ccs = self._control_residuals(x_nhwc, timesteps, context, control)
         return unet.hip(x_nhwc, timesteps, context, control=ccs, context_net=self.diffuser[c_type],
                         emb_table=emb_table)
+
+    def prepare_context_mix(self, c_info_list, mixing_type='attention'):
+        """[{'type', 'c', 'ratio'}] -> ContextMix with every context's K / V^T hoisted (pfd.py:366-386)"""
+        return ContextMix([(self.diffuser[ci['type']], as_context_kv(ci['c']), ci['ratio']) for ci in c_info_list],
+                          mixing_type)
+
+    @torch.no_grad()
+    def apply_model_multicontext(self, x_info, timesteps, c_info_list, mixing_type='attention'):
+        """pfd.py:388-439: the UNet forward with every context layer replaced by the ratio-weighted sum
+        ('attention') or a random pick ('layer') over the listed contexts.  NCHW in -> NCHW eps."""
+        x = x_info['x']
+        mix = self.prepare_context_mix(c_info_list, mixing_type)
+        eps = self.apply_model_nhwc(x_info['type'], ops.to_nhwc(x), timesteps, None, mix)
+        return ops.to_nchw(eps, x.dtype)
 
     @torch.no_grad()
     def apply_model(self, x_info, timesteps, c_info):

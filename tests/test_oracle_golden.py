@@ -132,3 +132,19 @@ def test_img2img(golden, param_shapes):
     x, pred = O.img2img(eps_fn, T(golden["i2i.x0"]), T(golden["i2i.noise"]), cond, torch.zeros_like(cond), 2.0, 8, 5)
     assert rel_err(x, golden["i2i.out"]) < 1e-3
     assert rel_err(pred, golden["i2i.pred_x0_last"]) < 1e-3
+
+
+def test_multicontext_sampling(golden, param_shapes):
+    """two contexts mixed 0.7 / 0.3 at every context layer, CFG 2.0, 4 DDIM steps (ddim.py:174-299)"""
+    sd = seeded_sd(param_shapes, "diffuser.image.")
+    conds = [T(golden["see.ctx"]), T(golden["see2.ctx"])]
+    unconds = [torch.zeros_like(c) for c in conds]
+    acp = O.schedule_buffers()["alphas_cumprod"]
+    ts, a, ap, sg = O.ddim_tables(acp, 4, 0.0)
+    x = T(golden["mc.xT"])
+    for i, step in enumerate(np.flip(ts)):
+        idx = len(ts) - i - 1
+        t = torch.full((1,), int(step), dtype=torch.long)
+        x, _ = O.ddim_step_multicontext(sd, "diffuser.image.", x, t, conds, unconds, list(golden["mc.ratios"]), 2.0,
+                                        float(a[idx]), float(ap[idx]), float(sg[idx]))
+    assert rel_err(x, golden["mc.out"]) < 1e-3
