@@ -45,15 +45,23 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(GnSrc s, int HW, int G, i
 #pragma unroll
     for (int e = 0; e < 8; ++e) sm[e] = sq[e] = 0.f;
     if (rt < RT && v < nvec) {
-      for (int r = r_beg + rt; r < r_end; r += RT) {
-        Pack16 p;
-        p.u = gn_load(s, (long)b * HW + r, v);
+      // four rows in flight per thread: the kernel is a pure stream and one 16-byte load per thread
+      // (~4 MB in flight chip-wide) cannot cover the HBM latency
+      for (int r = r_beg + rt; r < r_end; r += 4 * RT) {
+        Pack16 p[4];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          const float x = (float)p.e[e];
-          sm[e] += x;
-          sq[e] += x * x;
+        for (int u = 0; u < 4; ++u) {
+          p[u].u = make_uint4(0, 0, 0, 0);
+          if (r + u * RT < r_end) p[u].u = gn_load(s, (long)b * HW + r + u * RT, v);
         }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const float x = (float)p[u].e[e];
+            sm[e] += x;
+            sq[e] += x * x;
+          }
       }
     }
 #pragma unroll
@@ -148,17 +156,93 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(GnSrc s, const half_t* __
       w[e] = sc[v * 8 + e];
       o[e] = sh[v * 8 + e];
     }
-    for (int r = r_beg + rt; r < r_end; r += RT) {
-      const long row = (long)b * HW + r;
-      Pack16 p, q;
-      p.u = gn_load(s, row, v);
+    for (int r = r_beg + rt; r < r_end; r += 4 * RT) {
+      Pack16 p[4];
 #pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        float t = (float)p.e[e] * w[e] + o[e];
-        if (act == PFD_ACT_SILU) t = pfd_silu(t);
-        q.e[e] = (half_t)t;
+      for (int u = 0; u < 4; ++u)
+        if (r + u * RT < r_end) p[u].u = gn_load(s, (long)b * HW + r + u * RT, v);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        if (r + u * RT >= r_end) break;
+        const long row = (long)b * HW + r + u * RT;
+        Pack16 q;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          float t = (float)p[u].e[e] * w[e] + o[e];
+          if (act == PFD_ACT_SILU) t = pfd_silu(t);
+          q.e[e] = (half_t)t;
+        }
+        *reinterpret_cast<uint4*>(y + row * ldy + v * 8) = q.u;
       }
-      *reinterpret_cast<uint4*>(y + row * ldy + v * 8) = q.u;
+    }
+  }
+}
+
+// ---- GroupNorm, small-slab form: one block per (sample, group) keeps the group's HW x C/G slab in
+// registers (<= 32 chunks of 4 halves per thread), so statistics + normalise + activation are ONE launch
+// and the input is read once (4 B/element).  Serves the 8^2 / 16^2 / 32^2 UNet levels, where the
+// two-launch form is bound by launch latency (1280 @ 8^2: 10 us for 1.3 MB).  Needs (C/G) % 4 == 0.
+constexpr int GNS_MAX = 32;
+
+__global__ __launch_bounds__(256) void gn_small_kernel(GnSrc s, const half_t* __restrict__ gamma,
+                                                       const half_t* __restrict__ beta, half_t* __restrict__ y,
+                                                       long ldy, int HW, int G, int act, float eps) {
+  __shared__ float red[8];
+  const int C = s.C1 + s.C2;
+  const int cpg = C / G, cpr = cpg / 4;
+  const int g = blockIdx.x, b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int total = HW * cpr;
+  uint2 v[GNS_MAX];
+  float sm = 0.f, sq = 0.f;
+#pragma unroll
+  for (int k = 0; k < GNS_MAX; ++k) {
+    const int idx = tid + 256 * k;
+    v[k] = make_uint2(0, 0);
+    if (idx < total) {
+      const int r = idx / cpr, c = g * cpg + (idx - r * cpr) * 4;
+      const long row = (long)b * HW + r;
+      v[k] = c < s.C1 ? *reinterpret_cast<const uint2*>(s.x1 + row * s.ld1 + c)
+                      : *reinterpret_cast<const uint2*>(s.x2 + row * s.ld2 + (c - s.C1));
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < GNS_MAX; ++k) {   // padding slots hold zeros: they add nothing to either sum
+    Pack8 p;
+    p.u = v[k];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float x = (float)p.e[e];
+      sm += x;
+      sq += x * x;
+    }
+  }
+  sm = wave_sum(sm);
+  sq = wave_sum(sq);
+  if (lane == 0) {
+    red[wave] = sm;
+    red[4 + wave] = sq;
+  }
+  __syncthreads();
+  const float count = (float)HW * (float)cpg;
+  const float mean = (red[0] + red[1] + red[2] + red[3]) / count;
+  const float rstd = rsqrtf(fmaxf((red[4] + red[5] + red[6] + red[7]) / count - mean * mean, 0.f) + eps);
+#pragma unroll
+  for (int k = 0; k < GNS_MAX; ++k) {
+    const int idx = tid + 256 * k;
+    if (idx < total) {
+      const int r = idx / cpr, c = g * cpg + (idx - r * cpr) * 4;
+      Pack8 p, ga, be, o;
+      p.u = v[k];
+      ga.u = *reinterpret_cast<const uint2*>(gamma + c);
+      be.u = *reinterpret_cast<const uint2*>(beta + c);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float w = rstd * (float)ga.e[e];
+        float t = (float)p.e[e] * w + ((float)be.e[e] - mean * w);
+        if (act == PFD_ACT_SILU) t = pfd_silu(t);
+        o.e[e] = (half_t)t;
+      }
+      *reinterpret_cast<uint2*>(y + ((long)b * HW + r) * ldy + c) = o.u;
     }
   }
 }
@@ -289,6 +373,45 @@ __global__ __launch_bounds__(256) void softmax_rows_kernel(const half_t* __restr
   }
 }
 
+// rows longer than the register-resident form (VAE mid attention of 1152..1536-wide outputs: N up to
+// 36 864 keys): three streaming passes over the row (max, sum, write); the row (<= 72 KB) stays in L2.
+__global__ __launch_bounds__(256) void softmax_rows_long_kernel(const half_t* __restrict__ x, long ldx,
+                                                                half_t* __restrict__ y, long ldy, int N, float scale) {
+  __shared__ float red[8];
+  const int row = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int nvec = N / 8;
+  const half_t* xr = x + (long)row * ldx;
+  float mx = -INFINITY;
+  for (int v = tid; v < nvec; v += 256) {
+    Pack16 p;
+    p.u = *reinterpret_cast<const uint4*>(xr + v * 8);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) mx = fmaxf(mx, (float)p.e[e] * scale);
+  }
+  mx = wave_max(mx);
+  if (lane == 0) red[wave] = mx;
+  __syncthreads();
+  mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  float sum = 0.f;
+  for (int v = tid; v < nvec; v += 256) {
+    Pack16 p;
+    p.u = *reinterpret_cast<const uint4*>(xr + v * 8);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) sum += __expf((float)p.e[e] * scale - mx);
+  }
+  sum = wave_sum(sum);
+  if (lane == 0) red[4 + wave] = sum;
+  __syncthreads();
+  const float inv = 1.f / (red[4] + red[5] + red[6] + red[7]);
+  for (int v = tid; v < nvec; v += 256) {   // in-place safe: each thread rewrites only what it just read
+    Pack16 p, o;
+    p.u = *reinterpret_cast<const uint4*>(xr + v * 8);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o.e[e] = (half_t)(__expf((float)p.e[e] * scale - mx) * inv);
+    *reinterpret_cast<uint4*>(y + (long)row * ldy + v * 8) = o.u;
+  }
+}
+
 }  // namespace
 
 extern "C" size_t pfd_groupnorm_ws_bytes(int32_t B, int32_t C, int32_t HW) {
@@ -311,6 +434,15 @@ extern "C" int pfd_groupnorm_f16(const void* x1, int32_t C1, int64_t ldx1, const
   if (ws_bytes < pfd_groupnorm_ws_bytes(B, C, HW)) return PFD_EINVAL;
   hipStream_t s = (hipStream_t)stream;
   GnSrc src{(const half_t*)x1, (const half_t*)x2, ldx1, ldx2, C1, C2};
+  const bool prof = pfd_prof_on();
+  const int cpg = C / G;
+  if (cpg % 4 == 0 && cpg >= 32 && (long)HW * (cpg / 4) <= 256 * GNS_MAX && (long)B * G >= 128) {  // narrower groups: 40-byte row segments, the two-launch form wins (640 @ 32^2: 15 vs 17 us)
+    if (prof) pfd_prof_begin(10, 8.0 * B * HW * C, 4.0 * B * HW * C, s);  // 2B read + 2B write
+    hipLaunchKernelGGL(gn_small_kernel, dim3(G, B), dim3(256), 0, s, src, (const half_t*)gamma, (const half_t*)beta,
+                       (half_t*)y, (long)ldy, HW, G, act, eps);
+    if (prof) pfd_prof_end(s);
+    return pfd_check_launch("pfd_groupnorm_f16(small)");
+  }
   const int nvec = C / 8;
   const int RT = nvec < 256 ? 256 / nvec : 1;
   // aim for ~512 blocks over the chip, at least 4 row sweeps per block (every apply block re-reduces
@@ -323,7 +455,6 @@ extern "C" int pfd_groupnorm_f16(const void* x1, int32_t C1, int64_t ldx1, const
   const int rpc = (HW + nchunks - 1) / nchunks;
   nchunks = (HW + rpc - 1) / rpc;
   float* partial = (float*)ws;
-  const bool prof = pfd_prof_on();
   if (prof) pfd_prof_begin(10, 8.0 * B * HW * C, 6.0 * B * HW * C, s);  // 2B stats read + 2B read + 2B write
   hipLaunchKernelGGL(gn_stats_kernel, dim3(nchunks, B), dim3(256), 0, s, src, HW, G, rpc, partial);
   hipLaunchKernelGGL(gn_apply_kernel, dim3(nchunks, B), dim3(256), 0, s, src, (const half_t*)gamma,
@@ -352,9 +483,13 @@ extern "C" int pfd_layernorm_f16(const void* x, int64_t ldx, const void* gamma, 
 extern "C" int pfd_softmax_rows_f16(const void* x, int64_t ldx, void* y, int64_t ldy, int32_t R, int32_t N,
                                     float scale, pfd_stream_t stream) {
   if (!x || !y || R <= 0 || N <= 0) return PFD_EINVAL;
-  if ((N & 7) || N > 256 * 8 * SM_MAXV) return PFD_ESHAPE;
+  if (N & 7) return PFD_ESHAPE;
   if ((ldx & 7) || (ldy & 7)) return PFD_EINVAL;
-  hipLaunchKernelGGL(softmax_rows_kernel, dim3(R), dim3(256), 0, (hipStream_t)stream, (const half_t*)x,
-                     (long)ldx, (half_t*)y, (long)ldy, N, scale);
+  if (N > 256 * 8 * SM_MAXV)
+    hipLaunchKernelGGL(softmax_rows_long_kernel, dim3(R), dim3(256), 0, (hipStream_t)stream, (const half_t*)x,
+                       (long)ldx, (half_t*)y, (long)ldy, N, scale);
+  else
+    hipLaunchKernelGGL(softmax_rows_kernel, dim3(R), dim3(256), 0, (hipStream_t)stream, (const half_t*)x,
+                       (long)ldx, (half_t*)y, (long)ldy, N, scale);
   return pfd_check_launch("pfd_softmax_rows_f16");
 }

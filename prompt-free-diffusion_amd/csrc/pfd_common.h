@@ -58,6 +58,11 @@ union Pack16 {
   half_t e[8];
 };
 
+union Pack8 {
+  uint2 u;
+  half_t e[4];
+};
+
 // XCD-aware, bijective remap of a linear block id: the dispatcher places block b on XCD
 // b % 8; give every XCD one contiguous chunk of the tile space so neighbouring tiles
 // (which share an operand panel) meet in the same L2.  Speed only, never correctness.

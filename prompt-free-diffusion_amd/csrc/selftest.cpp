@@ -721,6 +721,17 @@ static int replay(const char* path, bool timed = false, int force_tile = 0) {
 int main(int argc, char** argv) {
   if (argc > 2 && !strcmp(argv[1], "--replay")) return replay(argv[2]);
   if (argc > 1 && !strcmp(argv[1], "--launch-floor")) { bench_launch_floor(); return 0; }
+  if (argc > 1 && !strcmp(argv[1], "--bench-gn")) {
+    bench_gn("groupnorm+silu 320 @64^2", 8, 4096, 320);
+    bench_gn("groupnorm+silu 640 @64^2", 8, 4096, 640);
+    bench_gn("groupnorm+silu 640 @32^2", 8, 1024, 640);
+    bench_gn("groupnorm+silu 1280 @32^2", 8, 1024, 1280);
+    bench_gn("groupnorm+silu 1280 @16^2", 8, 256, 1280);
+    bench_gn("groupnorm+silu 2560 @16^2", 8, 256, 2560);
+    bench_gn("groupnorm+silu 1280 @8^2", 8, 64, 1280);
+    bench_gn("groupnorm+silu 128 @512^2", 4, 262144, 128);
+    return 0;
+  }
   if (argc > 2 && !strcmp(argv[1], "--replay-time")) return replay(argv[2], true, argc > 3 ? atoi(argv[3]) : 0);
   const bool bench = argc > 1 && !strcmp(argv[1], "--bench");
   const bool only_bench = argc > 1 && !strcmp(argv[1], "--only-bench");
@@ -802,6 +813,11 @@ int main(int argc, char** argv) {
     run_gn_case(1, 50, 1280, 1280, 32, PFD_ACT_SILU, 1e-5f);  // two vec slots per thread
     run_gn_case(2, 1024, 128, 0, 32, PFD_ACT_SILU, 1e-6f);
     run_gn_case(1, 16, 1920, 0, 32, PFD_ACT_SILU, 1e-5f);
+    // single-launch small-slab form ((C/G) % 4 == 0, slab <= 32 K elements, >= 128 blocks)
+    run_gn_case(4, 64, 1280, 0, 32, PFD_ACT_SILU, 1e-5f);
+    run_gn_case(4, 256, 1280, 1280, 32, PFD_ACT_SILU, 1e-5f);
+    run_gn_case(8, 128, 1024, 0, 32, PFD_ACT_NONE, 1e-6f);
+    run_gn_case(4, 100, 1280, 640, 32, PFD_ACT_SILU, 1e-5f);   // cpg 60: groups straddle the seam
 
     run_ln_case(37, 320, 0, 0, 0, 0);
     run_ln_case(10, 1280, 0, 0, 0, 0);
@@ -809,6 +825,8 @@ int main(int argc, char** argv) {
     run_ln_case(2 * 4 * 3, 4 * 96, 1, 2, 7, 5);
     run_softmax_case(5, 4096, 0.044f);
     run_softmax_case(3, 1152, 0.1f);
+    run_softmax_case(2, 36864, 0.044f);   // long-row form (N > 16384)
+    run_softmax_case(2, 16392, 0.05f);
     run_elementwise();
     printf("SELFTEST %d/%d passed, %d failed\n", g_total - g_fail, g_total, g_fail);
   }

@@ -83,8 +83,8 @@ class AttnBlock(nn.Module):
     def hip(self, x):
         B, H, W_, Cc = x.shape
         N = H * W_
-        if N % 64 or N > 16384:
-            raise NotImplementedError(f"VAE attention over {N} tokens (need a multiple of 64, <= 16384)")
+        if N % 64:
+            raise NotImplementedError(f"VAE attention over {N} tokens (need a multiple of 64)")
         hn = self.norm.hip(x)
         q = self.q.hip(hn).view(B, N, Cc)
         k = self.k.hip(hn).view(B, N, Cc)

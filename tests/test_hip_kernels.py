@@ -125,6 +125,28 @@ def test_attention(B, H, Nq, Nk, D):
     close(o.view(B, Nq, H, D), ref.permute(0, 2, 1, 3), 5e-3)
 
 
+def test_vae_attention_beyond_16k_tokens():
+    """tall / wide outputs up to 1536 px (app.py:197-207): the VAE mid attention sees up to 36 864 tokens;
+    rows longer than 16 384 take the streaming softmax.  Checked against torch fp32 on the same device."""
+    from lib.hip import ops
+    from lib.model_zoo.autokl_modules import AttnBlock
+    s = _dev(3, 36864, scale=3.0)
+    y = ops.softmax_rows(s, 0.044)
+    close(y, torch.softmax(s.float() * 0.044, -1), 1e-3)
+    torch.manual_seed(3)
+    m = AttnBlock(512).half().cuda()
+    H, W = 192, 128                                     # 24 576 tokens = a 1536 x 1024 image
+    x = _dev(1, H, W, 512)
+    y = m.hip(x)
+    xf = x.float().permute(0, 3, 1, 2)
+    hn = F.group_norm(xf, 32, m.norm.weight.float(), m.norm.bias.float(), 1e-6)
+    q, k, v = (F.conv2d(hn, getattr(m, n).weight.float(), getattr(m, n).bias.float()).flatten(2) for n in "qkv")
+    att = torch.softmax(torch.bmm(q.transpose(1, 2), k) * 512 ** -0.5, dim=2)
+    o = torch.bmm(v, att.transpose(1, 2)).view(1, 512, H, W)
+    ref = xf + F.conv2d(o, m.proj_out.weight.float(), m.proj_out.bias.float())
+    close(y, ref.permute(0, 2, 3, 1))
+
+
 def test_cfg_ddim_step_matches_formula():
     from lib.hip import ops
     B, C, h, w = 2, 4, 8, 8
