@@ -65,6 +65,11 @@ __device__ __forceinline__ void glds16(const void* src, void* lds_dst) {
 
 // Epilogue shared by the wide-tile kernels: each wave stages 32 x 80 fp32 results through its private LDS
 // region (the operand ring is dead by now) and emits whole 16-byte row segments.
+// (Split-K keeps a separate reduce launch.  An in-kernel "last block to arrive reduces the slabs" variant
+//  was built and measured: with agent-scope fences the L2 write-back/invalidate per block took the UNet
+//  loop from 753 to 1046 ms; with sc1 / sc0+sc1 coherent slab accesses instead of fences, 685 -> 868 ms --
+//  the uncached slab round trip sits on the critical path of every tile's last block, while the reduce
+//  kernel streams the same data with 2048 blocks in ~11 us.)
 template <int WMB>
 __device__ __forceinline__ void epilogue160(const float4_t (&acc)[WMB][5], const G160Params& p, char* smem, int wave,
                                             int lane, int m0, int n0, int wm, int wn, int split) {

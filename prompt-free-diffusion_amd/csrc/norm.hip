@@ -319,6 +319,71 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const half_t* __restrict
   }
 }
 
+// LayerNorm of many short rows (UNet transformer blocks: C = 320 / 640 / 1280, M = 2 K .. 32 K tokens): each
+// wave normalises ROWS consecutive rows and issues all their loads up front -- with one row per wave the
+// kernel had a single 16-byte load per lane in flight and ran at a third of the HBM rate.
+template <int NV, int ROWS>
+__global__ __launch_bounds__(256) void layernorm_rows_kernel(const half_t* __restrict__ x, long ldx,
+                                                             const half_t* __restrict__ gamma,
+                                                             const half_t* __restrict__ beta, half_t* __restrict__ y,
+                                                             long ldy, int M, int C, float eps) {
+  const int lane = threadIdx.x & 63;
+  const int row0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * ROWS;
+  if (row0 >= M) return;
+  const int nvec = C / 8;
+  Pack16 p[ROWS][NV];
+#pragma unroll
+  for (int r = 0; r < ROWS; ++r)
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+      const int v = lane + 64 * k;
+      p[r][k].u = make_uint4(0, 0, 0, 0);
+      if (v < nvec && row0 + r < M) p[r][k].u = *reinterpret_cast<const uint4*>(x + (long)(row0 + r) * ldx + v * 8);
+    }
+  Pack16 g[NV], bt[NV];
+#pragma unroll
+  for (int k = 0; k < NV; ++k) {
+    const int v = lane + 64 * k;
+    g[k].u = bt[k].u = make_uint4(0, 0, 0, 0);
+    if (v < nvec) {
+      g[k].u = *reinterpret_cast<const uint4*>(gamma + v * 8);
+      bt[k].u = *reinterpret_cast<const uint4*>(beta + v * 8);
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < ROWS; ++r) {
+    if (row0 + r >= M) break;
+    float sum = 0.f;
+#pragma unroll
+    for (int k = 0; k < NV; ++k)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) sum += (float)p[r][k].e[e];   // padding lanes hold zeros
+    const float mean = wave_sum(sum) / (float)C;
+    float sq = 0.f;
+#pragma unroll
+    for (int k = 0; k < NV; ++k)
+      if (lane + 64 * k < nvec) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float d = (float)p[r][k].e[e] - mean;
+          sq += d * d;
+        }
+      }
+    const float rstd = rsqrtf(wave_sum(sq) / (float)C + eps);
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+      const int v = lane + 64 * k;
+      if (v < nvec) {
+        Pack16 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+          o.e[e] = (half_t)(((float)p[r][k].e[e] - mean) * rstd * (float)g[k].e[e] + (float)bt[k].e[e]);
+        *reinterpret_cast<uint4*>(y + (long)(row0 + r) * ldy + v * 8) = o.u;
+      }
+    }
+  }
+}
+
 // ---- scaled row softmax: one block per row ----
 constexpr int SM_MAXV = 8;  // N <= 256*8*8 = 16384
 
@@ -473,6 +538,19 @@ extern "C" int pfd_layernorm_f16(const void* x, int64_t ldx, const void* gamma, 
   if (gather4) {
     if ((C % 32) || B <= 0 || H <= 0 || W <= 0) return PFD_EINVAL;
     if ((long)B * ((H + 1) / 2) * ((W + 1) / 2) != M) return PFD_EINVAL;
+  }
+  if (!gather4 && C <= 1536 && M >= 2048) {
+    constexpr int ROWS = 4;
+    const dim3 grid((M + 4 * ROWS - 1) / (4 * ROWS));
+    const int nv = (C / 8 + 63) / 64;
+#define PFD_LN_ROWS(NV)                                                                                         \
+  hipLaunchKernelGGL((layernorm_rows_kernel<NV, ROWS>), grid, dim3(256), 0, (hipStream_t)stream, (const half_t*)x, \
+                     (long)ldx, (const half_t*)gamma, (const half_t*)beta, (half_t*)y, (long)ldy, M, C, eps)
+    if (nv == 1) PFD_LN_ROWS(1);
+    else if (nv == 2) PFD_LN_ROWS(2);
+    else PFD_LN_ROWS(3);
+#undef PFD_LN_ROWS
+    return pfd_check_launch("pfd_layernorm_f16(rows)");
   }
   hipLaunchKernelGGL(layernorm_kernel, dim3((M + 3) / 4), dim3(256), 0, (hipStream_t)stream,
                      (const half_t*)x, (long)ldx, (const half_t*)gamma, (const half_t*)beta, (half_t*)y,
