@@ -586,6 +586,15 @@ static void bench_gn(const char* label, int B, int HW, int C) {
   fflush(stdout);
 }
 
+static void bench_ln(const char* label, int M, int C) {
+  auto x = rand_h((size_t)M * C), g = rand_h(C), b = rand_h(C);
+  Dev<h16> dx(x), dg(g), db(b), dy((size_t)M * C);
+  int rc = 0;
+  const float ms = time_ms([&] { rc |= pfd_layernorm_f16(dx.p, C, dg.p, db.p, dy.p, C, M, C, 1e-5f, 0, 0, 0, 0, nullptr); }, 20);
+  printf("bench %-34s M%d C%d rc=%d %8.3f ms %8.1f GB/s (4 B/elem)\n", label, M, C, rc, ms, 4.0 * M * C / (ms * 1e-3) / 1e9);
+  fflush(stdout);
+}
+
 // Per-launch floor of the runtime: N dependent launches of a kernel with ~no work, in-stream and as one
 // hipGraph -- what every one of the ~500 launches of a UNet pass pays on top of its own duration.
 static void bench_launch_floor() {
@@ -730,6 +739,9 @@ int main(int argc, char** argv) {
     bench_gn("groupnorm+silu 2560 @16^2", 8, 256, 2560);
     bench_gn("groupnorm+silu 1280 @8^2", 8, 64, 1280);
     bench_gn("groupnorm+silu 128 @512^2", 4, 262144, 128);
+    bench_ln("layernorm 320 @64^2", 32768, 320);
+    bench_ln("layernorm 640 @32^2", 8192, 640);
+    bench_ln("layernorm 1280 @16^2", 2048, 1280);
     return 0;
   }
   if (argc > 2 && !strcmp(argv[1], "--replay-time")) return replay(argv[2], true, argc > 3 ? atoi(argv[3]) : 0);
@@ -823,6 +835,9 @@ int main(int argc, char** argv) {
     run_ln_case(10, 1280, 0, 0, 0, 0);
     run_ln_case(5, 3072, 0, 0, 0, 0);
     run_ln_case(2 * 4 * 3, 4 * 96, 1, 2, 7, 5);
+    run_ln_case(2051, 320, 0, 0, 0, 0);    // multi-row form (M >= 2048), ragged last wave
+    run_ln_case(2048, 640, 0, 0, 0, 0);
+    run_ln_case(2049, 1280, 0, 0, 0, 0);
     run_softmax_case(5, 4096, 0.044f);
     run_softmax_case(3, 1152, 0.1f);
     run_softmax_case(2, 36864, 0.044f);   // long-row form (N > 16384)
