@@ -130,6 +130,13 @@ __global__ __launch_bounds__(256) void attention_kernel(const AttnParams p) {
       if (ch < V_CHUNKS)   // key chunks past Nk are clamped (their P is 0); the ragged tile zeroes them below
         vreg[j] = *reinterpret_cast<const uint4*>(vbase + (long)d * p.ldvt + min(kv0 + cc * 8, v_last));
     }
+  };
+  // (the ragged-tile masking lives HERE, after the MFMAs of the current tile: touching the freshly loaded
+  //  registers inside load_tile made the compiler wait for the global loads before the MFMAs they are
+  //  supposed to overlap with)
+  auto store_tile = [&](const uint4* kreg, uint4* vreg, int stage, int kv0) {
+    half_t* Kd = Ks + stage * K_TILE_HALFS;
+    half_t* Vd = Vts + stage * V_TILE_HALFS;
     if (kv0 + KV_TILE > p.Nk) {  // ragged last tile only (wave-uniform)
 #pragma unroll
       for (int j = 0; j < V_PT; ++j) {
@@ -143,10 +150,6 @@ __global__ __launch_bounds__(256) void attention_kernel(const AttnParams p) {
         vreg[j] = make_uint4(w[0], w[1], w[2], w[3]);
       }
     }
-  };
-  auto store_tile = [&](const uint4* kreg, const uint4* vreg, int stage) {
-    half_t* Kd = Ks + stage * K_TILE_HALFS;
-    half_t* Vd = Vts + stage * V_TILE_HALFS;
 #pragma unroll
     for (int j = 0; j < K_PT; ++j) {
       const int ch = tid + 256 * j;
@@ -245,13 +248,17 @@ __global__ __launch_bounds__(256) void attention_kernel(const AttnParams p) {
   };
 
   load_tile(kregA, vregA, 0);
-  store_tile(kregA, vregA, 0);
+  store_tile(kregA, vregA, 0, 0);
+  // vmcnt(0) on EVERY path into the loop (the waits above sit inside exec-masked blocks): otherwise the
+  // compiler must assume the Q fragments may still be in flight at the first MFMA of each tile and, vmcnt
+  // being an in-order counter, drains the just-issued K/V prefetch there as well
+  __builtin_amdgcn_s_waitcnt(0x0F70);
   __syncthreads();
   for (int t = 0; t < ntiles; ++t) {
     const int stage = t & 1;
     if (t + 1 < ntiles) load_tile(kregA, vregA, (t + 1) * KV_TILE);  // in flight during this tile's MFMAs
     compute_tile(t, stage);
-    if (t + 1 < ntiles) store_tile(kregA, vregA, stage ^ 1);
+    if (t + 1 < ntiles) store_tile(kregA, vregA, stage ^ 1, (t + 1) * KV_TILE);
     __syncthreads();
   }
 

@@ -730,6 +730,14 @@ static int replay(const char* path, bool timed = false, int force_tile = 0) {
 int main(int argc, char** argv) {
   if (argc > 2 && !strcmp(argv[1], "--replay")) return replay(argv[2]);
   if (argc > 1 && !strcmp(argv[1], "--launch-floor")) { bench_launch_floor(); return 0; }
+  if (argc > 1 && !strcmp(argv[1], "--bench-attn")) {
+    bench_attn("self-attn 64^2 d40", 8, 8, 4096, 4096, 40);
+    bench_attn("self-attn 32^2 d80", 8, 8, 1024, 1024, 80);
+    bench_attn("self-attn 16^2 d160", 8, 8, 256, 256, 160);
+    bench_attn("cross-attn 64^2 d40", 4, 8, 4096, 148, 40);
+    bench_attn("seecoder cross d96", 1, 8, 144, 4096, 96);
+    return 0;
+  }
   if (argc > 1 && !strcmp(argv[1], "--bench-gn")) {
     bench_gn("groupnorm+silu 320 @64^2", 8, 4096, 320);
     bench_gn("groupnorm+silu 640 @64^2", 8, 4096, 640);

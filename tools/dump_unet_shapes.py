@@ -22,6 +22,7 @@ x = torch.randn(B, 4, 64, 64, device='cuda')
 c = torch.randn(B, 148, 768, device='cuda', dtype=torch.float16)
 t = torch.full((B,), 981, device='cuda', dtype=torch.long)
 ctx = net.prepare_context(c)
+ctx.zero_lead = B // 2   # the bench runs CFG with the all-zero unconditional context (app.py:236)
 unet = net.diffuser['image']
 emb_all, _ = unet.emb_projections(t[:1])
 xin = ops.to_nhwc(x)
