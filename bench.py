@@ -183,7 +183,7 @@ def main():
         }
         if prof:
             top = max(prof, key=lambda b: b["ms"])
-            mfma = top["name"].startswith(("gemm", "attention", "swin"))
+            mfma = top["name"].startswith(("gemm", "conv3x3", "attention", "swin"))
             secs = top["ms"] / 1e3
             if mfma:
                 ach = top["flops"] / secs / 1e12

@@ -63,8 +63,13 @@ __device__ __forceinline__ void glds16(const void* src, void* lds_dst) {
                                    (__attribute__((address_space(3))) void*)lds_dst, 16, 0, 0);
 }
 
-// Epilogue shared by the wide-tile kernels: each wave stages 32 x 80 fp32 results through its private LDS
-// region (the operand ring is dead by now) and emits whole 16-byte row segments.
+// Epilogue shared by the wide-tile kernels.  The MFMAs are issued with the operands SWAPPED (W fragment as
+// the A operand, activation fragment as B), so a 16x16 accumulator tile holds, per lane, FOUR CONSECUTIVE
+// OUTPUT COLUMNS of ONE output row: row m = tile row (lane & 15), columns n = 4*(lane >> 4) + r.  Bias / row
+// vector / residual are 8-byte loads, the result is an 8-byte store, and nothing goes through LDS (the
+// row-major staging the natural layout needed cost 2 x 164 KB of LDS traffic per 256x160 tile -- as much as
+// two K steps, on problems that have 5 to 20 of them).  Only GEGLU, whose x / gate partners sit 40 columns
+// apart, still exchanges through the wave's private LDS region.
 // (Split-K keeps a separate reduce launch.  An in-kernel "last block to arrive reduces the slabs" variant
 //  was built and measured: with agent-scope fences the L2 write-back/invalidate per block took the UNet
 //  loop from 753 to 1046 ms; with sc1 / sc0+sc1 coherent slab accesses instead of fences, 685 -> 868 ms --
@@ -74,48 +79,51 @@ template <int WMB>
 __device__ __forceinline__ void epilogue160(const float4_t (&acc)[WMB][5], const G160Params& p, char* smem, int wave,
                                             int lane, int m0, int n0, int wm, int wn, int split) {
   const int l15 = lane & 15, g = lane >> 4;
-  float* Es = reinterpret_cast<float*>(smem + wave * EP_WAVE_BYTES);
-  const bool geglu = p.act == PFD_ACT_GEGLU;
-  const bool raw = p.splits > 1;
+  const int mw = m0 + wm * WMB * 16 + l15;   // + i*16: this lane's output row in row-tile i
+  const int nw = n0 + wn * 80 + 4 * g;       // + j*16: first of this lane's 4 columns in column-tile j
+
+  if (p.splits > 1) {  // split-K: raw fp32 partials, [split][M][N]
 #pragma unroll
-  for (int h = 0; h < WMB / 2; ++h) {
+    for (int i = 0; i < WMB; ++i) {
+      const int m = mw + i * 16;
+      if (m >= p.M) continue;
 #pragma unroll
-    for (int ii = 0; ii < 2; ++ii)
+      for (int j = 0; j < 5; ++j)
+        *reinterpret_cast<float4_t*>(p.ws + ((long)split * p.M + m) * p.N + nw + j * 16) = acc[i][j];
+    }
+    return;
+  }
+
+  if (p.Ct && n0 >= p.n_split) {  // transposed tail (tile-uniform): Ct[(n - n_split) * ldct + m] (+ bias)
+    float bv[5][4];
+#pragma unroll
+    for (int j = 0; j < 5; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) bv[j][r] = p.bias ? (float)p.bias[nw + j * 16 + r] : 0.f;
+#pragma unroll
+    for (int i = 0; i < WMB; ++i) {
+      const int m = mw + i * 16;
+      if (m >= p.M) continue;
 #pragma unroll
       for (int j = 0; j < 5; ++j)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) Es[(ii * 16 + 4 * g + r) * EP_LD + j * 16 + l15] = acc[2 * h + ii][j][r];
-    const int mrow0 = m0 + wm * WMB * 16 + h * 32;
-    if (p.Ct && n0 >= p.n_split) {
-      // transposed tail (tile-uniform): column c of the staged 32 x 80 block becomes 32 consecutive
-      // halves of row (n - n_split) of Ct -- four 16-byte segments, one per lane
+        for (int r = 0; r < 4; ++r)   // 16 lanes = 16 consecutive m: 32-byte segments per output row
+          p.Ct[(long)(nw + j * 16 + r - p.n_split) * p.ldct + m] = (half_t)(acc[i][j][r] + bv[j][r]);
+    }
+    return;
+  }
+
+  if (p.act == PFD_ACT_GEGLU) {
+    // stage 32 x 80 fp32 per pass through the wave's private LDS region (the operand ring is dead by now)
+    float* Es = reinterpret_cast<float*>(smem + wave * EP_WAVE_BYTES);
 #pragma unroll
-      for (int t = 0; t < 5; ++t) {
-        const int idx = lane + 64 * t;
-        const int c = idx >> 2, rc = idx & 3;
-        const int n = n0 + wn * 80 + c;
-        const int m = mrow0 + rc * 8;
-        if (m >= p.M) continue;
-        const float bv = p.bias ? (float)p.bias[n] : 0.f;
-        Pack16 o;
+    for (int h = 0; h < WMB / 2; ++h) {
 #pragma unroll
-        for (int e = 0; e < 8; ++e) o.e[e] = (half_t)(Es[(rc * 8 + e) * EP_LD + c] + bv);
-        half_t* dst = p.Ct + (long)(n - p.n_split) * p.ldct + m;
-        if (m + 8 <= p.M) {
-          *reinterpret_cast<uint4*>(dst) = o.u;
-        } else {
-          for (int e = 0; e < p.M - m; ++e) dst[e] = o.e[e];
-        }
-      }
-    } else if (raw) {
-      for (int idx = lane; idx < 32 * 20; idx += 64) {  // 20 float4 per row
-        const int rr = idx / 20, cc = idx - rr * 20;
-        const int m = mrow0 + rr;
-        if (m < p.M)
-          *reinterpret_cast<float4_t*>(p.ws + ((long)split * p.M + m) * p.N + n0 + wn * 80 + cc * 4) =
-              *reinterpret_cast<const float4_t*>(Es + rr * EP_LD + cc * 4);
-      }
-    } else if (geglu) {
+      for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+        for (int j = 0; j < 5; ++j)
+          *reinterpret_cast<float4_t*>(Es + (ii * 16 + l15) * EP_LD + j * 16 + 4 * g) = acc[2 * h + ii][j];
+      const int mrow0 = m0 + wm * WMB * 16 + h * 32;
       // loads first (all items), then math: one exposed latency per pass instead of one per item
       Pack16 bx[3], bg[3];
 #pragma unroll
@@ -144,46 +152,46 @@ __device__ __forceinline__ void epilogue160(const float4_t (&acc)[WMB][5], const
         }
         *reinterpret_cast<uint4*>(p.C + (long)m * p.ldc + (n0 >> 1) + wn * 40 + cc * 8) = o.u;
       }
-    } else {
-      Pack16 lb[5], lv[5], lr[5];
+    }
+    return;
+  }
+
+  // ---- bias + per-sample row vector -> activation -> + residual -> fp16, straight from the accumulators ----
+  float bv[5][4];
 #pragma unroll
-      for (int t = 0; t < 5; ++t) {
-        const int idx = lane + 64 * t;
-        const int rr = idx / 10, cc = idx - rr * 10;
-        const int m = mrow0 + rr;
-        const int n = n0 + wn * 80 + cc * 8;
-        lb[t].u = lv[t].u = lr[t].u = make_uint4(0, 0, 0, 0);
-        if (m < p.M) {
-          if (p.bias) lb[t].u = *reinterpret_cast<const uint4*>(p.bias + n);
-          if (p.rowvec) lv[t].u = *reinterpret_cast<const uint4*>(p.rowvec + (long)(m / p.rows_per_rv) * p.ldrv + n);
-          if (p.R) lr[t].u = *reinterpret_cast<const uint4*>(p.R + (long)m * p.ldr + n);
-        }
+  for (int j = 0; j < 5; ++j) {
+    Pack8 b;
+    b.u = make_uint2(0, 0);
+    if (p.bias) b.u = *reinterpret_cast<const uint2*>(p.bias + nw + j * 16);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) bv[j][r] = (float)b.e[r];
+  }
+#pragma unroll
+  for (int i = 0; i < WMB; ++i) {
+    const int m = mw + i * 16;
+    if (m >= p.M) continue;
+    Pack8 lv[5], lr[5];
+    const half_t* rvp = p.rowvec ? p.rowvec + (long)(m / p.rows_per_rv) * p.ldrv + nw : nullptr;
+    const half_t* rp = p.R ? p.R + (long)m * p.ldr + nw : nullptr;
+#pragma unroll
+    for (int j = 0; j < 5; ++j) {   // all loads of the row first: one exposed latency per row tile
+      lv[j].u = lr[j].u = make_uint2(0, 0);
+      if (rvp) lv[j].u = *reinterpret_cast<const uint2*>(rvp + j * 16);
+      if (rp) lr[j].u = *reinterpret_cast<const uint2*>(rp + j * 16);
+    }
+    half_t* cp = p.C + (long)m * p.ldc + nw;
+#pragma unroll
+    for (int j = 0; j < 5; ++j) {
+      Pack8 o;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float v = acc[i][j][r] + bv[j][r] + (float)lv[j].e[r];
+        if (p.act == PFD_ACT_GELU) v = pfd_gelu(v);
+        else if (p.act == PFD_ACT_RELU) v = fmaxf(v, 0.f);
+        else if (p.act == PFD_ACT_SILU) v = pfd_silu(v);
+        o.e[r] = (half_t)(v + (float)lr[j].e[r]);
       }
-#pragma unroll
-      for (int t = 0; t < 5; ++t) {
-        const int idx = lane + 64 * t;
-        const int rr = idx / 10, cc = idx - rr * 10;
-        const int m = mrow0 + rr;
-        if (m >= p.M) continue;
-        const int n = n0 + wn * 80 + cc * 8;
-        float v[8];
-#pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = Es[rr * EP_LD + cc * 8 + e] + (float)lb[t].e[e] + (float)lv[t].e[e];
-        if (p.act == PFD_ACT_GELU) {
-#pragma unroll
-          for (int e = 0; e < 8; ++e) v[e] = pfd_gelu(v[e]);
-        } else if (p.act == PFD_ACT_RELU) {
-#pragma unroll
-          for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
-        } else if (p.act == PFD_ACT_SILU) {
-#pragma unroll
-          for (int e = 0; e < 8; ++e) v[e] = pfd_silu(v[e]);
-        }
-        Pack16 o;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) o.e[e] = (half_t)(v[e] + (float)lr[t].e[e]);
-        *reinterpret_cast<uint4*>(p.C + (long)m * p.ldc + n) = o.u;
-      }
+      *reinterpret_cast<uint2*>(cp + j * 16) = o.u;
     }
   }
 }
@@ -375,7 +383,7 @@ __global__ __launch_bounds__(WAVES_M * 128) void gemm160_kernel(const G160Params
         for (int i = 0; i < WMB; ++i)
 #pragma unroll
           for (int j = 0; j < 5; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[i], bf[j], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[j], af[i], acc[i][j], 0, 0, 0);
       }
       if (++buf == NBUF) buf = 0;
     }
@@ -522,7 +530,7 @@ __global__ __launch_bounds__(512) void conv3x3_patch_kernel(const G160Params p) 
             for (int i = 0; i < WMB; ++i)
 #pragma unroll
               for (int j = 0; j < 5; ++j)
-                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[i], bf[j], acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[j], af[i], acc[i][j], 0, 0, 0);
           }
           __syncthreads();  // carries vmcnt(0)
           stage ^= 1;
