@@ -72,9 +72,10 @@ const char* pfd_last_error(void);
  *
  * Requirements: K % 64 == 0 (linear) or Cin % 64 == 0 (conv); lda/ldw % 8 == 0;
  * A, W 16-byte aligned.  M, N arbitrary (tails are masked).
- * PFD_ACT_GEGLU weight packing: when N % 160 == 0 (wide-tile kernel) every group of 40 outputs
- * stores its 40 x-rows then its 40 gate-rows (80 packed rows); otherwise (N % 128 == 0) every
- * group of 32 outputs stores 32 x-rows then 32 gate-rows.  bias is packed the same way.
+ * PFD_ACT_GEGLU weight packing: when N % 160 == 0 (wide-tile kernel) every PAIR of outputs
+ * stores its 2 x-rows then its 2 gate-rows (x0 x1 g0 g1 | x2 x3 g2 g3 | ...: the four accumulator
+ * columns one lane owns); otherwise (N % 128 == 0) every group of 32 outputs stores 32 x-rows then
+ * 32 gate-rows.  bias is packed the same way.
  * ---------------------------------------------------------------------------------- */
 typedef struct PfdGemmDesc {
   const void* A;

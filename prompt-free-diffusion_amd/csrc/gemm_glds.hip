@@ -21,10 +21,9 @@
 // (openaimodel.py:114) are pure address arithmetic.  K is walked tap-major / channel-minor with
 // counters (no integer division in the loop).
 //
-// Epilogue: each wave stages 32 x 80 fp32 results through its private LDS region and emits whole
-// 16-byte row segments: + bias + per-sample row vector (time embedding) -> activation (or GEGLU:
-// the packed weight keeps the 40 x-rows and 40 gate-rows of a wave's 40 outputs adjacent) ->
-// + residual -> fp16.
+// Epilogue: straight from the accumulators (operands are swapped in the MFMA so a lane owns 4 consecutive
+// output columns of one row): + bias + per-sample row vector (time embedding) -> activation (or GEGLU:
+// the packed weight stores x0 x1 g0 g1 | x2 x3 g2 g3 ..., a lane's four columns) -> + residual -> fp16.
 //
 // Algorithmic bytes / flops per launch: see pfd_prof_begin below (operands + result once; 2MNK).
 #include "pfd_common.h"
@@ -34,8 +33,6 @@ namespace {
 constexpr int BK = 64;
 constexpr int BN = 160;
 constexpr int ROWB = BK * 2;         // bytes per LDS row (128)
-constexpr int EP_LD = 84;            // floats per staged epilogue row (80 + 4 pad; 336 B = 21 x 16 B)
-constexpr int EP_WAVE_BYTES = 32 * EP_LD * 4;
 
 __device__ __attribute__((aligned(256))) half_t g_zero_page[128];  // zero-initialised: OOB source of the gather
 
@@ -68,16 +65,16 @@ __device__ __forceinline__ void glds16(const void* src, void* lds_dst) {
 // OUTPUT COLUMNS of ONE output row: row m = tile row (lane & 15), columns n = 4*(lane >> 4) + r.  Bias / row
 // vector / residual are 8-byte loads, the result is an 8-byte store, and nothing goes through LDS (the
 // row-major staging the natural layout needed cost 2 x 164 KB of LDS traffic per 256x160 tile -- as much as
-// two K steps, on problems that have 5 to 20 of them).  Only GEGLU, whose x / gate partners sit 40 columns
-// apart, still exchanges through the wave's private LDS region.
+// two K steps, on problems that have 5 to 20 of them).  GEGLU packs its weight rows so that a lane's four
+// columns are two (x, gate) pairs.
 // (Split-K keeps a separate reduce launch.  An in-kernel "last block to arrive reduces the slabs" variant
 //  was built and measured: with agent-scope fences the L2 write-back/invalidate per block took the UNet
 //  loop from 753 to 1046 ms; with sc1 / sc0+sc1 coherent slab accesses instead of fences, 685 -> 868 ms --
 //  the uncached slab round trip sits on the critical path of every tile's last block, while the reduce
 //  kernel streams the same data with 2048 blocks in ~11 us.)
 template <int WMB>
-__device__ __forceinline__ void epilogue160(const float4_t (&acc)[WMB][5], const G160Params& p, char* smem, int wave,
-                                            int lane, int m0, int n0, int wm, int wn, int split) {
+__device__ __forceinline__ void epilogue160(const float4_t (&acc)[WMB][5], const G160Params& p, int lane, int m0,
+                                            int n0, int wm, int wn, int split) {
   const int l15 = lane & 15, g = lane >> 4;
   const int mw = m0 + wm * WMB * 16 + l15;   // + i*16: this lane's output row in row-tile i
   const int nw = n0 + wn * 80 + 4 * g;       // + j*16: first of this lane's 4 columns in column-tile j
@@ -114,43 +111,29 @@ __device__ __forceinline__ void epilogue160(const float4_t (&acc)[WMB][5], const
   }
 
   if (p.act == PFD_ACT_GEGLU) {
-    // stage 32 x 80 fp32 per pass through the wave's private LDS region (the operand ring is dead by now)
-    float* Es = reinterpret_cast<float*>(smem + wave * EP_WAVE_BYTES);
+    // packed weight rows come in groups of four: x(2c), x(2c+1), gate(2c), gate(2c+1) -- exactly the four
+    // columns a lane owns, so out(2c..2c+1) = x * gelu(gate) needs no exchange; a lane stores 2 halves and
+    // the four lanes of a row cover 16 contiguous bytes of the [M, N/2] output
+    float bv[5][4];
 #pragma unroll
-    for (int h = 0; h < WMB / 2; ++h) {
+    for (int j = 0; j < 5; ++j) {
+      Pack8 b;
+      b.u = make_uint2(0, 0);
+      if (p.bias) b.u = *reinterpret_cast<const uint2*>(p.bias + nw + j * 16);
 #pragma unroll
-      for (int ii = 0; ii < 2; ++ii)
+      for (int r = 0; r < 4; ++r) bv[j][r] = (float)b.e[r];
+    }
 #pragma unroll
-        for (int j = 0; j < 5; ++j)
-          *reinterpret_cast<float4_t*>(Es + (ii * 16 + l15) * EP_LD + j * 16 + 4 * g) = acc[2 * h + ii][j];
-      const int mrow0 = m0 + wm * WMB * 16 + h * 32;
-      // loads first (all items), then math: one exposed latency per pass instead of one per item
-      Pack16 bx[3], bg[3];
+    for (int i = 0; i < WMB; ++i) {
+      const int m = mw + i * 16;
+      if (m >= p.M) continue;
+      half_t* cp = p.C + (long)m * p.ldc + (nw >> 1);
 #pragma unroll
-      for (int t = 0; t < 3; ++t) {
-        const int idx = lane + 64 * t;
-        const int rr = idx / 5, cc = idx - rr * 5;
-        const int nx = n0 + wn * 80 + cc * 8;  // packed-weight row of the x half; gate = +40
-        bx[t].u = bg[t].u = make_uint4(0, 0, 0, 0);
-        if (p.bias && idx < 160) {
-          bx[t].u = *reinterpret_cast<const uint4*>(p.bias + nx);
-          bg[t].u = *reinterpret_cast<const uint4*>(p.bias + nx + 40);
-        }
-      }
-#pragma unroll
-      for (int t = 0; t < 3; ++t) {
-        const int idx = lane + 64 * t;
-        const int rr = idx / 5, cc = idx - rr * 5;
-        const int m = mrow0 + rr;
-        if (idx >= 160 || m >= p.M) continue;
-        Pack16 o;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          const float xv = Es[rr * EP_LD + cc * 8 + e] + (float)bx[t].e[e];
-          const float gv = Es[rr * EP_LD + 40 + cc * 8 + e] + (float)bg[t].e[e];
-          o.e[e] = (half_t)(xv * pfd_gelu(gv));
-        }
-        *reinterpret_cast<uint4*>(p.C + (long)m * p.ldc + (n0 >> 1) + wn * 40 + cc * 8) = o.u;
+      for (int j = 0; j < 5; ++j) {
+        half2_t o;
+        o[0] = (half_t)((acc[i][j][0] + bv[j][0]) * pfd_gelu(acc[i][j][2] + bv[j][2]));
+        o[1] = (half_t)((acc[i][j][1] + bv[j][1]) * pfd_gelu(acc[i][j][3] + bv[j][3]));
+        *reinterpret_cast<half2_t*>(cp + j * 8) = o;
       }
     }
     return;
@@ -210,8 +193,7 @@ __global__ __launch_bounds__(WAVES_M * 128) void gemm160_kernel(const G160Params
   constexpr int DEPTH = NBUF - 1;  // K tiles in flight ahead of the one being consumed
   static_assert(NBUF == 2 || B_INSTR % NW == 0, "counted vmcnt needs the same DMA count in every wave");
   static_assert(MAIN_BYTES <= 160 * 1024, "operand ring exceeds the 160 KiB LDS");
-  constexpr int EPI_BYTES = NW * EP_WAVE_BYTES;
-  constexpr int SMEM = MAIN_BYTES > EPI_BYTES ? MAIN_BYTES : EPI_BYTES;
+  constexpr int SMEM = MAIN_BYTES;
   static_assert(A_INSTR % NW == 0, "A tile must split evenly over the waves");
   __shared__ __attribute__((aligned(1024))) char smem[SMEM];
 
@@ -390,7 +372,7 @@ __global__ __launch_bounds__(WAVES_M * 128) void gemm160_kernel(const G160Params
     __syncthreads();  // the epilogue reuses the ring as staging space
   }
 
-  epilogue160<WMB>(acc, p, smem, wave, lane, m0, n0, wm, wn, split);
+  epilogue160<WMB>(acc, p, lane, m0, n0, wm, wn, split);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -412,8 +394,7 @@ __global__ __launch_bounds__(512) void conv3x3_patch_kernel(const G160Params p) 
   constexpr int WT_BYTES = BN * ROWB;             // 20480
   constexpr int OFF_W = 2 * PATCH_BYTES;
   constexpr int MAIN_BYTES = OFF_W + 2 * WT_BYTES;  // 143360
-  constexpr int EPI_BYTES = NW * EP_WAVE_BYTES;
-  constexpr int SMEM = MAIN_BYTES > EPI_BYTES ? MAIN_BYTES : EPI_BYTES;
+  constexpr int SMEM = MAIN_BYTES;
   constexpr int P_INSTR = PATCH_ROWS / 8;   // 50 DMA instructions per patch
   constexpr int P_SLOTS = (P_INSTR + NW - 1) / NW;  // 7 per wave
   __shared__ __attribute__((aligned(1024))) char smem[SMEM];
@@ -540,7 +521,7 @@ __global__ __launch_bounds__(512) void conv3x3_patch_kernel(const G160Params p) 
       }
     }
   }
-  epilogue160<WMB>(acc, p, smem, wave, lane, m0, n0, wm, wn, split);
+  epilogue160<WMB>(acc, p, lane, m0, n0, wm, wn, split);
 }
 
 // sum the split-K slabs and apply the epilogue (bias, row vector, activation, residual)

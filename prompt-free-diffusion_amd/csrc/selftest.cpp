@@ -200,7 +200,7 @@ static void run_gemm_case(const GemmCase& c) {
     for (int n = 0; n < (c.n_split > 0 ? c.n_split : Nout); ++n) {
       double v;
       if (c.act == PFD_ACT_GEGLU) {
-        const int gr = (N % 160 == 0) ? 40 : 32;  // packing granularity of the kernel that serves this N
+        const int gr = (N % 160 == 0) ? 2 : 32;  // packing granularity of the kernel that serves this N
         const int blk = n / gr, j = n % gr;
         const double x = pre[(size_t)m * N + blk * 2 * gr + j], g = pre[(size_t)m * N + blk * 2 * gr + gr + j];
         v = x * act_ref(g, PFD_ACT_GELU);

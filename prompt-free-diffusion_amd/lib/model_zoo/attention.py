@@ -105,8 +105,8 @@ def as_context_kv(context):
 
 class GEGLU(nn.Module, L._Packed):
     """proj: Linear(dim_in, 2*dim_out); y = x * gelu(gate).  The packed weight interleaves x/gate
-    rows (blocks of 40 for the wide-tile kernel, 32 otherwise) so both halves of an output column
-    sit in one GEMM tile."""
+    rows (pairs for the wide-tile kernel: x0 x1 g0 g1 | x2 x3 g2 g3 ... = the four columns one lane of
+    its accumulator owns; blocks of 32 otherwise) so both halves of an output column meet in the epilogue."""
 
     def __init__(self, dim_in, dim_out):
         super().__init__()
@@ -118,7 +118,7 @@ class GEGLU(nn.Module, L._Packed):
             n = self.dim_out
             w = L._dev16(self.proj.weight)
             b = L._dev16(self.proj.bias)
-            gr = 40 if (2 * n) % 160 == 0 else 32  # packing granularity of the kernel serving this N (pfd_hip.h)
+            gr = 2 if (2 * n) % 160 == 0 else 32  # packing granularity of the kernel serving this N (pfd_hip.h)
             wi = torch.stack([w[:n].view(n // gr, gr, -1), w[n:].view(n // gr, gr, -1)], 1).reshape(2 * n, -1)
             bi = torch.stack([b[:n].view(n // gr, gr), b[n:].view(n // gr, gr)], 1).reshape(2 * n)
             return wi.contiguous(), bi.contiguous()
