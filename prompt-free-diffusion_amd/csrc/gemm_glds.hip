@@ -670,14 +670,16 @@ int pfd_gemm160_try(const PfdGemmDesc* d, int variant, int splits, hipStream_t s
   const bool auto_variant = variant == 0;
   const int nk_all = p.K / BK;
   if (auto_variant) {
-    // measured on MI355X with COLD weights (the 1.7 GB of other layers evict every W between two uses;
-    // profiles/r01_gemm_cold_cache.log): the 256x160 tile when it fills the chip; two K halves of it for
-    // long-K problems with ~128 tiles; short K (<= 24 tiles of 64) is bound by the per-barrier DMA round
-    // trip, so it wants as many small blocks as possible (64x160); otherwise 128x160 tiles + split-K.
-    if (tiles(256) >= 200) variant = 44;
-    else if (tiles(256) >= 96 && nk_all >= 48) variant = 44;
-    else if (nk_all <= 24) variant = 22;
-    else variant = 24;
+    // measured on MI355X: every GEMM/conv of a UNet pass replayed with COLD weights (the 1.7 GB of other
+    // layers evict every W between two uses) under each forced variant (profiles/r01_gemm_replay_variants.log),
+    // then A/B-ed end to end in one job: 256x160 when its tiles fill the chip; otherwise 128x160 (two
+    // co-resident 4-wave blocks, + split-K when there are < 256 of them) -- except problems with a short K
+    // loop and too few 128-row tiles to fill the chip twice, which take 64x160 (8192x640x640: 24 -> 20 us).
+    // (In the cold replay 128x160 also beat 256x160 on the big problems -- GEGLU 99 -> 93 us -- but inside
+    //  the real loop it lost: 664 vs 661 ms per batch.)
+    const long t128 = tiles(128);
+    const bool few = nk_all >= 16 ? t128 < 256 : t128 < 384;
+    variant = tiles(256) >= 200 ? 44 : (nk_all <= 24 && few) ? 22 : 24;
   }
   const int bm = variant == 44 ? 256 : (variant == 24 || variant == 26) ? 128 : 64;
   if (splits == 0) {
@@ -691,6 +693,10 @@ int pfd_gemm160_try(const PfdGemmDesc* d, int variant, int splits, hipStream_t s
       splits = (int)((512 + tl - 1) / tl);
       if (splits > 8) splits = 8;
       while (splits > 1 && nk / splits < 16) --splits;  // the slab round trip must stay small vs the K loop
+      while (splits > 1 && (size_t)splits * p.M * p.N * 4 > d->ws_bytes) --splits;
+    } else if (p.act != PFD_ACT_GEGLU && d->ws && variant == 22 && tl <= 128 && nk >= 16) {
+      splits = (int)(256 / tl);   // M <= 1024 rows (8^2 level, cond-half projections): 25 -> 21 us
+      if (splits > 4) splits = 4;
       while (splits > 1 && (size_t)splits * p.M * p.N * 4 > d->ws_bytes) --splits;
     }
   }
