@@ -843,9 +843,9 @@ int main(int argc, char** argv) {
     run_ln_case(10, 1280, 0, 0, 0, 0);
     run_ln_case(5, 3072, 0, 0, 0, 0);
     run_ln_case(2 * 4 * 3, 4 * 96, 1, 2, 7, 5);
-    run_ln_case(2051, 320, 0, 0, 0, 0);    // multi-row form (M >= 2048), ragged last wave
-    run_ln_case(2048, 640, 0, 0, 0, 0);
-    run_ln_case(2049, 1280, 0, 0, 0, 0);
+    run_ln_case(8195, 320, 0, 0, 0, 0);    // multi-row form (M >= 8192), ragged last wave
+    run_ln_case(8192, 640, 0, 0, 0, 0);
+    run_ln_case(8193, 1280, 0, 0, 0, 0);
     run_softmax_case(5, 4096, 0.044f);
     run_softmax_case(3, 1152, 0.1f);
     run_softmax_case(2, 36864, 0.044f);   // long-row form (N > 16384)
