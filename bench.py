@@ -107,7 +107,7 @@ def main():
             torch.nn.init.normal_(pe.mlp[-1].weight, std=768 ** -0.5)
             net.ctx['image'].qtransformer.pe_layer = pe.half().to(f'cuda:{local}')
     pipe = PromptFreePipeline(net, rank=rank, world_size=world)
-    pipe.sampler.enable_graph(not args.no_graph)
+    pipe.enable_graph(not args.no_graph)
     image = torch.rand((1, 3, args.height, args.width), generator=torch.Generator().manual_seed(1234))
     n_global = args.batch * world
     gen = torch.Generator().manual_seed(4321)
@@ -150,12 +150,12 @@ def main():
     elif not args.no_prof and rank == 0:
         # the timed region replayed a hipGraph; time the same kernels on one more, eagerly launched,
         # instrumented batch (identical kernels, shapes and data path; not part of `value`)
-        pipe.sampler.enable_graph(False)
+        pipe.enable_graph(False)
         binding.prof_enable(True)
         step(999, gather=False)   # rank-0 only: must not enter the collective
         torch.cuda.synchronize()
         prof, prof_steps, prof_where = binding.prof_read(), 1, "instrumented eager replica of one timed step"
-        pipe.sampler.enable_graph(True)
+        pipe.enable_graph(True)
     binding.prof_enable(False)
     if rank == 0:   # per-stage split of one more (graph-replayed) batch, outside the timed region
         step(998, gather=False, timings=stage_ms)

@@ -289,6 +289,21 @@ def test_hipgraph_replay_matches_eager(net, golden):
     assert len(graphed._graphs) == 1
 
 
+def test_pipeline_graphed_stages_match_eager(net, golden):
+    """PromptFreePipeline with all three stages replayed as hipGraphs == the eager pipeline, bit for bit,
+    across repeated requests and a different seed"""
+    from lib.pipeline import PromptFreePipeline
+    img = T(golden["see.img"])
+    eager, graphed = PromptFreePipeline(net), PromptFreePipeline(net)
+    graphed.enable_graph(True)
+    for seed in (5, 6, 5):
+        ie, xe = eager.generate(img, 2, 64, 64, steps=4, scale=2.0, seed=seed)
+        ig, xg = graphed.generate(img, 2, 64, 64, steps=4, scale=2.0, seed=seed)
+        assert torch.equal(xe, xg) and torch.equal(ie, ig), seed
+    assert graphed._ctx_stage is not None and not graphed._ctx_stage.broken and len(graphed._ctx_stage.graphs) == 1
+    assert not graphed._vae_stage.broken and len(graphed._vae_stage.graphs) == 1
+
+
 def test_zero_uncond_shortcut_is_exact(net, golden):
     """skipping cross-attention for the all-zero unconditional context must be bit-identical"""
     from lib.model_zoo.ddim import DDIMSampler
