@@ -327,6 +327,19 @@ def test_full_size_properties(net):
     assert rel <= 5e-3
 
 
+@pytest.mark.parametrize("h,w", [(1536, 512), (768, 1024), (1536, 1536)])
+def test_tall_and_wide_resolutions(net, h, w):
+    """app.py:197-207 lets the output be anything in [512, 1536]^2 (multiples of 64): non-square latents,
+    UNet self-attention over up to 36 864 tokens, VAE mid attention beyond the 16 384-token register form,
+    convolutions on image widths the patch kernel does not take"""
+    from lib.pipeline import PromptFreePipeline
+    img = torch.rand((1, 3, h, w), generator=torch.Generator().manual_seed(1))
+    im, x = PromptFreePipeline(net).generate(img, 1, h, w, steps=2, scale=2.0, seed=3)
+    assert im.shape == (1, 3, h, w) and x.shape == (1, 4, h // 8, w // 8)
+    assert torch.isfinite(im).all() and torch.isfinite(x).all()
+    assert float(im.min()) >= 0.0 and float(im.max()) <= 1.0 and float(im.float().std()) > 1e-3
+
+
 def test_zero_uncond_shortcut_is_exact(net, golden):
     """skipping cross-attention for the all-zero unconditional context must be bit-identical"""
     from lib.model_zoo.ddim import DDIMSampler
