@@ -71,7 +71,9 @@ const char* pfd_last_error(void);
  * GEGLU (attention.py:49-51).
  *
  * Requirements: K % 64 == 0 (linear) or Cin % 64 == 0 (conv); lda/ldw % 8 == 0;
- * A, W 16-byte aligned.  M, N arbitrary (tails are masked).
+ * A, W 16-byte aligned.  M, N arbitrary (tails are masked).  N % 160 == 0 or N % 128 == 0 is
+ * served by the LDS-DMA wide-tile kernels (160- / 128-wide tiles), anything else by the
+ * register-staged 128x128 kernel.
  * PFD_ACT_GEGLU weight packing: when N % 160 == 0 (wide-tile kernel) every PAIR of outputs
  * stores its 2 x-rows then its 2 gate-rows (x0 x1 g0 g1 | x2 x3 g2 g3 | ...: the four accumulator
  * columns one lane owns); otherwise (N % 128 == 0) every group of 32 outputs stores 32 x-rows then
@@ -101,8 +103,9 @@ typedef struct PfdGemmDesc {
    * written to C but, transposed, to Ct[(n - n_split) * ldct + m] (+ bias[n] only).  This is how the
    * self-attention q | k | v projection (attention.py:169-176) is ONE launch over the shared
    * activation: q | k land token-major in C, v lands as the V^T [inner, tokens] operand
-   * pfd_attention_f16 consumes.  Wide-tile path only: plain GEMM (ksize == 0), N % 160 == 0,
-   * n_split % 160 == 0, ldct % 8 == 0, Ct 16-byte aligned, act == NONE, rowvec == R == NULL,
+   * pfd_attention_f16 consumes.  Wide-tile path only: plain GEMM (ksize == 0), N a multiple of the
+   * tile width T (160 if N % 160 == 0, else 128 if N % 128 == 0), n_split % T == 0,
+   * ldct % 8 == 0, Ct 16-byte aligned, act == NONE, rowvec == R == NULL,
    * bias_per_row == 0; anything else is PFD_ESHAPE (there is no slow path behind it). */
   void* Ct;
   int64_t ldct;

@@ -73,12 +73,12 @@ __device__ __forceinline__ void glds16(const void* src, void* lds_dst) {
 //  loop from 753 to 1046 ms; with sc1 / sc0+sc1 coherent slab accesses instead of fences, 685 -> 868 ms --
 //  the uncached slab round trip sits on the critical path of every tile's last block, while the reduce
 //  kernel streams the same data with 2048 blocks in ~11 us.)
-template <int WMB>
-__device__ __forceinline__ void epilogue160(const float4_t (&acc)[WMB][5], const G160Params& p, int lane, int m0,
+template <int WMB, int NT>
+__device__ __forceinline__ void epilogue160(const float4_t (&acc)[WMB][NT], const G160Params& p, int lane, int m0,
                                             int n0, int wm, int wn, int split) {
   const int l15 = lane & 15, g = lane >> 4;
   const int mw = m0 + wm * WMB * 16 + l15;   // + i*16: this lane's output row in row-tile i
-  const int nw = n0 + wn * 80 + 4 * g;       // + j*16: first of this lane's 4 columns in column-tile j
+  const int nw = n0 + wn * (16 * NT) + 4 * g;       // + j*16: first of this lane's 4 columns in column-tile j
 
   if (p.splits > 1) {  // split-K: raw fp32 partials, [split][M][N]
 #pragma unroll
@@ -86,16 +86,16 @@ __device__ __forceinline__ void epilogue160(const float4_t (&acc)[WMB][5], const
       const int m = mw + i * 16;
       if (m >= p.M) continue;
 #pragma unroll
-      for (int j = 0; j < 5; ++j)
+      for (int j = 0; j < NT; ++j)
         *reinterpret_cast<float4_t*>(p.ws + ((long)split * p.M + m) * p.N + nw + j * 16) = acc[i][j];
     }
     return;
   }
 
   if (p.Ct && n0 >= p.n_split) {  // transposed tail (tile-uniform): Ct[(n - n_split) * ldct + m] (+ bias)
-    float bv[5][4];
+    float bv[NT][4];
 #pragma unroll
-    for (int j = 0; j < 5; ++j)
+    for (int j = 0; j < NT; ++j)
 #pragma unroll
       for (int r = 0; r < 4; ++r) bv[j][r] = p.bias ? (float)p.bias[nw + j * 16 + r] : 0.f;
 #pragma unroll
@@ -103,7 +103,7 @@ __device__ __forceinline__ void epilogue160(const float4_t (&acc)[WMB][5], const
       const int m = mw + i * 16;
       if (m >= p.M) continue;
 #pragma unroll
-      for (int j = 0; j < 5; ++j)
+      for (int j = 0; j < NT; ++j)
 #pragma unroll
         for (int r = 0; r < 4; ++r)   // 16 lanes = 16 consecutive m: 32-byte segments per output row
           p.Ct[(long)(nw + j * 16 + r - p.n_split) * p.ldct + m] = (half_t)(acc[i][j][r] + bv[j][r]);
@@ -115,9 +115,9 @@ __device__ __forceinline__ void epilogue160(const float4_t (&acc)[WMB][5], const
     // packed weight rows come in groups of four: x(2c), x(2c+1), gate(2c), gate(2c+1) -- exactly the four
     // columns a lane owns, so out(2c..2c+1) = x * gelu(gate) needs no exchange; a lane stores 2 halves and
     // the four lanes of a row cover 16 contiguous bytes of the [M, N/2] output
-    float bv[5][4];
+    float bv[NT][4];
 #pragma unroll
-    for (int j = 0; j < 5; ++j) {
+    for (int j = 0; j < NT; ++j) {
       Pack8 b;
       b.u = make_uint2(0, 0);
       if (p.bias) b.u = *reinterpret_cast<const uint2*>(p.bias + nw + j * 16);
@@ -130,7 +130,7 @@ __device__ __forceinline__ void epilogue160(const float4_t (&acc)[WMB][5], const
       if (m >= p.M) continue;
       half_t* cp = p.C + (long)m * p.ldc + (nw >> 1);
 #pragma unroll
-      for (int j = 0; j < 5; ++j) {
+      for (int j = 0; j < NT; ++j) {
         half2_t o;
         o[0] = (half_t)((acc[i][j][0] + bv[j][0]) * pfd_gelu(acc[i][j][2] + bv[j][2]));
         o[1] = (half_t)((acc[i][j][1] + bv[j][1]) * pfd_gelu(acc[i][j][3] + bv[j][3]));
@@ -141,9 +141,9 @@ __device__ __forceinline__ void epilogue160(const float4_t (&acc)[WMB][5], const
   }
 
   // ---- bias + per-sample row vector -> activation -> + residual -> fp16, straight from the accumulators ----
-  float bv[5][4];
+  float bv[NT][4];
 #pragma unroll
-  for (int j = 0; j < 5; ++j) {
+  for (int j = 0; j < NT; ++j) {
     Pack8 b;
     b.u = make_uint2(0, 0);
     if (p.bias) b.u = *reinterpret_cast<const uint2*>(p.bias + nw + j * 16);
@@ -154,18 +154,18 @@ __device__ __forceinline__ void epilogue160(const float4_t (&acc)[WMB][5], const
   for (int i = 0; i < WMB; ++i) {
     const int m = mw + i * 16;
     if (m >= p.M) continue;
-    Pack8 lv[5], lr[5];
+    Pack8 lv[NT], lr[NT];
     const half_t* rvp = p.rowvec ? p.rowvec + (long)(m / p.rows_per_rv) * p.ldrv + nw : nullptr;
     const half_t* rp = p.R ? p.R + (long)m * p.ldr + nw : nullptr;
 #pragma unroll
-    for (int j = 0; j < 5; ++j) {   // all loads of the row first: one exposed latency per row tile
+    for (int j = 0; j < NT; ++j) {   // all loads of the row first: one exposed latency per row tile
       lv[j].u = lr[j].u = make_uint2(0, 0);
       if (rvp) lv[j].u = *reinterpret_cast<const uint2*>(rvp + j * 16);
       if (rp) lr[j].u = *reinterpret_cast<const uint2*>(rp + j * 16);
     }
     half_t* cp = p.C + (long)m * p.ldc + nw;
 #pragma unroll
-    for (int j = 0; j < 5; ++j) {
+    for (int j = 0; j < NT; ++j) {
       Pack8 o;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
@@ -180,13 +180,13 @@ __device__ __forceinline__ void epilogue160(const float4_t (&acc)[WMB][5], const
   }
 }
 
-template <int WAVES_M, int WMB, bool CONV, int NBUF>
+template <int WAVES_M, int WMB, bool CONV, int NBUF, int NT>
 __global__ __launch_bounds__(WAVES_M * 128) void gemm160_kernel(const G160Params p) {
+  constexpr int BN = 32 * NT;   // 160 (every UNet / ControlNet width) or 128 (VAE, Swin, SeeCoder widths)
   constexpr int NW = WAVES_M * 2;
-  constexpr int NT = NW * 64;
   constexpr int BM = WAVES_M * WMB * 16;
   constexpr int A_INSTR = BM / 8;                  // wave-instructions per A tile
-  constexpr int B_INSTR = BN / 8;                  // 20
+  constexpr int B_INSTR = BN / 8;                  // 20 / 16
   constexpr int A_PER_WAVE = A_INSTR / NW;         // 4, 4, 2
   constexpr int B_PER_WAVE = (B_INSTR + NW - 1) / NW;
   constexpr int STAGE = (BM + BN) * ROWB;
@@ -316,18 +316,18 @@ __global__ __launch_bounds__(WAVES_M * 128) void gemm160_kernel(const G160Params
     }
   };
 
-  float4_t acc[WMB][5];
+  float4_t acc[WMB][NT];
 #pragma unroll
   for (int i = 0; i < WMB; ++i)
 #pragma unroll
-    for (int j = 0; j < 5; ++j) acc[i][j] = (float4_t){0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < NT; ++j) acc[i][j] = (float4_t){0.f, 0.f, 0.f, 0.f};
 
   // fragment read offsets (bytes): row (.. + l15), chunk (ks*4 + g) ^ ((l15 >> 1) & 7)
   const int sw = (l15 >> 1) & 7;
   const int off_k0 = ((0 + g) ^ sw) * 16 + l15 * ROWB;
   const int off_k1 = ((4 + g) ^ sw) * 16 + l15 * ROWB;
   const int a_row0 = wm * WMB * 16 * ROWB;
-  const int b_row0 = BM * ROWB + wn * 80 * ROWB;
+  const int b_row0 = BM * ROWB + wn * (16 * NT) * ROWB;
 
   // (Also A/B-tested and dropped: the same 256x160 tile as 4 waves of 128x80 -- 28 % fewer LDS fragment
   //  bytes per MFMA but one wave per SIMD, so nothing covers the ds_read latency: conv 32^2 106 -> 163 us,
@@ -359,17 +359,17 @@ __global__ __launch_bounds__(WAVES_M * 128) void gemm160_kernel(const G160Params
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) {
         const int off = ks ? off_k1 : off_k0;
-        half8_t af[WMB], bf[5];
+        half8_t af[WMB], bf[NT];
 #pragma unroll
         for (int i = 0; i < WMB; ++i)
           af[i] = *reinterpret_cast<const half8_t*>(base + a_row0 + i * 16 * ROWB + off);
 #pragma unroll
-        for (int j = 0; j < 5; ++j)
+        for (int j = 0; j < NT; ++j)
           bf[j] = *reinterpret_cast<const half8_t*>(base + b_row0 + j * 16 * ROWB + off);
 #pragma unroll
         for (int i = 0; i < WMB; ++i)
 #pragma unroll
-          for (int j = 0; j < 5; ++j)
+          for (int j = 0; j < NT; ++j)
             acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[j], af[i], acc[i][j], 0, 0, 0);
       }
       if (++buf == NBUF) buf = 0;
@@ -377,7 +377,7 @@ __global__ __launch_bounds__(WAVES_M * 128) void gemm160_kernel(const G160Params
     __syncthreads();  // the epilogue reuses the ring as staging space
   }
 
-  epilogue160<WMB>(acc, p, lane, m0, n0, wm, wn, split);
+  epilogue160<WMB, NT>(acc, p, lane, m0, n0, wm, wn, split);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -530,7 +530,7 @@ __global__ __launch_bounds__(512) void conv3x3_patch_kernel(const G160Params p) 
       }
     }
   }
-  epilogue160<WMB>(acc, p, lane, m0, n0, wm, wn, split);
+  epilogue160<WMB, 5>(acc, p, lane, m0, n0, wm, wn, split);
 }
 
 // sum the split-K slabs and apply the epilogue (bias, row vector, activation, residual)
@@ -579,11 +579,11 @@ inline int pick_nmajor(const G160Params& p) {
   return (p.tiles_n >= 2 && p.tiles_m >= 2 && w_bytes > a_bytes) ? 1 : 0;
 }
 
-template <int WAVES_M, int WMB, int NBUF = 2>
+template <int WAVES_M, int WMB, int NBUF = 2, int NT = 5>
 int launch160(G160Params& p, int bucket, hipStream_t s) {
   constexpr int BM = WAVES_M * WMB * 16;
   p.tiles_m = (p.M + BM - 1) / BM;
-  p.tiles_n = p.N / BN;
+  p.tiles_n = p.N / (32 * NT);
   p.nmajor = pick_nmajor(p);
   const int nk = p.K / BK;
   p.kt_per_split = (nk + p.splits - 1) / p.splits;
@@ -596,9 +596,9 @@ int launch160(G160Params& p, int bucket, hipStream_t s) {
     pfd_prof_begin(bucket, 2.0 * p.M * p.N * p.K, a_bytes + 2.0 * p.N * p.K + 2.0 * p.M * n_out * (p.R ? 2 : 1), s);
   }
   if (p.ksize > 0)
-    hipLaunchKernelGGL((gemm160_kernel<WAVES_M, WMB, true, NBUF>), grid, dim3(WAVES_M * 128), 0, s, p);
+    hipLaunchKernelGGL((gemm160_kernel<WAVES_M, WMB, true, NBUF, NT>), grid, dim3(WAVES_M * 128), 0, s, p);
   else
-    hipLaunchKernelGGL((gemm160_kernel<WAVES_M, WMB, false, NBUF>), grid, dim3(WAVES_M * 128), 0, s, p);
+    hipLaunchKernelGGL((gemm160_kernel<WAVES_M, WMB, false, NBUF, NT>), grid, dim3(WAVES_M * 128), 0, s, p);
   if (p.splits > 1) {
     const long nvec = (long)p.M * (p.N / 8);
     int g = (int)((nvec + 255) / 256);
@@ -636,8 +636,12 @@ int launch_patch(G160Params& p, hipStream_t s) {
 
 // Called by pfd_gemm_f16_ex (gemm_conv.hip).  Returns 1 if the problem is not for this path.
 // variant: 0 = heuristic, 44 / 24 / 22 force <WAVES_M,WMB>; splits: 0 = heuristic.
+// N % 160 == 0 runs 160-wide tiles (every UNet / ControlNet width); otherwise N % 128 == 0 runs the same
+// kernel with 128-wide tiles (wave tile x 64: the VAE's 128/256/512 channels, Swin / SeeCoder widths).
 int pfd_gemm160_try(const PfdGemmDesc* d, int variant, int splits, hipStream_t s) {
-  if (d->N % BN || d->bias_per_row || d->K % BK) return 1;
+  const int bn = d->N % 160 == 0 ? 160 : 128;
+  if (d->N % bn || d->bias_per_row || d->K % BK) return 1;
+  if (bn == 128 && d->act == PFD_ACT_GEGLU) return 1;   // GEGLU packing is defined per serving kernel (pfd_hip.h)
   if (d->ksize > 0 && (d->Cin % BK)) return 1;
   if (d->act == PFD_ACT_GEGLU && (d->rowvec || d->R)) return 1;
   if ((d->ldc & 7) || (reinterpret_cast<uintptr_t>(d->C) & 15)) return 1;
@@ -645,7 +649,7 @@ int pfd_gemm160_try(const PfdGemmDesc* d, int variant, int splits, hipStream_t s
   if (d->R && ((d->ldr & 7) || (reinterpret_cast<uintptr_t>(d->R) & 15))) return 1;
   if (d->rowvec && ((d->ldrv & 7) || (reinterpret_cast<uintptr_t>(d->rowvec) & 15))) return 1;
   if (d->Ct) {  // transposed tail: validated by the caller to be a plain, epilogue-free GEMM
-    if (d->ksize > 0 || d->n_split <= 0 || d->n_split >= d->N || d->n_split % BN || (d->ldct & 7) ||
+    if (d->ksize > 0 || d->n_split <= 0 || d->n_split >= d->N || d->n_split % bn || (d->ldct & 7) ||
         (reinterpret_cast<uintptr_t>(d->Ct) & 15))
       return 1;
     splits = 1;
@@ -663,10 +667,10 @@ int pfd_gemm160_try(const PfdGemmDesc* d, int variant, int splits, hipStream_t s
   p.B = d->B; p.H = d->H; p.Wd = d->Wd; p.Cin = d->Cin; p.Ho = d->Ho; p.Wo = d->Wo;
   p.tiles_m = p.tiles_n = 0;
   p.kt_per_split = 0;
-  const int tn = p.N / BN;
+  const int tn = p.N / bn;
   auto tiles = [&](int bm) { return (long)((p.M + bm - 1) / bm) * tn; };
   // 3x3 / s1 / p1 convolution on a 16-, 32- or 64-wide image: the patch kernel (variant 0 or 99)
-  if ((variant == 0 || variant == 99) && p.ksize == 3 && p.stride == 1 && p.pad == 1 && !p.ups &&
+  if (bn == 160 && (variant == 0 || variant == 99) && p.ksize == 3 && p.stride == 1 && p.pad == 1 && !p.ups &&
       (p.Wd == 16 || p.Wd == 32 || p.Wd == 64) && p.Ho == p.H && p.Wo == p.Wd && p.H % (256 / p.Wd) == 0 &&
       p.M % 256 == 0 && p.act != PFD_ACT_GEGLU) {
     const int ncb = p.Cin / BK;
@@ -721,6 +725,14 @@ int pfd_gemm160_try(const PfdGemmDesc* d, int variant, int splits, hipStream_t s
   if (splits > 1 && (!d->ws || (size_t)splits * p.M * p.N * 4 > d->ws_bytes || p.act == PFD_ACT_GEGLU)) splits = 1;
   p.splits = splits;
   const int conv = p.ksize > 0 ? 1 : 0;
+  if (bn == 128) {
+    switch (variant) {
+      case 44: return launch160<4, 4, 2, 4>(p, 12 + 4 * conv, s) < 0 ? PFD_ELAUNCH : 0;
+      case 24: return launch160<2, 4, 2, 4>(p, 13 + 4 * conv, s) < 0 ? PFD_ELAUNCH : 0;
+      case 22: return launch160<2, 2, 2, 4>(p, 14 + 4 * conv, s) < 0 ? PFD_ELAUNCH : 0;
+      default: return variant == 99 ? 1 : PFD_EINVAL;
+    }
+  }
   switch (variant) {
     case 44: return launch160<4, 4>(p, 12 + 4 * conv, s) < 0 ? PFD_ELAUNCH : 0;
     case 24: return launch160<2, 4>(p, 13 + 4 * conv, s) < 0 ? PFD_ELAUNCH : 0;

@@ -794,6 +794,17 @@ int main(int argc, char** argv) {
     run_gemm_case({520, 160, 1024, PFD_ACT_GELU, true, true, true, false, 3204});   // 64x160 tiles, split-K 4
     run_gemm_case({130, 320, 2048, 0, true, true, false, false, 5403});             // 256x160, split-K 3
     run_gemm_case({200, 320, 128, PFD_ACT_GEGLU, true, false, false, false, 0});     // GEGLU, 40-row packing
+    // 128-wide tiles of the wide kernel (N % 128 == 0, N % 160 != 0: VAE / Swin / SeeCoder widths)
+    run_gemm_case({300, 256, 192, PFD_ACT_SILU, true, true, true, false, 5400});
+    run_gemm_case({77, 128, 64, 0, true, false, false, false, 3400, 8});
+    run_gemm_case({130, 384, 320, PFD_ACT_GELU, true, true, false, false, 3200});
+    run_gemm_case({520, 256, 2048, 0, true, true, false, false, 3404});
+    run_gemm_case({0, 256, 0, PFD_ACT_SILU, true, true, true, false, 0, 0, 3, 1, 1, 0, 2, 9, 7, 128});
+    run_gemm_case({0, 128, 0, 0, true, false, false, false, 5400, 0, 3, 1, 1, 1, 1, 5, 6, 128});   // upsample
+    run_gemm_case({0, 512, 0, 0, true, false, false, false, 0, 0, 3, 2, 0, 0, 1, 9, 9, 64});       // stride 2, pad 0
+    {
+      GemmCase t{200, 384, 128, 0, true, false, false, false, 0}; t.n_split = 256; run_gemm_case(t);
+    }
     // transposed tail (fused q|k|v projection): all three tile heights, ragged M, bias
     {
       GemmCase t{520, 480, 128, 0, false, false, false, false, 0}; t.n_split = 320; run_gemm_case(t);

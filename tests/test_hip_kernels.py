@@ -56,8 +56,11 @@ def test_gemm_transposed_tail_and_fused_qkv(M, C, K):
     close(qk, ref[:, :2 * C])
     close(vt[:, :M], ref[:, 2 * C:].t())
     assert float(vt[:, M:].abs().max()) == 0.0          # pad columns untouched
-    with pytest.raises(Exception):                       # no slow path behind it: N % 160 != 0 is loud
-        ops.gemm(a, w[:3 * 128], out_t=vt[:128, :M], n_split=256)
+    with pytest.raises(Exception):                       # no slow path behind it: N % 160 and N % 128 != 0 is loud
+        ops.gemm(a, w[:3 * 96], out_t=vt[:96, :M], n_split=192)
+    qk2 = ops.gemm(a, w[:3 * 128], out_t=vt[:128, :M], n_split=256)   # 128-wide tiles serve N % 128 == 0
+    close(qk2, (a.float() @ w[:3 * 128].float().t())[:, :256])
+    close(vt[:128, :M], (a.float() @ w[256:384].float().t()).t())
 
 
 def test_self_attention_fused_projection_matches_split_path():
