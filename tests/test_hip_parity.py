@@ -304,6 +304,32 @@ def test_pipeline_graphed_stages_match_eager(net, golden):
     assert not graphed._vae_stage.broken and len(graphed._vae_stage.graphs) == 1
 
 
+def test_config_c1_end_to_end_vs_oracle(net, param_shapes):
+    """BASELINE config C1 (256x256, 10-step DDIM, batch 1 -- the reference's own CPU-runnable case), whole
+    pipeline: SeeCoder context -> 10 CFG steps -> VAE decode, HIP path vs the CPU oracle run on this host on
+    the same seeded weights, reference image and x_T."""
+    import pfd_oracle as O
+    from lib.pipeline import PromptFreePipeline, shard_xT
+    torch.set_num_threads(max(1, min(64, torch.get_num_threads())))
+    img = torch.rand((1, 3, 256, 256), generator=torch.Generator().manual_seed(1234))
+    sd_c, sd_u, sd_v = (seeded_sd(param_shapes, p) for p in ("ctx.image.", "diffuser.image.", "vae.image."))
+    cond = O.seecoder_encode(sd_c, "ctx.image.", img)
+    acp = O.schedule_buffers()["alphas_cumprod"]
+    ts, a, ap, sg = O.ddim_tables(acp, 10, 0.0)
+    x = shard_xT(1, 256, 256, 20, 0, 1)
+    eps_fn = lambda xx, tt, cc: O.unet_apply(sd_u, "diffuser.image.", xx, tt, cc)  # noqa: E731
+    for i, step in enumerate(np.flip(ts)):
+        idx = len(ts) - i - 1
+        t = torch.full((1,), int(step), dtype=torch.long)
+        x, _ = O.ddim_step(eps_fn, x, t, cond, torch.zeros_like(cond), 2.0, float(a[idx]), float(ap[idx]), float(sg[idx]))
+    ref_img = O.vae_decode(sd_v, "vae.image.", x)
+    im, lat = PromptFreePipeline(net).generate(img, 1, 256, 256, steps=10, scale=2.0, seed=20)
+    rel = float((lat.double().cpu() - x.double()).norm() / x.double().norm())
+    print(f"[parity] C1 (256x256, 10 steps) latent rel-L2 {rel:.3e}, latent std {float(x.std()):.2f}")
+    assert rel <= 1e-2
+    check("C1 decoded image vs oracle", im, ref_img, 2e-2)
+
+
 def test_full_size_properties(net):
     """BASELINE config C2 shapes (512x512, batch 4 -> UNet batch 8, 64x64 latent), where the CPU oracle is out
     of reach: size-independent properties instead -- determinism, hipGraph == eager, batch invariance (sample 0
