@@ -115,9 +115,10 @@ typedef struct PfdGemmDesc {
 int pfd_gemm_f16(const PfdGemmDesc* d, pfd_stream_t stream);
 /* Same, with the kernel variant forced (tests and tuning only); 0 = the library's heuristic.
  *   tile in {22, 21, 12, 11}: register-staged kernel, (64*TM) x (64*TN) x 64 tile, tile = 10*TM+TN
- *   tile = 1000 + 10*v + s : LDS-DMA wide-tile kernel (needs N % 160 == 0), v in {44, 24, 22} =
- *          256x160 / 128x160 / 64x160 block tile (or 0), split-K factor s in 0..8 (0 = heuristic),
- *          encoded as 1000 + 100*v + s, e.g. 1000 + 4400 + 2 = 5402. */
+ *   tile = 1000 + 100*v + s : LDS-DMA wide-tile kernel (needs N % 160 == 0 or N % 128 == 0),
+ *          v in {44, 24, 22} = 256 / 128 / 64 rows x (160 | 128) columns block tile (0 = heuristic;
+ *          26, 27 = deeper operand rings of 24 / 22; 99 = the 3x3 patch kernel), split-K factor s in
+ *          0..8 (0 = heuristic), e.g. 1000 + 4400 + 2 = 5402. */
 int pfd_gemm_f16_ex(const PfdGemmDesc* d, int32_t tile, pfd_stream_t stream);
 
 /* ------------------------------------------------------------------------------------

@@ -1,11 +1,11 @@
-// pfd_gemm_f16, wide-tile path: linear / 1x1 / 3x3 implicit-GEMM convolution for N % 160 == 0
-// (every SD-v1.5 UNet / ControlNet width is a multiple of 320) on v_mfma_f32_16x16x32_f16.
+// pfd_gemm_f16, wide-tile path: linear / 1x1 / 3x3 implicit-GEMM convolution on v_mfma_f32_16x16x32_f16
+// for N % 160 == 0 (every SD-v1.5 UNet / ControlNet width is a multiple of 320; 160-wide tiles, NT = 5) or
+// N % 128 == 0 (VAE / Swin / SeeCoder widths; 128-wide tiles, NT = 4).
 //
-// Block tile BM x 160 x 64 with BM = WAVES_M * WMB * 16; waves laid out WAVES_M (M) x 2 (N); each
-// wave owns a (WMB*16) x 80 sub-tile = WMB x 5 MFMA tiles of 16x16 (fp32 accumulators in the
-// unified VGPR/AGPR file: WMB*5*4 registers).  Variants: <4,4> 256x160 (8 waves), <2,4> 128x160,
-// <2,2> 64x160 (4 waves); small-MN / huge-K problems add split-K over gridDim.z with fp32 slabs
-// and a reduce+epilogue kernel (no in-launch inter-workgroup hand-off).
+// Block tile BM x BN x 64 with BM = WAVES_M * WMB * 16, BN = 32 * NT; waves laid out WAVES_M (M) x 2 (N);
+// each wave owns a (WMB*16) x (16*NT) sub-tile = WMB x NT MFMA tiles of 16x16 (fp32 accumulators:
+// WMB*NT*4 registers).  Variants: <4,4> 256xBN (8 waves), <2,4> 128xBN, <2,2> 64xBN (4 waves);
+// small-MN / huge-K problems add split-K over gridDim.z with fp32 slabs and a reduce+epilogue kernel.
 //
 // Staging is LDS-DMA (global_load_lds_dwordx4): one wave instruction moves 8 rows x 128 B straight
 // from global memory into LDS, two LDS stages, the next K tile in flight during the MFMAs of the
@@ -31,7 +31,7 @@
 namespace {
 
 constexpr int BK = 64;
-constexpr int BN = 160;
+constexpr int BN = 160;             // patch kernel / default tile width (gemm160_kernel derives its own from NT)
 constexpr int ROWB = BK * 2;         // bytes per LDS row (128)
 
 __device__ __attribute__((aligned(256))) half_t g_zero_page[128];  // zero-initialised: OOB source of the gather
