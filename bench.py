@@ -10,8 +10,13 @@ checkpoints / datasets in the environment).
 
   python bench.py [--gpus N --steps K --warmup W]          (N>1: launched by torch.distributed.run)
 
-Prints ONE JSON line (rank 0).  `roofline` is measured live: HIP-event pairs around every launch
-of the dominant kernel on its launch stream during the timed region (libpfd_hip's pfd_prof_*).
+Prints ONE JSON line (rank 0).  `roofline` is measured live inside this process with HIP-event pairs
+around every launch of every kernel family on its launch stream (libpfd_hip's pfd_prof_*): with
+--no-graph during the timed region itself; by default the timed region replays hipGraphs (events cannot
+be captured), so the same kernels, shapes and data path are timed on ONE more, eagerly launched, batch
+right after the timed region (`roofline.measured_on` says which; rocprofv3 summaries of the same command
+are under profiles/).  `roofline.traffic` = HBM bytes per launch from rocprofv3 PMC passes
+(profiles/pmc_traffic.json, see tools/pmc_bucket.py).
 `cpu_baseline` times the CPU oracle (a port of the reference's algorithm, oracle/pfd_oracle.py)
 on a bounded sample of the same workload on this host's cores.
 """
