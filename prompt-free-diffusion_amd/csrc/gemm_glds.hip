@@ -440,7 +440,7 @@ __global__ __launch_bounds__(512) void conv3x3_patch_kernel(const G160Params p) 
     const int r = (wave + NW * j) * 8 + srow;
     const int py = r / PW, px = r - py * PW;
     const int y = y0 - 1 + py, x = px - 1;
-    const int c = cpos ^ ((r >> 1) & 7);
+    const int c = (cpos - (r & ~1)) & 7;   // rotation swizzle of the patch rows, see the fragment read below
     const bool ok = r < prow_count && y >= 0 && y < H && x >= 0 && x < W;
     pp[j] = ok ? img + ((long)y * W + x) * p.lda + c * 8 : nullptr;
   }
@@ -510,8 +510,15 @@ __global__ __launch_bounds__(512) void conv3x3_patch_kernel(const G160Params p) 
             half8_t af[WMB], bf[5];
 #pragma unroll
             for (int i = 0; i < WMB; ++i) {
+              // The nine taps read the SAME stored patch at nine different row offsets, so the 16 rows of
+              // a fragment start anywhere.  ds_read_b128 is served in four fixed 16-lane groups that mix the
+              // k-chunks of lane rows {0-3, 12-15} of one g with rows {4-11} of the next g; the XOR swizzle
+              // c ^ (row >> 1) of the GEMM kernel is conflict-free only for 16-aligned starts (PMC: 23 % of the
+              // LDS cycles of this kernel were bank conflicts), no XOR-by-row function is for every start, but
+              // the ROTATION pos = (chunk + 2 * (row >> 1)) mod 8 is: within a parity class the four rows of
+              // one sub-set always land on the four even positions + chunk and the other four on the odd ones.
               const int r = rbase[i] + toff;
-              af[i] = *reinterpret_cast<const half8_t*>(patch + r * ROWB + (((ks * 4 + g) ^ ((r >> 1) & 7)) << 4));
+              af[i] = *reinterpret_cast<const half8_t*>(patch + r * ROWB + ((((ks * 4 + g) + (r & ~1)) & 7) << 4));
             }
             const int bo = ks ? boff1 : boff0;
 #pragma unroll

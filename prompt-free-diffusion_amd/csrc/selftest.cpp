@@ -730,6 +730,13 @@ static int replay(const char* path, bool timed = false, int force_tile = 0) {
 int main(int argc, char** argv) {
   if (argc > 2 && !strcmp(argv[1], "--replay")) return replay(argv[2]);
   if (argc > 1 && !strcmp(argv[1], "--launch-floor")) { bench_launch_floor(); return 0; }
+  if (argc > 1 && !strcmp(argv[1], "--bench-patch")) {   // one 3x3 conv per image width the patch kernel serves
+    bench_gemm("conv3x3 320->320 @64^2", 0, 320, 0, 3, 8, 64, 320, 0);
+    bench_gemm("conv3x3 640->640 @32^2", 0, 640, 0, 3, 8, 32, 640, 0);
+    bench_gemm("conv3x3 1280->1280 @16^2", 0, 1280, 0, 3, 8, 16, 1280, 0);
+    bench_gemm("conv3x3 320->320 @64^2 implicit GEMM", 0, 320, 0, 3, 8, 64, 320, 5400);
+    return 0;
+  }
   if (argc > 1 && !strcmp(argv[1], "--bench-attn")) {
     bench_attn("self-attn 64^2 d40", 8, 8, 4096, 4096, 40);
     bench_attn("self-attn 32^2 d80", 8, 8, 1024, 1024, 80);
