@@ -8,8 +8,12 @@ calling convention (NCHW / any float dtype) wrapped around `.hip`.
 
 Canonical parameters stay the `nn.Parameter`s; kernel-layout fp16 copies are cached per layer
 and rebuilt whenever the canonical tensor changes identity, version, dtype or device
-(`load_state_dict`, `.half()`, `.to()`, in-place edits) -- app.py hot-swaps weights per
-request (app.py:139-177, 217-222).
+(`load_state_dict`, `.half()`, `.to()`, in-place ops on the parameter itself) -- app.py hot-swaps
+weights per request (app.py:139-177, 217-222).  NOT detected: edits made through `param.data`
+(`p.data.copy_(w)`, `p.data.mul_()` -- `.data` carries its own version counter, so neither the
+pointer nor `p._version` moves).  Code that edits weights that way (EMA / LoRA merging) must call
+`invalidate_packed(module)` afterwards; it also bumps a global generation that the hipGraph keys of
+DDIMSampler / the pipeline stages include, so stale graphs are re-captured rather than replayed.
 """
 import torch
 import torch.nn as nn
@@ -22,8 +26,27 @@ def _round_up(v, m):
     return (v + m - 1) // m * m
 
 
+_GENERATION = [0]
+
+
+def generation():
+    """bumped by invalidate_packed(); part of every packed-cache and hipGraph key"""
+    return _GENERATION[0]
+
+
+def invalidate_packed(module=None):
+    """Drop the kernel-layout weight copies of `module` (and its children; None: nothing to walk, only the
+    generation moves) after weights were edited through `.data` / raw pointers, and invalidate every
+    captured hipGraph that may have baked the old copies in."""
+    _GENERATION[0] += 1
+    if module is not None:
+        for m in module.modules():
+            m.__dict__.pop("_pk_cache", None)
+
+
 def _sig(*ps):
-    return tuple((p.data_ptr(), p._version, p.dtype, p.device) if p is not None else None for p in ps)
+    return (_GENERATION[0],) + tuple((p.data_ptr(), p._version, p.dtype, p.device) if p is not None else None
+                                     for p in ps)
 
 
 def _dev16(t):
@@ -101,7 +124,8 @@ class Conv2d(nn.Conv2d, _Packed):
             raise NotImplementedError("narrow-channel conv with fused upsample")
         r2 = None if res is None else res.reshape(-1, res.shape[-1])
         ho, wo = out_hw if out_hw is not None else (None, None)
-        return ops.conv_narrow(x, w, k, stride=s, pad=p, bias=b, rowvec=rowvec, res=r2, act=act, ho=ho, wo=wo)
+        return ops.conv_narrow(x, w, k, stride=s, pad=p, bias=b, rowvec=rowvec, res=r2, act=act, ho=ho, wo=wo,
+                               out=out)
 
     def forward(self, x):
         return _io_wrap_nchw(self, x, self.hip)

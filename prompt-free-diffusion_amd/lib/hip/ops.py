@@ -6,7 +6,9 @@ Layout convention of the whole product path: activations are fp16, token-major /
 reference API boundary (ops.to_nhwc / ops.to_nchw).
 """
 import ctypes as C
+import functools
 import os
+import threading
 
 import torch
 
@@ -26,6 +28,23 @@ def _stream():
 
 def _ptr(t):
     return t.data_ptr() if t is not None else None
+
+
+# The reference's models are called from Gradio worker threads on ONE shared global model with no lock
+# (app.py:277, 405-410).  Everything here runs on the current stream and shares per-device scratch (the
+# split-K slabs below, the per-layer packed-weight caches, captured hipGraphs with static input buffers),
+# so every public entry point of the product path (composite model methods, DDIMSampler, the pipeline)
+# holds this re-entrant lock for the duration of its launch sequence: concurrent requests serialise
+# instead of interleaving a GEMM and its split-K reduce with another thread's GEMM.
+DEVICE_LOCK = threading.RLock()
+
+
+def serialised(fn):
+    @functools.wraps(fn)
+    def wrapper(*a, **k):
+        with DEVICE_LOCK:
+            return fn(*a, **k)
+    return wrapper
 
 
 _WS = {}
@@ -95,6 +114,10 @@ def gemm(a, w, *, bias=None, rowvec=None, rows_per_rv=1, res=None, act=ACT_NONE,
         n_out = n_split
     if out is None:
         out = torch.empty((M, n_out), dtype=torch.float16, device=a.device)
+    else:
+        _chk16(out, "gemm out")
+        if out.device != a.device or out.shape[-1] != n_out or out.numel() != M * n_out:
+            raise ValueError(f"gemm: out {tuple(out.shape)} on {out.device} cannot hold [{M}, {n_out}] on {a.device}")
     _, _, ldc = _rows(out)
     d = _b.PfdGemmDesc()
     if out_t is not None:
@@ -144,6 +167,10 @@ def conv(x, w, ksize, *, stride=1, pad=None, ups=False, bias=None, rowvec=None, 
     M = B * Ho * Wo
     if out is None:
         out = torch.empty((B, Ho, Wo, N), dtype=torch.float16, device=x.device)
+    else:
+        _chk16(out, "conv out")
+        if out.device != x.device or out.shape[-1] != N or out.numel() != M * N:
+            raise ValueError(f"conv: out {tuple(out.shape)} on {out.device} cannot hold [{B},{Ho},{Wo},{N}]")
     d = _b.PfdGemmDesc()
     d.A, d.W, d.C = x.data_ptr(), w.data_ptr(), out.data_ptr()
     d.bias, d.rowvec, d.R = _ptr(bias), _ptr(rowvec), _ptr(res)
@@ -177,15 +204,16 @@ def im2col(x, ksize, stride, pad, kpad, ho=None, wo=None):
 
 
 def conv_narrow(x, w, ksize, *, stride=1, pad=None, bias=None, rowvec=None, res=None, act=ACT_NONE,
-                ho=None, wo=None):
+                ho=None, wo=None, out=None):
     """Convolution whose Cin is not a multiple of 64: im2col + GEMM.  w: [N, kpad] packed."""
     if pad is None:
         pad = ksize // 2
     B = x.shape[0]
     col, Ho, Wo = im2col(x, ksize, stride, pad, w.shape[1], ho, wo)
     N = w.shape[0]
-    out = gemm(col, w, bias=bias, rowvec=rowvec, rows_per_rv=Ho * Wo, res=res, act=act)
-    return out.view(B, Ho, Wo, N)
+    o2 = None if out is None else out.view(-1, out.shape[-1])
+    y = gemm(col, w, bias=bias, rowvec=rowvec, rows_per_rv=Ho * Wo, res=res, act=act, out=o2)
+    return y.view(B, Ho, Wo, N) if out is None else out
 
 
 # ----------------------------------------------------------------------------------------------
@@ -326,8 +354,11 @@ def cfg_ddim_step(eps, nb, x, coef, *, noise=None, want_next=True):
 
 def add(a, b, out=None):
     _chk16(a, "add a")
+    _chk16(b, "add b")
     if not (a.is_contiguous() and b.is_contiguous()):
         raise ValueError("add: dense tensors expected")
+    if a.numel() != b.numel() or (out is not None and out.numel() != a.numel()):
+        raise ValueError(f"add: operand sizes differ ({tuple(a.shape)} vs {tuple(b.shape)}); no broadcasting")
     if out is None:
         out = torch.empty_like(a)
     _b.check(_lib().pfd_add_f16(a.data_ptr(), b.data_ptr(), out.data_ptr(), a.numel(), _stream()), "pfd_add_f16")
@@ -339,6 +370,8 @@ def axpby(a, alpha, b=None, beta=0.0, out=None):
     _chk16(a, "axpby a")
     if not a.is_contiguous() or (b is not None and not b.is_contiguous()):
         raise ValueError("axpby: dense tensors expected")
+    if (b is not None and b.numel() != a.numel()) or (out is not None and out.numel() != a.numel()):
+        raise ValueError("axpby: operand sizes differ; no broadcasting")
     if out is None:
         out = torch.empty_like(a)
     _b.check(_lib().pfd_axpby_f16(a.data_ptr(), float(alpha), _ptr(b), float(beta), out.data_ptr(), a.numel(),

@@ -160,10 +160,17 @@ class ControlNet(nn.Module):
                 conv = module[0]
                 if guided.shape[0] == B:
                     h = conv.hip(h, res=guided)                       # h = conv(x) + guided_hint
-                else:                                                # one hint for the whole batch
+                elif guided.shape[0] == 1:                            # one hint for the whole batch
                     h = conv.hip(h)
                     for b in range(B):
                         ops.add(h[b:b + 1], guided, out=h[b:b + 1])
+                elif B % guided.shape[0] == 0:                        # per-sample hints under CFG: [u | c] halves
+                    h = conv.hip(h)
+                    k = guided.shape[0]
+                    for b in range(0, B, k):
+                        ops.add(h[b:b + k], guided, out=h[b:b + k])
+                else:   # the reference's `h + guided_hint` raises a broadcast error here (controlnet.py:315)
+                    raise ValueError(f"control hint batch {guided.shape[0]} does not broadcast to batch {B}")
             else:
                 h = module.hip(h, semb, context)
             outs.append(zero_conv[0].hip(h))

@@ -77,6 +77,7 @@ class DDIMSampler(object):
         tab = np.stack([a, ap, sg, s1, np.full_like(np.asarray(a, dtype=np.float64), float(scale))], axis=1)
         return torch.tensor(tab, dtype=torch.float32, device=self.model.device)
 
+    @ops.serialised
     @torch.no_grad()
     def sample(self, steps, shape, x_info, c_info, eta=0., temperature=1., noise_dropout=0., verbose=True,
                log_every_t=100):
@@ -86,6 +87,7 @@ class DDIMSampler(object):
         return self.ddim_sampling(shape, x_info=x_info, c_info=c_info, noise_dropout=noise_dropout,
                                   temperature=temperature, log_every_t=log_every_t)
 
+    @ops.serialised
     @torch.no_grad()
     def ddim_sampling(self, shape, x_info, c_info, noise_dropout=0., temperature=1., log_every_t=100,
                       callback=None):
@@ -165,6 +167,7 @@ class DDIMSampler(object):
             ent = self._graphs.get(key)
             if ent is None:
                 if len(self._graphs) >= 4:
+                    torch.cuda.synchronize()   # never drop a graph whose replay may still be in flight
                     self._graphs.clear()
                 ent = self._capture(run_loop, x, c_in, hint, (coef, t_table))
                 self._graphs[key] = ent
@@ -184,6 +187,7 @@ class DDIMSampler(object):
         return out, intermediates
 
     # ---- multi-context sampling (ddim.py:174-299) ------------------------------------------------
+    @ops.serialised
     @torch.no_grad()
     def sample_multicontext(self, steps, shape, x_info, c_info_list, eta=0., temperature=1., noise_dropout=0.,
                             verbose=True, log_every_t=100):
@@ -213,6 +217,7 @@ class DDIMSampler(object):
                 kv.zero_lead = bs if not bool(ci['unconditional_conditioning'].any()) else 0
         return mix, scale, (1 if scale == 1. else 2)
 
+    @ops.serialised
     @torch.no_grad()
     def ddim_sampling_multicontext(self, shape, x_info, c_info_list, noise_dropout=0., temperature=1.,
                                    log_every_t=100):
@@ -258,6 +263,7 @@ class DDIMSampler(object):
         x_info['x'] = out
         return out, inter
 
+    @ops.serialised
     @torch.no_grad()
     def p_sample_ddim_multicontext(self, x_info, c_info_list, t, index, repeat_noise=False,
                                    use_original_steps=False, noise_dropout=0., temperature=1.):
@@ -293,7 +299,8 @@ class DDIMSampler(object):
             self._graphs = {}
 
     def _weights_signature(self):
-        return hash(tuple((p.data_ptr(), p._version) for p in self.model.parameters()))
+        from ..hip.layers import generation
+        return hash((generation(),) + tuple((p.data_ptr(), p._version) for p in self.model.parameters()))
 
     def _capture(self, run_loop, x, c_in, hint, keep):
         from ..hip import binding
@@ -311,6 +318,7 @@ class DDIMSampler(object):
             outs = run_loop(sx, sc, sh)
         return g, sx, sc, sh, outs, keep
 
+    @ops.serialised
     @torch.no_grad()
     def p_sample_ddim(self, x_info, c_info, t, index, repeat_noise=False, use_original_steps=False,
                       noise_dropout=0., temperature=1.):

@@ -126,17 +126,20 @@ class PromptFreeDiffusion(nn.Module):
                 extract_into_tensor(self.sqrt_recipm1_alphas_cumprod, t, x_t.shape) * noise)
 
     # ---- inference surface -----------------------------------------------------------------
+    @ops.serialised
     @torch.no_grad()
     def vae_encode(self, x, which, **kwargs):
         z = self.vae[which].encode(x, **kwargs)
         scale = (self.latent_scale_factor or {}).get(which, None)
         return z if scale is None else scale * z
 
+    @ops.serialised
     @torch.no_grad()
     def vae_decode(self, z, which, **kwargs):
         scale = (self.latent_scale_factor or {}).get(which, None)
         return self.vae[which].decode(z, in_scale=1.0 if scale is None else 1. / scale, **kwargs)
 
+    @ops.serialised
     @torch.no_grad()
     def ctx_encode(self, x, which, **kwargs):
         if which.find('vae_') == 0:
@@ -153,6 +156,7 @@ class PromptFreeDiffusion(nn.Module):
     def _control_residuals(self, x_nhwc, timesteps, context, control):
         return None
 
+    @ops.serialised
     @torch.no_grad()
     def apply_model_nhwc(self, x_type, x_nhwc, timesteps, c_type, context, control=None, emb_table=None):
         """x_nhwc fp16 [B,h,w,C]; context ContextKV; -> eps NHWC fp16"""
@@ -173,6 +177,7 @@ class PromptFreeDiffusion(nn.Module):
         return ContextMix([(self.diffuser[ci['type']], as_context_kv(ci['c']), ci['ratio']) for ci in c_info_list],
                           mixing_type)
 
+    @ops.serialised
     @torch.no_grad()
     def apply_model_multicontext(self, x_info, timesteps, c_info_list, mixing_type='attention'):
         """pfd.py:388-439: the UNet forward with every context layer replaced by the ratio-weighted sum
@@ -182,6 +187,7 @@ class PromptFreeDiffusion(nn.Module):
         eps = self.apply_model_nhwc(x_info['type'], ops.to_nhwc(x), timesteps, None, mix)
         return ops.to_nchw(eps, x.dtype)
 
+    @ops.serialised
     @torch.no_grad()
     def apply_model(self, x_info, timesteps, c_info):
         x_type, x = x_info['type'], x_info['x']

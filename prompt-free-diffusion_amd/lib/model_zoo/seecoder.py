@@ -151,7 +151,21 @@ class PPE_MLP(nn.Module):
         nn.init.constant_(self.mlp[-1].weight, 0)
 
     def features(self, h, w, device):
-        """[h*w, 4*freq_num] fp16 sinusoid features (host fp32 math, shape-only dependence)"""
+        """[h*w, 4*freq_num] fp16 sinusoid features: a table that depends on the SHAPE only, built once per
+        (h, w, device) with host fp32 math (like the DDIM schedule tables) and kept on the device -- so a
+        hipGraph capture of the context stage never sees a pageable host->device copy"""
+        cache = self.__dict__.setdefault("_feat_cache", {})
+        key = (h, w, str(device), self.freq_num, self.freq_max)
+        hit = cache.get(key)
+        if hit is None:
+            if torch.cuda.is_available() and torch.cuda.is_current_stream_capturing():
+                raise RuntimeError("PPE_MLP.features: table for a new shape requested during stream capture")
+            if len(cache) >= 16:
+                cache.clear()
+            hit = cache[key] = self._features_host(h, w).to(device=device, dtype=torch.float16)
+        return hit
+
+    def _features_host(self, h, w):
         minlen = min(h, w)
         ys, xs = torch.meshgrid(torch.arange(h, dtype=torch.float32), torch.arange(w, dtype=torch.float32),
                                 indexing='ij')
@@ -161,7 +175,7 @@ class PPE_MLP(nn.Module):
         dim_t = float(freq_max) ** torch.linspace(0, 1, self.freq_num, dtype=torch.float32)
         ph, pw = ys[:, :, None] * dim_t, xs[:, :, None] * dim_t
         pos = torch.cat((ph.sin(), ph.cos(), pw.sin(), pw.cos()), dim=-1)
-        return pos.reshape(h * w, -1).to(device=device, dtype=torch.float16)
+        return pos.reshape(h * w, -1)
 
     def hip(self, h, w, device):
         x = self.features(h, w, device)

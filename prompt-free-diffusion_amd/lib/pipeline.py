@@ -14,6 +14,8 @@ all-gather of the decoded images after the loop (`gather=True`).
 """
 import torch
 
+from .hip.ops import serialised
+
 
 def build_model(name='pfd_seecoder', device='cuda', fp16=True, randomize_zero_init=True, seed=0, verbose=False):
     """Construct a composite from the config bank with synthetic weights (no checkpoints exist in
@@ -66,41 +68,45 @@ class _GraphedStage:
     """One stage (context encode, VAE decode) replayed as a hipGraph: ~1500 / ~150 launches per call whose
     issue cost is otherwise paid by the host every batch (SeeCoder: 8 ms eager vs ~3 ms of GPU work).  One
     graph per (input shape, dtype, weights identity+version of the sub-model); static input buffer owned here;
-    the same kernels as the eager path.  A capture that fails (e.g. an op that synchronises) disables the
-    stage's graph and the call simply runs eagerly."""
+    the same kernels as the eager path.  A capture that fails RAISES (like DDIMSampler._capture): a stage
+    that silently fell back to eager launches would hide exactly the kind of capture-illegal call (host sync,
+    pageable H2D copy) that corrupts a replay."""
 
-    def __init__(self, fn, module):
-        self.fn, self.module = fn, module
-        self.graphs, self.broken = {}, False
+    def __init__(self, net, method, which, module):
+        # (net, method name) instead of a closure over the pipeline: no reference cycle, so the graphs and
+        # their private memory pools are released by refcount when the pipeline is dropped, not at some
+        # later cyclic-GC pass (possibly in the middle of another stream capture)
+        self.net, self.method, self.which, self.module = net, method, which, module
+        self.graphs = {}
+
+    def fn(self, x):
+        return getattr(self.net, self.method)(x, self.which)
 
     def _signature(self):
-        return hash(tuple((p.data_ptr(), p._version) for p in self.module.parameters()))
+        from .hip.layers import generation
+        return hash((generation(),) + tuple((p.data_ptr(), p._version) for p in self.module.parameters()))
 
+    @serialised
     def __call__(self, x):
-        if self.broken or not x.is_cuda:
-            return self.fn(x)
+        if not x.is_cuda:
+            raise RuntimeError("HIP path: stage input must be on the GPU (no CPU fallback)")
         key = (tuple(x.shape), x.dtype, self._signature())
         ent = self.graphs.get(key)
         if ent is None:
-            try:
-                from .hip import binding
-                binding.prof_enable(False)
-                sx = x.clone()
-                side = torch.cuda.Stream()
-                side.wait_stream(torch.cuda.current_stream())
-                with torch.cuda.stream(side):     # warm-up outside capture: packs weights, sizes the allocator
-                    self.fn(sx)
-                torch.cuda.current_stream().wait_stream(side)
-                torch.cuda.synchronize()
-                g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g):
-                    out = self.fn(sx)
-            except Exception as e:    # noqa: BLE001 -- e.g. a stream-capture-illegal call in a custom context encoder
-                print(f"[pipeline] hipGraph capture of {getattr(self.fn, '__name__', 'stage')} failed ({e}); running eagerly")
-                self.broken = True
-                torch.cuda.synchronize()
-                return self.fn(x)
+            from .hip import binding
+            binding.prof_enable(False)
+            sx = x.clone()
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):     # warm-up outside capture: packs weights, sizes the allocator
+                self.fn(sx)
+            torch.cuda.current_stream().wait_stream(side)
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                out = self.fn(sx)
             if len(self.graphs) >= 4:
+                torch.cuda.synchronize()      # never drop a graph whose replay may still be in flight
                 self.graphs.clear()
             ent = self.graphs[key] = (g, sx, out)
         g, sx, out = ent
@@ -122,10 +128,11 @@ class PromptFreePipeline:
         context encode and the VAE decode"""
         self.sampler.enable_graph(on)
         if on and self._stages is None:
-            self._stages = (_GraphedStage(lambda im: self.net.ctx_encode(im, 'image'), self.net.ctx['image']),
-                            _GraphedStage(lambda z: self.net.vae_decode(z, 'image'), self.net.vae['image']))
+            self._stages = (_GraphedStage(self.net, 'ctx_encode', 'image', self.net.ctx['image']),
+                            _GraphedStage(self.net, 'vae_decode', 'image', self.net.vae['image']))
         self._ctx_stage, self._vae_stage = self._stages if on else (None, None)
 
+    @serialised
     @torch.no_grad()
     def encode_reference(self, image, n):
         """image: [1,3,H,W] in [0,1] -> (cond [n,148,768], uncond zeros), app.py:234-236"""
@@ -133,6 +140,7 @@ class PromptFreePipeline:
         cond = c.repeat(n, 1, 1)
         return cond, torch.zeros_like(cond)
 
+    @serialised
     @torch.no_grad()
     def generate(self, image, n_global, height, width, steps=50, scale=2.0, eta=0.0, seed=20, control=None,
                  uncond=None, decode=True, gather=False, verbose=False, timings=None):
