@@ -35,6 +35,26 @@ def param_shapes(state_spec):
     return {k: v["shape"] for k, v in state_spec.items() if v["param"]}
 
 
+@pytest.fixture(scope="session")
+def net(param_shapes):
+    """the full composite on the GPU, fp16 (like app.py:117-129), seeded weights; shared by every GPU test file"""
+    from lib.cfg_helper import model_cfg_bank
+    from lib.model_zoo import get_model
+    from weights import seeded_tensor
+    assert torch.cuda.is_available(), "GPU tests need a visible MI355X"
+    cfg = model_cfg_bank()('pfd_seecoder_with_controlnet')
+    cfg.args.vae_cfg_list[0][1].pth = None
+    n = get_model()(cfg, verbose=False)
+    sd = n.state_dict()
+    for k, s in param_shapes.items():
+        sd[k] = seeded_tensor(k, s, 0)
+    n.load_state_dict(sd, strict=True)
+    n.half()
+    n.to('cuda')
+    n.eval()
+    return n
+
+
 def seeded_sd(param_shapes, prefix):
     """fp32 CPU state dict of the sub-model under `prefix` (keys keep the full composite name)"""
     from weights import seeded_tensor

@@ -29,26 +29,6 @@ def check(name, a, ref, tol=TOL):
     assert e <= tol, f"{name}: {e} > {tol}"
 
 
-@pytest.fixture(scope="module")
-def net(param_shapes):
-    """the full composite on the GPU, fp16 (like app.py:117-129), seeded weights"""
-    from lib.cfg_helper import model_cfg_bank
-    from lib.model_zoo import get_model
-    from weights import seeded_tensor
-    assert torch.cuda.is_available(), "GPU tests need a visible MI355X"
-    cfg = model_cfg_bank()('pfd_seecoder_with_controlnet')
-    cfg.args.vae_cfg_list[0][1].pth = None
-    n = get_model()(cfg, verbose=False)
-    sd = n.state_dict()
-    for k, s in param_shapes.items():
-        sd[k] = seeded_tensor(k, s, 0)
-    n.load_state_dict(sd, strict=True)
-    n.half()
-    n.to('cuda')
-    n.eval()
-    return n
-
-
 def test_native_library_is_loaded(net):
     from lib.hip import binding
     lib = binding.load()
