@@ -101,7 +101,7 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world)  # "nccl" == RCCL on ROCm
 
     from lib.hip import binding
-    from lib.pipeline import PromptFreePipeline, build_model
+    from lib.pipeline import PromptFreePipeline, build_model, max_over_ranks
     import contextlib
     with contextlib.redirect_stdout(sys.stderr):   # constructors print (like the reference's); keep stdout = the JSON line
         net = build_model('pfd_seecoder_with_controlnet' if args.config == "c3" else 'pfd_seecoder',
@@ -164,10 +164,7 @@ def main():
     binding.prof_enable(False)
     if rank == 0:   # per-stage split of one more (graph-replayed) batch, outside the timed region
         step(998, gather=False, timings=stage_ms)
-    if world > 1:
-        tmax = torch.tensor([dt], device='cuda', dtype=torch.float64)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dt = float(tmax.item())
+    dt = max_over_ranks(dt, world, device='cuda')     # a step is as slow as its slowest rank
     assert out is not None and out.shape[0] == n_global and bool(torch.isfinite(out).all())
 
     if rank == 0:

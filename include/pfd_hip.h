@@ -34,7 +34,7 @@ extern "C" {
 #define PFD_ESHAPE (-2)   /* shape outside what the kernels are built for           */
 #define PFD_ELAUNCH (-3)  /* hipGetLastError() != hipSuccess after the launch       */
 
-#define PFD_ABI_VERSION 3
+#define PFD_ABI_VERSION 4
 
 typedef void* pfd_stream_t; /* hipStream_t */
 
@@ -120,6 +120,13 @@ int pfd_gemm_f16(const PfdGemmDesc* d, pfd_stream_t stream);
  *          26, 27 = deeper operand rings of 24 / 22; 99 = the 3x3 patch kernel), split-K factor s in
  *          0..8 (0 = heuristic), e.g. 1000 + 4400 + 2 = 5402. */
 int pfd_gemm_f16_ex(const PfdGemmDesc* d, int32_t tile, pfd_stream_t stream);
+
+/* GEGLU weight packing the serving kernel expects for a projection of N = 2*dim_out output rows: the
+ * returned g is the interleave granularity -- packed rows come in groups [x(g rows) | gate(g rows)]
+ * (g = 2: the four accumulator columns one lane of the wide-tile kernel owns; g = 32: one 32-column MFMA
+ * tile pair of the 128x128 kernel).  pfd_gemm_f16 with act = PFD_ACT_GEGLU returns PFD_ESHAPE rather than
+ * fall through to a kernel with a different packing.  (GEGLU, attention.py:44-51.) */
+int32_t pfd_gemm_geglu_group(int32_t N);
 
 /* ------------------------------------------------------------------------------------
  * Fused scaled-dot-product attention, online softmax in fp32 (never materialises the
@@ -243,6 +250,13 @@ int pfd_axpby_f16(const void* a, float alpha, const void* b, float beta, void* y
  * seecoder.py:402,515). */
 int pfd_add_rowvec_f16(const void* x, int64_t ldx, const void* v, void* y, int64_t ldy, int32_t R,
                        int32_t C, pfd_stream_t stream);
+
+/* NHWC f16 -> packed uint8 image(s) [B, H, W, C]: v = clamp(x*mul + add, 0, 1) rounded to f16, then
+ * uint8(v * 255) with the f16 product truncated -- bit for bit what the reference's output stage does to
+ * the decoded image: AutoencoderKL.decode's (x+1)/2 + clamp (autokl.py:47,53) followed by
+ * torchvision's ToPILImage, i.e. `pic.mul(255).byte()` on the f16 tensor (app.py:273-275).  The
+ * request front-end hands the bytes to the client without a float image ever leaving the device. */
+int pfd_image_u8_f16(const void* x, void* y, int64_t n, float mul, float add, pfd_stream_t stream);
 
 /* y = act(x) elementwise (act in NONE|GELU|RELU|SILU), n f16 elements.  The SiLU in front
  * of every ResBlock emb_layers Linear (openaimodel.py:217-218) applied once to the shared

@@ -202,6 +202,28 @@ __global__ void act_kernel(const half_t* __restrict__ x, half_t* __restrict__ y,
   }
 }
 
+// 8 pixels-channels per thread: one 16-byte load, one 8-byte store
+__global__ void image_u8_kernel(const half_t* __restrict__ x, uint8_t* __restrict__ y, long n, float mul, float add) {
+  const long nv = n / 8;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < nv; i += (long)gridDim.x * blockDim.x) {
+    Pack16 p;
+    p.u = reinterpret_cast<const uint4*>(x)[i];
+    union { uint2 u; uint8_t b[8]; } o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const half_t v = (half_t)fminf(fmaxf((float)p.e[e] * mul + add, 0.f), 1.f);   // the f16 image the reference holds
+      const half_t m = v * (half_t)255.f;                                          // f16 product (round to nearest even)
+      o.b[e] = (uint8_t)(float)m;                                                  // .byte(): truncation
+    }
+    reinterpret_cast<uint2*>(y)[i] = o.u;
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (n & 7)) {
+    const long i = nv * 8 + threadIdx.x;
+    const half_t v = (half_t)fminf(fmaxf((float)x[i] * mul + add, 0.f), 1.f);
+    y[i] = (uint8_t)(float)(v * (half_t)255.f);
+  }
+}
+
 inline int grid_for(long n, int block) {
   long g = (n + block - 1) / block;
   if (g > 4096) g = 4096;
@@ -291,6 +313,14 @@ extern "C" int pfd_add_rowvec_f16(const void* x, int64_t ldx, const void* v, voi
   hipLaunchKernelGGL(add_rowvec_kernel, dim3(grid_for(n, 256)), dim3(256), 0, (hipStream_t)stream,
                      (const half_t*)x, (long)ldx, (const half_t*)v, (half_t*)y, (long)ldy, R, C);
   return pfd_check_launch("pfd_add_rowvec_f16");
+}
+
+extern "C" int pfd_image_u8_f16(const void* x, void* y, int64_t n, float mul, float add, pfd_stream_t stream) {
+  if (!x || !y || n <= 0) return PFD_EINVAL;
+  if ((reinterpret_cast<uintptr_t>(x) & 15) || (reinterpret_cast<uintptr_t>(y) & 7)) return PFD_EINVAL;
+  hipLaunchKernelGGL(image_u8_kernel, dim3(grid_for(n / 8 + 1, 256)), dim3(256), 0, (hipStream_t)stream,
+                     (const half_t*)x, (uint8_t*)y, (long)n, mul, add);
+  return pfd_check_launch("pfd_image_u8_f16");
 }
 
 extern "C" int pfd_act_f16(const void* x, void* y, int64_t n, int32_t act, pfd_stream_t stream) {

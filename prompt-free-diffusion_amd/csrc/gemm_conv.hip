@@ -295,6 +295,8 @@ int launch(const GemmParams& p0, hipStream_t s) {
 
 int pfd_gemm160_try(const PfdGemmDesc* d, int variant, int splits, hipStream_t s);  // gemm_glds.hip
 
+extern "C" int32_t pfd_gemm_geglu_group(int32_t N) { return N % 160 == 0 ? 2 : 32; }
+
 extern "C" int pfd_gemm_f16_ex(const PfdGemmDesc* d, int32_t tile, pfd_stream_t stream) {
   if (!d || !d->A || !d->W || !d->C) return PFD_EINVAL;
   if (d->M <= 0 || d->N <= 0 || d->K <= 0) return PFD_EINVAL;
@@ -339,7 +341,10 @@ extern "C" int pfd_gemm_f16_ex(const PfdGemmDesc* d, int32_t tile, pfd_stream_t 
   if (p.act < PFD_ACT_NONE || p.act > PFD_ACT_GEGLU) return PFD_EINVAL;
   hipStream_t s = (hipStream_t)stream;
   if (p.act == PFD_ACT_GEGLU) {
-    if (p.N % 128) return PFD_ESHAPE;
+    // N % 160 == 0 is packed in pairs for the wide-tile kernel (pfd_gemm_geglu_group): if that kernel declined
+    // the call (unaligned C / ldc, forced tile), running the 32-block-interleave kernel here would pair the
+    // wrong x / gate rows silently
+    if (p.N % 128 || pfd_gemm_geglu_group(p.N) != 32) return PFD_ESHAPE;
     return launch<2, 2>(p, s);
   }
   switch (tile) {  // explicit tile (tests / tuning); 0 = heuristic below

@@ -14,7 +14,7 @@ import os
 _LIB = None
 _LIB_PATH = os.path.normpath(os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "..", "libpfd_hip.so"))
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 ACT_NONE, ACT_GELU, ACT_RELU, ACT_SILU, ACT_GEGLU = 0, 1, 2, 3, 4
 
@@ -58,6 +58,7 @@ SIGNATURES = {
     "pfd_last_error": (C.c_char_p, []),
     "pfd_gemm_f16": (_i32, [C.POINTER(PfdGemmDesc), _vp]),
     "pfd_gemm_f16_ex": (_i32, [C.POINTER(PfdGemmDesc), _i32, _vp]),
+    "pfd_gemm_geglu_group": (_i32, [_i32]),
     "pfd_attention_f16": (_i32, [C.POINTER(PfdAttnDesc), _vp]),
     "pfd_swin_window_attention_f16": (_i32, [C.POINTER(PfdSwinAttnDesc), _vp]),
     "pfd_groupnorm_ws_bytes": (_sz, [_i32, _i32, _i32]),
@@ -74,6 +75,7 @@ SIGNATURES = {
     "pfd_axpby_f16": (_i32, [_vp, _f32, _vp, _f32, _vp, _i64, _vp]),
     "pfd_add_rowvec_f16": (_i32, [_vp, _i64, _vp, _vp, _i64, _i32, _i32, _vp]),
     "pfd_act_f16": (_i32, [_vp, _vp, _i64, _i32, _vp]),
+    "pfd_image_u8_f16": (_i32, [_vp, _vp, _i64, _f32, _f32, _vp]),
     "pfd_prof_enable": (_i32, [_i32]),
     "pfd_prof_read": (_i32, [_i32, C.POINTER(C.c_double), C.POINTER(_i64), C.POINTER(C.c_double),
                              C.POINTER(C.c_double)]),

@@ -18,6 +18,7 @@ import numpy.random as npr
 import torch
 import torch.nn as nn
 
+from ..hip import binding
 from ..hip import layers as L
 from ..hip import ops
 
@@ -118,7 +119,7 @@ class GEGLU(nn.Module, L._Packed):
             n = self.dim_out
             w = L._dev16(self.proj.weight)
             b = L._dev16(self.proj.bias)
-            gr = 2 if (2 * n) % 160 == 0 else 32  # packing granularity of the kernel serving this N (pfd_hip.h)
+            gr = int(binding.load().pfd_gemm_geglu_group(2 * n))  # packing granularity of the kernel serving this N
             wi = torch.stack([w[:n].view(n // gr, gr, -1), w[n:].view(n // gr, gr, -1)], 1).reshape(2 * n, -1)
             bi = torch.stack([b[:n].view(n // gr, gr), b[n:].view(n // gr, gr)], 1).reshape(2 * n)
             return wi.contiguous(), bi.contiguous()

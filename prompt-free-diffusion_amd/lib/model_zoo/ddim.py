@@ -112,6 +112,10 @@ class DDIMSampler(object):
         uc = c_info.get('unconditional_conditioning', None)
         cond = c_info['conditioning']
         cfg = not ((scale == 1.) or (uc is None))
+        if cfg and uc.shape[0] == 1 and cond.shape[0] > 1:
+            # app.py:239-241 loads ONE fixed unconditional context (SeeCoder-Anime) whatever n_samples is; the
+            # reference's torch.cat below then fails for n_samples > 1 -- broadcast it instead
+            uc = uc.expand(cond.shape[0], -1, -1)
         c_in = torch.cat([uc, cond]) if cfg else cond   # uncond first, like ddim.py:147
         c_info['c'] = c_in
         # all-zero unconditional context (SeeCoder / SeeCoder-PA, app.py:236): its cross-attention is

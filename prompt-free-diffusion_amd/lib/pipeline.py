@@ -115,11 +115,47 @@ class _GraphedStage:
         return out.clone()
 
 
+class _Marks:
+    """stage boundaries of one request: HIP events on a GPU model, wall clock otherwise (CPU tests)"""
+
+    def __init__(self, on_gpu):
+        self.on_gpu, self.t = on_gpu, []
+
+    def mark(self):
+        if self.on_gpu:
+            e = torch.cuda.Event(enable_timing=True)
+            e.record()
+            self.t.append(e)
+        else:
+            import time
+            self.t.append(time.perf_counter())
+
+    def ms(self, i, j):
+        if self.on_gpu:
+            return self.t[i].elapsed_time(self.t[j])
+        return (self.t[j] - self.t[i]) * 1e3
+
+
+def max_over_ranks(seconds, world_size, device='cpu'):
+    """the timing reduction of bench.py: a step is as slow as its slowest rank"""
+    if world_size == 1:
+        return float(seconds)
+    import torch.distributed as dist
+    t = torch.tensor([float(seconds)], device=device, dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
 class PromptFreePipeline:
-    def __init__(self, net, rank=0, world_size=1):
-        from .model_zoo.ddim import DDIMSampler
+    """One rank's view of a (possibly multi-GPU) request: shard -> encode -> DDIM loop -> decode -> gather.
+    `sampler` is injectable (the gloo CPU tests drive this very code with a stand-in for the GPU compute)."""
+
+    def __init__(self, net, rank=0, world_size=1, sampler=None):
         self.net = net
-        self.sampler = DDIMSampler(net)
+        if sampler is None:
+            from .model_zoo.ddim import DDIMSampler
+            sampler = DDIMSampler(net)
+        self.sampler = sampler
         self.rank, self.world_size = rank, world_size
         self._ctx_stage = self._vae_stage = self._stages = None
 
@@ -143,20 +179,22 @@ class PromptFreePipeline:
     @serialised
     @torch.no_grad()
     def generate(self, image, n_global, height, width, steps=50, scale=2.0, eta=0.0, seed=20, control=None,
-                 uncond=None, decode=True, gather=False, verbose=False, timings=None):
-        """returns (images [n_local|n_global, 3, H, W] in [0,1] or latents, latents [n_local,4,h,w])"""
+                 uncond=None, decode=True, gather=False, verbose=False, timings=None, as_uint8=False):
+        """returns (images, latents [n_local,4,h,w]); images = [n_local | n_global (gather), 3, H, W] in [0,1]
+        in the model dtype, or -- as_uint8 -- packed uint8 [n, H, W, 3] (the bytes ToPILImage would produce,
+        app.py:273-275; 4x fewer bytes through the all-gather); decode=False returns the latents twice"""
         P, r = self.world_size, self.rank
-        ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)] if timings is not None else None
-        if ev:
-            ev[0].record()
+        dev = self.net.device
+        mk = _Marks(torch.device(dev).type == 'cuda') if timings is not None else None
+        if mk:
+            mk.mark()
         xT = shard_xT(n_global, height, width, seed, r, P)
         n = xT.shape[0]
-        dev = self.net.device
         cond, zeros = self.encode_reference(image.to(dev), n)
         if uncond is None:
             uncond = zeros
-        if ev:
-            ev[1].record()
+        if mk:
+            mk.mark()
         x_info = {'type': 'image', 'xt': xT.to(dev)}
         c_info = {'type': 'image', 'conditioning': cond, 'unconditional_conditioning': uncond,
                   'unconditional_guidance_scale': scale}
@@ -164,16 +202,19 @@ class PromptFreePipeline:
             c_info['control'] = control.to(dev)
         x, _ = self.sampler.sample(steps=steps, shape=list(xT.shape), x_info=x_info, c_info=c_info, eta=eta,
                                    verbose=verbose)
-        if ev:
-            ev[2].record()
+        if mk:
+            mk.mark()
         if not decode:
             return x, x
-        img = self._vae_stage(x) if self._vae_stage is not None else self.net.vae_decode(x, 'image')
-        if ev:
-            ev[3].record()
-            torch.cuda.synchronize()
-            timings.update(ctx_encode_ms=ev[0].elapsed_time(ev[1]), ddim_loop_ms=ev[1].elapsed_time(ev[2]),
-                           vae_decode_ms=ev[2].elapsed_time(ev[3]))
+        if as_uint8:
+            img = self.net.vae_decode(x, 'image', out_uint8=True)
+        else:
+            img = self._vae_stage(x) if self._vae_stage is not None else self.net.vae_decode(x, 'image')
+        if mk:
+            mk.mark()
+            if mk.on_gpu:
+                torch.cuda.synchronize()
+            timings.update(ctx_encode_ms=mk.ms(0, 1), ddim_loop_ms=mk.ms(1, 2), vae_decode_ms=mk.ms(2, 3))
         if gather:
             img = all_gather_batch(img, P)
         return img, x
