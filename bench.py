@@ -36,12 +36,41 @@ MFMA_PEAK_TFLOPS = 2500.0   # dense fp16, MI355X_MICROARCH.md
 HBM_PEAK_GBS = 8000.0
 
 
+def _pick_cpu_threads():
+    """thread count for the CPU baseline: quick sweep of a proxy of the UNet's hot ops (3x3 conv at 64^2 and
+    a materialised-attention matmul) -- all the host's cores is often NOT the fastest setting"""
+    import torch
+    import torch.nn.functional as F
+    ncpu = os.cpu_count() or 1
+    x, w = torch.randn(2, 320, 64, 64), torch.randn(320, 320, 3, 3)
+    q = torch.randn(16, 4096, 40)
+    cands = sorted({n for n in (8, 16, 32, 48, 64, 96, 128, ncpu) if n <= ncpu})
+    best, best_t, log = cands[0], float("inf"), {}
+    with torch.no_grad():
+        for n in cands:
+            torch.set_num_threads(n)
+            F.conv2d(x, w, padding=1)
+            t0 = time.perf_counter()
+            for _ in range(3):
+                F.conv2d(x, w, padding=1)
+                (q @ q.transpose(1, 2)).softmax(-1) @ q
+            dt = time.perf_counter() - t0
+            log[n] = round(dt, 3)
+            if dt < best_t:
+                best, best_t = n, dt
+    torch.set_num_threads(best)
+    return best, log
+
+
 def cpu_baseline(net, height, width, ddim_steps, scale):
-    """oracle on the host cores: 1 SeeCoder encode + 1 CFG UNet step (batch 2) + 1 VAE decode for ONE
-    image, extrapolated to the 50-step schedule (every step costs the same)."""
+    """CPU path on the host cores, same workload, bounded sample: 1 SeeCoder encode + 1 CFG UNet step
+    (batch 2) + 1 VAE decode for ONE image, extrapolated over the schedule (every step costs the same).
+    kind = "port": the reference itself is Python over /root/reference, which does not exist on the GPU box;
+    what runs here is oracle/pfd_oracle.py, the op-for-op restatement pinned to it by tests/test_oracle_golden.py
+    (same torch CPU kernels: F.conv2d, materialised softmax(QK^T)V, F.group_norm ...)."""
     import torch
     import pfd_oracle as O
-    threads = torch.get_num_threads()
+    threads, sweep = _pick_cpu_threads()
     sd = {k: v.detach().float().cpu() for k, v in net.state_dict().items()
           if k.startswith(("diffuser.image.", "vae.image.", "ctx.image."))}
     g = torch.Generator().manual_seed(1234)
@@ -60,8 +89,10 @@ def cpu_baseline(net, height, width, ddim_steps, scale):
     t_ctx, t_step, t_vae = t1 - t0, t2 - t1, t3 - t2
     per_image = t_ctx + ddim_steps * t_step + t_vae
     return {"value": 1.0 / per_image, "unit": "images/s", "cores": threads, "kind": "port",
+            "host_cpus": os.cpu_count(), "thread_sweep_s": sweep,
             "sample": f"1 image {height}x{width}: SeeCoder encode {t_ctx:.2f}s + 1 CFG UNet step (batch 2) "
-                      f"{t_step:.2f}s x{ddim_steps} (extrapolated) + VAE decode {t_vae:.2f}s, fp32 torch CPU"}
+                      f"{t_step:.2f}s x{ddim_steps} (extrapolated) + VAE decode {t_vae:.2f}s, fp32 torch CPU, "
+                      f"{threads} threads (best of a sweep)"}
 
 
 def main():
