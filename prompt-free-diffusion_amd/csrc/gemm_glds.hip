@@ -26,6 +26,8 @@
 // the packed weight stores x0 x1 g0 g1 | x2 x3 g2 g3 ..., a lane's four columns) -> + residual -> fp16.
 //
 // Algorithmic bytes / flops per launch: see pfd_prof_begin below (operands + result once; 2MNK).
+#include <type_traits>
+
 #include "pfd_common.h"
 
 namespace {
@@ -73,9 +75,17 @@ __device__ __forceinline__ void glds16(const void* src, void* lds_dst) {
 //  loop from 753 to 1046 ms; with sc1 / sc0+sc1 coherent slab accesses instead of fences, 685 -> 868 ms --
 //  the uncached slab round trip sits on the critical path of every tile's last block, while the reduce
 //  kernel streams the same data with 2048 blocks in ~11 us.)
+// Row stride (bytes) of the fp16 staging image of an output tile of `cols` columns: + 16 bytes makes the
+// 8-byte (4-byte for GEGLU) accumulator writes of 16 consecutive rows hit 16 distinct bank groups and keeps
+// every row 16-byte aligned for the ds_read_b128 of the store pass (cols = 160: 336 B = 84 dwords, row r
+// starts at bank 20 r mod 64; 128: 272 B -> 4 r; 80: 176 B -> 44 r mod 64; 64: 144 B -> 36 r mod 64).
+constexpr int stage_row_bytes(int cols) { return cols * 2 + 16; }
+
+// pass 1 (the waves that hold accumulators): returns true when the tile was staged in LDS and needs pass 2
 template <int WMB, int NT>
-__device__ __forceinline__ void epilogue160(const float4_t (&acc)[WMB][NT], const G160Params& p, int lane, int m0,
-                                            int n0, int wm, int wn, int split) {
+__device__ __forceinline__ bool epilogue_stage(const float4_t (&acc)[WMB][NT], const G160Params& p, int lane, int m0,
+                                               int n0, int wm, int wn, int split, char* smem) {
+  constexpr int BN = 32 * NT;
   const int l15 = lane & 15, g = lane >> 4;
   const int mw = m0 + wm * WMB * 16 + l15;   // + i*16: this lane's output row in row-tile i
   const int nw = n0 + wn * (16 * NT) + 4 * g;       // + j*16: first of this lane's 4 columns in column-tile j
@@ -89,7 +99,7 @@ __device__ __forceinline__ void epilogue160(const float4_t (&acc)[WMB][NT], cons
       for (int j = 0; j < NT; ++j)
         *reinterpret_cast<float4_t*>(p.ws + ((long)split * p.M + m) * p.N + nw + j * 16) = acc[i][j];
     }
-    return;
+    return false;
   }
 
   if (p.Ct && n0 >= p.n_split) {  // transposed tail (tile-uniform): Ct[(n - n_split) * ldct + m] (+ bias)
@@ -108,39 +118,17 @@ __device__ __forceinline__ void epilogue160(const float4_t (&acc)[WMB][NT], cons
         for (int r = 0; r < 4; ++r)   // 16 lanes = 16 consecutive m: 32-byte segments per output row
           p.Ct[(long)(nw + j * 16 + r - p.n_split) * p.ldct + m] = (half_t)(acc[i][j][r] + bv[j][r]);
     }
-    return;
+    return false;
   }
 
-  if (p.act == PFD_ACT_GEGLU) {
-    // packed weight rows come in groups of four: x(2c), x(2c+1), gate(2c), gate(2c+1) -- exactly the four
-    // columns a lane owns, so out(2c..2c+1) = x * gelu(gate) needs no exchange; a lane stores 2 halves and
-    // the four lanes of a row cover 16 contiguous bytes of the [M, N/2] output
-    float bv[NT][4];
-#pragma unroll
-    for (int j = 0; j < NT; ++j) {
-      Pack8 b;
-      b.u = make_uint2(0, 0);
-      if (p.bias) b.u = *reinterpret_cast<const uint2*>(p.bias + nw + j * 16);
-#pragma unroll
-      for (int r = 0; r < 4; ++r) bv[j][r] = (float)b.e[r];
-    }
-#pragma unroll
-    for (int i = 0; i < WMB; ++i) {
-      const int m = mw + i * 16;
-      if (m >= p.M) continue;
-      half_t* cp = p.C + (long)m * p.ldc + (nw >> 1);
-#pragma unroll
-      for (int j = 0; j < NT; ++j) {
-        half2_t o;
-        o[0] = (half_t)((acc[i][j][0] + bv[j][0]) * pfd_gelu(acc[i][j][2] + bv[j][2]));
-        o[1] = (half_t)((acc[i][j][1] + bv[j][1]) * pfd_gelu(acc[i][j][3] + bv[j][3]));
-        *reinterpret_cast<half2_t*>(cp + j * 8) = o;
-      }
-    }
-    return;
-  }
-
-  // ---- bias + per-sample row vector -> activation -> + residual -> fp16, straight from the accumulators ----
+  // ---- pass 1: bias + per-sample row vector -> activation (or GEGLU) in registers, fp16 into the LDS image ----
+  // (The accumulator layout gives a lane 4 consecutive columns of ONE row, 16 rows per instruction: stored to
+  //  HBM directly that is 16 scattered 32-byte segments per wave instruction -- 8-byte stores at 2.3 TB/s,
+  //  the GEGLU's 4-byte ones at 1.4 TB/s, measured; on the UNet's short-K linears that store pass was 40-60 %
+  //  of the launch (profiles/r02_ring_and_ablation.log).  Through LDS the stores are whole 16-byte chunks of
+  //  contiguous row segments and the residual is read the same way.)
+  const bool geglu = p.act == PFD_ACT_GEGLU;
+  const int lrow = wm * WMB * 16 + l15;
   float bv[NT][4];
 #pragma unroll
   for (int j = 0; j < NT; ++j) {
@@ -150,34 +138,89 @@ __device__ __forceinline__ void epilogue160(const float4_t (&acc)[WMB][NT], cons
 #pragma unroll
     for (int r = 0; r < 4; ++r) bv[j][r] = (float)b.e[r];
   }
+  if (geglu) {
+    // packed weight rows come in groups of four: x(2c), x(2c+1), gate(2c), gate(2c+1) -- exactly the four
+    // columns a lane owns, so out(2c..2c+1) = x * gelu(gate) needs no exchange
+    constexpr int RS = stage_row_bytes(BN / 2);
 #pragma unroll
-  for (int i = 0; i < WMB; ++i) {
-    const int m = mw + i * 16;
-    if (m >= p.M) continue;
-    Pack8 lv[NT], lr[NT];
-    const half_t* rvp = p.rowvec ? p.rowvec + (long)(m / p.rows_per_rv) * p.ldrv + nw : nullptr;
-    const half_t* rp = p.R ? p.R + (long)m * p.ldr + nw : nullptr;
+    for (int i = 0; i < WMB; ++i) {
+      char* sp = smem + (lrow + i * 16) * RS + (wn * (8 * NT) + 2 * g) * 2;
 #pragma unroll
-    for (int j = 0; j < NT; ++j) {   // all loads of the row first: one exposed latency per row tile
-      lv[j].u = lr[j].u = make_uint2(0, 0);
-      if (rvp) lv[j].u = *reinterpret_cast<const uint2*>(rvp + j * 16);
-      if (rp) lr[j].u = *reinterpret_cast<const uint2*>(rp + j * 16);
-    }
-    half_t* cp = p.C + (long)m * p.ldc + nw;
-#pragma unroll
-    for (int j = 0; j < NT; ++j) {
-      Pack8 o;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        float v = acc[i][j][r] + bv[j][r] + (float)lv[j].e[r];
-        if (p.act == PFD_ACT_GELU) v = pfd_gelu(v);
-        else if (p.act == PFD_ACT_RELU) v = fmaxf(v, 0.f);
-        else if (p.act == PFD_ACT_SILU) v = pfd_silu(v);
-        o.e[r] = (half_t)(v + (float)lr[j].e[r]);
+      for (int j = 0; j < NT; ++j) {
+        half2_t o;
+        o[0] = (half_t)((acc[i][j][0] + bv[j][0]) * pfd_gelu(acc[i][j][2] + bv[j][2]));
+        o[1] = (half_t)((acc[i][j][1] + bv[j][1]) * pfd_gelu(acc[i][j][3] + bv[j][3]));
+        *reinterpret_cast<half2_t*>(sp + j * 16) = o;
       }
-      *reinterpret_cast<uint2*>(cp + j * 16) = o.u;
+    }
+  } else {
+    constexpr int RS = stage_row_bytes(BN);
+#pragma unroll
+    for (int i = 0; i < WMB; ++i) {
+      const int m = mw + i * 16;
+      Pack8 lv[NT];
+      const half_t* rvp = (p.rowvec && m < p.M) ? p.rowvec + (long)(m / p.rows_per_rv) * p.ldrv + nw : nullptr;
+#pragma unroll
+      for (int j = 0; j < NT; ++j) {
+        lv[j].u = make_uint2(0, 0);
+        if (rvp) lv[j].u = *reinterpret_cast<const uint2*>(rvp + j * 16);
+      }
+      char* sp = smem + (lrow + i * 16) * RS + (wn * (16 * NT) + 4 * g) * 2;
+#pragma unroll
+      for (int j = 0; j < NT; ++j) {
+        Pack8 o;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float v = acc[i][j][r] + bv[j][r] + (float)lv[j].e[r];
+          if (p.act == PFD_ACT_GELU) v = pfd_gelu(v);
+          else if (p.act == PFD_ACT_RELU) v = fmaxf(v, 0.f);
+          else if (p.act == PFD_ACT_SILU) v = pfd_silu(v);
+          o.e[r] = (half_t)v;
+        }
+        *reinterpret_cast<uint2*>(sp + j * 32) = o.u;
+      }
     }
   }
+  return true;
+}
+
+// pass 2 (every thread of the block, after a barrier): + residual, 16-byte chunks of contiguous row segments
+template <int BM, int NT, int NTHREADS>
+__device__ __forceinline__ void epilogue_store(const G160Params& p, int m0, int n0, const char* smem, int tid) {
+  constexpr int BN = 32 * NT;
+  if (p.splits > 1 || (p.Ct && n0 >= p.n_split)) return;   // written directly by pass 1 (tile-uniform)
+  const bool geglu = p.act == PFD_ACT_GEGLU;
+  auto store_pass = [&](auto cols_tag) {
+    constexpr int COLS = decltype(cols_tag)::value;
+    constexpr int RS = stage_row_bytes(COLS);
+    constexpr int CPR = COLS / 8;   // 16-byte chunks per row
+    const int nc0 = geglu ? n0 / 2 : n0;
+    for (int c = tid; c < BM * CPR; c += NTHREADS) {
+      const int row = c / CPR, cc = c - row * CPR;
+      const int m = m0 + row;
+      if (m >= p.M) continue;
+      Pack16 v;
+      v.u = *reinterpret_cast<const uint4*>(smem + row * RS + cc * 16);
+      const long n = nc0 + cc * 8;
+      if (p.R) {
+        Pack16 r;
+        r.u = *reinterpret_cast<const uint4*>(p.R + (long)m * p.ldr + n);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v.e[e] = (half_t)((float)v.e[e] + (float)r.e[e]);
+      }
+      *reinterpret_cast<uint4*>(p.C + (long)m * p.ldc + n) = v.u;
+    }
+  };
+  if (geglu) store_pass(std::integral_constant<int, BN / 2>{});
+  else store_pass(std::integral_constant<int, BN>{});
+}
+
+template <int WMB, int NT, int NTHREADS>
+__device__ __forceinline__ void epilogue160(const float4_t (&acc)[WMB][NT], const G160Params& p, int lane, int m0,
+                                            int n0, int wm, int wn, int split, char* smem, int tid) {
+  epilogue_stage<WMB, NT>(acc, p, lane, m0, n0, wm, wn, split, smem);
+  __syncthreads();
+  epilogue_store<(NTHREADS / 128) * WMB * 16, NT, NTHREADS>(p, m0, n0, smem, tid);
 }
 
 template <int WAVES_M, int WMB, bool CONV, int NBUF, int NT>
@@ -194,6 +237,7 @@ __global__ __launch_bounds__(WAVES_M * 128) void gemm160_kernel(const G160Params
   constexpr int DEPTH = NBUF - 1;  // K tiles in flight ahead of the one being consumed
   static_assert(NBUF == 2 || B_INSTR % NW == 0, "counted vmcnt needs the same DMA count in every wave");
   static_assert(MAIN_BYTES <= 160 * 1024, "operand ring exceeds the 160 KiB LDS");
+  static_assert(BM * stage_row_bytes(BN) <= MAIN_BYTES, "the epilogue's staging image reuses the operand ring");
   constexpr int SMEM = MAIN_BYTES;
   static_assert(A_INSTR % NW == 0, "A tile must split evenly over the waves");
   __shared__ __attribute__((aligned(1024))) char smem[SMEM];
@@ -377,7 +421,188 @@ __global__ __launch_bounds__(WAVES_M * 128) void gemm160_kernel(const G160Params
     __syncthreads();  // the epilogue reuses the ring as staging space
   }
 
-  epilogue160<WMB, NT>(acc, p, lane, m0, n0, wm, wn, split);
+  epilogue160<WMB, NT, WAVES_M * 128>(acc, p, lane, m0, n0, wm, wn, split, smem, tid);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Wave-specialised form of the 256 x BN tile kernel: 8 consumer waves (the 4 x 2 MFMA layout above) that
+// never touch VMEM in the K loop + 4 loader waves (one per SIMD) that do nothing but issue the LDS-DMA pieces.
+// Why: on the kernel above, DMA-only (33 us) and MFMA-only (29 us) times of the GEGLU GEMM simply ADD to the
+// 59 us of the full K loop (profiles/r02_ring_and_ablation.log) -- a wave that is stuck in VMEM issue (a 1 KiB
+// LDS-DMA piece costs 100-185 issue cycles inside a busy phase) cannot issue its MFMAs, and since every wave
+// passes the same barrier, all eight are stuck at the same time, whether the pieces sit behind the barrier or
+// are interleaved with the MFMAs (both measured).  With the pieces on their own waves the consumers' issue
+// stream is ds_read + MFMA only.  52 (48) pieces per K tile = 13 (12) per loader.  One raw s_barrier per K
+// step for all 12 waves: loaders arrive after vmcnt(0) (their pieces of tile kt landed), consumers after the
+// MFMAs of tile kt - 1; then loaders refill the buffer the consumers just left.
+// ------------------------------------------------------------------------------------------------
+template <bool CONV, int NT>
+__global__ __launch_bounds__(768) void gemm160ws_kernel(const G160Params p) {
+  constexpr int WMB = 4, NCW = 8, NLW = 4;
+  constexpr int BN = 32 * NT, BM = 256;
+  constexpr int A_INSTR = BM / 8, B_INSTR = BN / 8;
+  constexpr int A_PL = A_INSTR / NLW, B_PL = B_INSTR / NLW;      // pieces per loader wave: 8 + 5 | 4
+  static_assert(A_INSTR % NLW == 0 && B_INSTR % NLW == 0, "pieces must split evenly over the loader waves");
+  constexpr int STAGE = (BM + BN) * ROWB;
+  constexpr int SMEM = 2 * STAGE;
+  static_assert(BM * stage_row_bytes(BN) <= SMEM, "the epilogue's staging image reuses the operand ring");
+  __shared__ __attribute__((aligned(1024))) char smem[SMEM];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int nblk = p.tiles_m * p.tiles_n;
+  const int t = xcd_remap(blockIdx.x, nblk);
+  const int tile_m = p.nmajor ? t % p.tiles_m : t / p.tiles_n;
+  const int tile_n = p.nmajor ? t / p.tiles_m : t - tile_m * p.tiles_n;
+  const int m0 = tile_m * BM;
+  const int n0 = tile_n * BN;
+  const int split = blockIdx.z;
+  const int kt_begin = split * p.kt_per_split;
+  const int kt_end = min(p.K / BK, kt_begin + p.kt_per_split);
+  const int nsteps = kt_end - kt_begin;
+
+  auto block_barrier = [&]() {
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+  };
+
+  if (wave >= NCW) {
+    // ================================ loader waves ================================
+    const int lw = wave - NCW;
+    const int srow = lane >> 3, cpos = lane & 7;
+    const half_t* a_ptr[A_PL];
+    int a_oy[A_PL], a_ox[A_PL];
+    long a_img[A_PL];
+    bool a_ok[A_PL];
+    int a_chunk[A_PL];
+#pragma unroll
+    for (int j = 0; j < A_PL; ++j) {
+      const int r = (lw + NLW * j) * 8 + srow;
+      const int c = cpos ^ ((r >> 1) & 7);
+      a_chunk[j] = c * 8;
+      const int m = m0 + r;
+      a_ok[j] = m < p.M;
+      if (CONV) {
+        const int hw = p.Ho * p.Wo;
+        const int b = m / hw;
+        const int rem = m - b * hw;
+        const int oy = rem / p.Wo;
+        a_oy[j] = oy * p.stride - p.pad;
+        a_ox[j] = (rem - oy * p.Wo) * p.stride - p.pad;
+        a_img[j] = (long)b * p.H * p.Wd * p.lda;
+        a_ptr[j] = p.A;
+      } else {
+        a_ptr[j] = a_ok[j] ? p.A + (long)m * p.lda + c * 8 : g_zero_page;
+        a_oy[j] = a_ox[j] = 0;
+        a_img[j] = 0;
+      }
+    }
+    const half_t* b_ptr[B_PL];
+#pragma unroll
+    for (int j = 0; j < B_PL; ++j) {
+      const int r = (lw + NLW * j) * 8 + srow;
+      const int c = cpos ^ ((r >> 1) & 7);
+      b_ptr[j] = p.W + (long)(n0 + r) * p.ldw + c * 8;
+    }
+    const int Hin = p.ups ? 2 * p.H : p.H;
+    const int Win = p.ups ? 2 * p.Wd : p.Wd;
+    int tap_ky = 0, tap_kx = 0, ci0 = 0;
+    if (CONV) {
+      const int k0 = kt_begin * BK;
+      const int tap = k0 / p.Cin;
+      ci0 = k0 - tap * p.Cin;
+      tap_ky = tap / p.ksize;
+      tap_kx = tap - tap_ky * p.ksize;
+    }
+    const half_t* a_tap[A_PL];
+    auto set_tap = [&]() {
+#pragma unroll
+      for (int j = 0; j < A_PL; ++j) {
+        int iy = a_oy[j] + tap_ky, ix = a_ox[j] + tap_kx;
+        const bool ok = a_ok[j] && iy >= 0 && iy < Hin && ix >= 0 && ix < Win;
+        if (p.ups) {
+          iy >>= 1;
+          ix >>= 1;
+        }
+        a_tap[j] = ok ? p.A + a_img[j] + ((long)iy * p.Wd + ix) * p.lda + a_chunk[j] : nullptr;
+      }
+    };
+    if (CONV) set_tap();
+    auto issue = [&](int stage, int kt) {
+      char* As = smem + stage * STAGE;
+      char* Bs = As + BM * ROWB;
+      const int k0 = kt * BK;
+#pragma unroll
+      for (int j = 0; j < A_PL; ++j) {
+        const half_t* src;
+        if (CONV) src = a_tap[j] ? a_tap[j] + ci0 : g_zero_page;
+        else src = a_ok[j] ? a_ptr[j] + k0 : a_ptr[j];
+        glds16(src, As + (lw + NLW * j) * 1024);
+      }
+#pragma unroll
+      for (int j = 0; j < B_PL; ++j) glds16(b_ptr[j] + k0, Bs + (lw + NLW * j) * 1024);
+      if (CONV) {
+        ci0 += BK;
+        if (ci0 >= p.Cin) {
+          ci0 = 0;
+          if (++tap_kx == p.ksize) {
+            tap_kx = 0;
+            ++tap_ky;
+          }
+          set_tap();
+        }
+      }
+    };
+    if (nsteps > 0) issue(0, kt_begin);
+    for (int s = 0; s < nsteps; ++s) {
+      __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): this wave's pieces of K tile s are in LDS
+      block_barrier();                      // (A) tile s complete; consumers are done with tile s - 1
+      if (s + 1 < nsteps) issue((s + 1) & 1, kt_begin + s + 1);
+    }
+    block_barrier();                        // (B) consumers finished the last tile: LDS is free
+    block_barrier();                        // (C) the staging image is written
+  } else {
+    // ================================ consumer waves ================================
+    const int wm = wave >> 1, wn = wave & 1;
+    const int l15 = lane & 15, g = lane >> 4;
+    float4_t acc[WMB][NT];
+#pragma unroll
+    for (int i = 0; i < WMB; ++i)
+#pragma unroll
+      for (int j = 0; j < NT; ++j) acc[i][j] = (float4_t){0.f, 0.f, 0.f, 0.f};
+    const int sw = (l15 >> 1) & 7;
+    const int off_k0 = ((0 + g) ^ sw) * 16 + l15 * ROWB;
+    const int off_k1 = ((4 + g) ^ sw) * 16 + l15 * ROWB;
+    const int a_row0 = wm * WMB * 16 * ROWB;
+    const int b_row0 = BM * ROWB + wn * (16 * NT) * ROWB;
+    for (int s = 0; s < nsteps; ++s) {
+      block_barrier();                      // (A)
+      const char* base = smem + (s & 1) * STAGE;
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        const int off = ks ? off_k1 : off_k0;
+        half8_t af[WMB], bf[NT];
+#pragma unroll
+        for (int i = 0; i < WMB; ++i)
+          af[i] = *reinterpret_cast<const half8_t*>(base + a_row0 + i * 16 * ROWB + off);
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+          bf[j] = *reinterpret_cast<const half8_t*>(base + b_row0 + j * 16 * ROWB + off);
+#pragma unroll
+        for (int i = 0; i < WMB; ++i)
+#pragma unroll
+          for (int j = 0; j < NT; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[j], af[i], acc[i][j], 0, 0, 0);
+      }
+    }
+    block_barrier();                        // (B)
+    epilogue_stage<WMB, NT>(acc, p, lane, m0, n0, wm, wn, split, smem);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    block_barrier();                        // (C)
+  }
+  epilogue_store<BM, NT, 768>(p, m0, n0, smem, tid);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -537,7 +762,7 @@ __global__ __launch_bounds__(512) void conv3x3_patch_kernel(const G160Params p) 
       }
     }
   }
-  epilogue160<WMB, 5>(acc, p, lane, m0, n0, wm, wn, split);
+  epilogue160<WMB, 5, 512>(acc, p, lane, m0, n0, wm, wn, split, smem, tid);
 }
 
 // sum the split-K slabs and apply the epilogue (bias, row vector, activation, residual)
@@ -614,6 +839,33 @@ int launch160(G160Params& p, int bucket, hipStream_t s) {
   }
   if (prof) pfd_prof_end(s);
   return pfd_check_launch("pfd_gemm_f16(wide)");
+}
+
+template <int NT>
+int launch160ws(G160Params& p, int bucket, hipStream_t s) {
+  p.tiles_m = (p.M + 255) / 256;
+  p.tiles_n = p.N / (32 * NT);
+  p.nmajor = pick_nmajor(p);
+  const int nk = p.K / BK;
+  p.kt_per_split = (nk + p.splits - 1) / p.splits;
+  p.splits = (nk + p.kt_per_split - 1) / p.kt_per_split;
+  dim3 grid(p.tiles_m * p.tiles_n, 1, p.splits);
+  const bool prof = pfd_prof_on();
+  if (prof) {
+    const double a_bytes = p.ksize > 0 ? 2.0 * p.B * p.H * p.Wd * p.Cin : 2.0 * p.M * p.K;
+    const double n_out = p.act == PFD_ACT_GEGLU ? p.N / 2 : p.N;
+    pfd_prof_begin(bucket, 2.0 * p.M * p.N * p.K, a_bytes + 2.0 * p.N * p.K + 2.0 * p.M * n_out * (p.R ? 2 : 1), s);
+  }
+  if (p.ksize > 0) hipLaunchKernelGGL((gemm160ws_kernel<true, NT>), grid, dim3(768), 0, s, p);
+  else hipLaunchKernelGGL((gemm160ws_kernel<false, NT>), grid, dim3(768), 0, s, p);
+  if (p.splits > 1) {
+    const long nvec = (long)p.M * (p.N / 8);
+    int g = (int)((nvec + 255) / 256);
+    if (g > 2048) g = 2048;
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(g), dim3(256), 0, s, p);
+  }
+  if (prof) pfd_prof_end(s);
+  return pfd_check_launch("pfd_gemm_f16(wave-specialised)");
 }
 
 int launch_patch(G160Params& p, hipStream_t s) {
@@ -709,13 +961,17 @@ int pfd_gemm160_try(const PfdGemmDesc* d, int variant, int splits, hipStream_t s
     const long t128 = tiles(128);
     const bool few = nk_all >= 16 ? t128 < 256 : t128 < 384;
     variant = tiles(256) >= 200 ? 44 : (nk_all <= 24 && few) ? 22 : 24;
+    // implicit-GEMM convolutions (stride 2, fused upsample, widths the patch kernel does not take) run long K loops
+    // of 53 KB stages: with the DMA pieces on four dedicated loader waves they gain 5-17 % (32768 x 640 x 5760
+    // upsample conv: 225 -> 192 us = 1260 TF); the short-K linears do not (profiles/r02_wave_specialised_ab.log)
+    if (variant == 44 && p.ksize > 0) variant = 48;
   }
-  const int bm = variant == 44 ? 256 : (variant == 24 || variant == 26) ? 128 : 64;
+  const int bm = (variant == 44 || variant == 48) ? 256 : (variant == 24 || variant == 26) ? 128 : 64;
   if (splits == 0) {
     splits = 1;
     const long tl = tiles(bm);
     const int nk = nk_all;
-    if (p.act != PFD_ACT_GEGLU && d->ws && variant == 44 && tl < 200 && nk >= 48 &&
+    if (p.act != PFD_ACT_GEGLU && d->ws && (variant == 44 || variant == 48) && tl < 200 && nk >= 48 &&
         (size_t)2 * p.M * p.N * 4 <= d->ws_bytes) {
       splits = 2;  // 128 tiles of 256x160: two K halves fill the chip (758 vs 579 TF at 640->640 @32^2)
     } else if (p.act != PFD_ACT_GEGLU && d->ws && variant == 24 && tl < 256) {
@@ -732,6 +988,10 @@ int pfd_gemm160_try(const PfdGemmDesc* d, int variant, int splits, hipStream_t s
   if (splits > 1 && (!d->ws || (size_t)splits * p.M * p.N * 4 > d->ws_bytes || p.act == PFD_ACT_GEGLU)) splits = 1;
   p.splits = splits;
   const int conv = p.ksize > 0 ? 1 : 0;
+  if (variant == 48) {   // 8 MFMA waves + 4 loader waves
+    if (bn == 128) return launch160ws<4>(p, 12 + 4 * conv, s) < 0 ? PFD_ELAUNCH : 0;
+    return launch160ws<5>(p, 12 + 4 * conv, s) < 0 ? PFD_ELAUNCH : 0;
+  }
   if (bn == 128) {
     switch (variant) {
       case 44: return launch160<4, 4, 2, 4>(p, 12 + 4 * conv, s) < 0 ? PFD_ELAUNCH : 0;
@@ -744,8 +1004,6 @@ int pfd_gemm160_try(const PfdGemmDesc* d, int variant, int splits, hipStream_t s
     case 44: return launch160<4, 4>(p, 12 + 4 * conv, s) < 0 ? PFD_ELAUNCH : 0;
     case 24: return launch160<2, 4>(p, 13 + 4 * conv, s) < 0 ? PFD_ELAUNCH : 0;
     case 22: return launch160<2, 2>(p, 14 + 4 * conv, s) < 0 ? PFD_ELAUNCH : 0;
-    case 26: return launch160<2, 4, 4>(p, 13 + 4 * conv, s) < 0 ? PFD_ELAUNCH : 0;  // 3 K tiles in flight
-    case 27: return launch160<2, 2, 5>(p, 14 + 4 * conv, s) < 0 ? PFD_ELAUNCH : 0;  // 4 K tiles in flight
     default: return PFD_EINVAL;
   }
 }

@@ -29,6 +29,26 @@ def test_gemm_bias_act_residual(M, N, K):
     close(y, ref)
 
 
+@pytest.mark.parametrize("M,N,K", [(1, 320, 1280), (301, 160, 192), (1184, 640, 768), (2500, 1280, 320),
+                                   (5000, 384, 64), (8192, 1920, 640), (70000, 320, 320)])
+def test_gemm_wave_specialised_variant(M, N, K):
+    """variant 48: 8 MFMA waves + 4 loader waves per block (ragged M, one tile, one K step, many tiles)"""
+    from lib.hip import ops
+    a, w, b, r = _dev(M, K), _dev(N, K, scale=K ** -0.5), _dev(N), _dev(M, N)
+    rv = _dev((M + 63) // 64, N)
+    tile = 1000 + 100 * 48
+    y = ops.gemm(a, w, bias=b, res=r, act=ops.ACT_SILU, rowvec=rv, rows_per_rv=64, tile=tile)
+    idx = torch.arange(M, device="cuda") // 64
+    ref = F.silu(a.float() @ w.float().t() + b.float() + rv.float()[idx]) + r.float()
+    close(y, ref, 4e-3)
+    y2 = ops.gemm(a, w, tile=tile)                       # no epilogue operands at all
+    close(y2, a.float() @ w.float().t(), 4e-3)
+    for _ in range(3):                                    # same launch again: no state left behind
+        assert torch.equal(ops.gemm(a, w, tile=tile), y2)
+    if K >= 256:
+        close(ops.gemm(a, w, bias=b, tile=tile + 2), a.float() @ w.float().t() + b.float(), 4e-3)   # split-K 2
+
+
 def test_gemm_geglu_and_strided_views():
     from lib.hip import ops
     from lib.model_zoo.attention import GEGLU

@@ -147,22 +147,23 @@ def _tile(variant, splits=0):
     return 1000 + 100 * variant + splits
 
 
-# (record filter, [(variant, splits)]): 44 = 256-row tiles, 24 = 128, 22 = 64, 99 = 3x3 patch kernel
+# (record filter, [(variant, splits)]): 44 = 256-row tiles, 24 = 128, 22 = 64, 99 = 3x3 patch kernel,
+# 48 = 256-row tiles with 4 dedicated loader waves
 FORCED = [
-    (dict(M=32768, N=320, K=2880, ks=3), [(99, 1), (99, 2), (44, 1), (44, 2), (24, 1), (22, 1)]),
+    (dict(M=32768, N=320, K=2880, ks=3), [(99, 1), (99, 2), (44, 1), (44, 2), (24, 1), (22, 1), (48, 1), (48, 2)]),
     (dict(M=32768, N=320, K=8640, ks=3), [(99, 1), (99, 4), (44, 1)]),
     (dict(M=8192, N=640, K=5760, ks=3, ups=0), [(99, 1), (99, 2), (99, 4), (44, 2), (24, 2), (22, 1)]),
     (dict(M=2048, N=1280, K=11520, ks=3, ups=0), [(99, 1), (99, 4), (99, 8), (24, 4), (24, 8), (22, 4)]),
     (dict(M=2048, N=1280, K=23040, ks=3), [(99, 8), (24, 8)]),
     (dict(M=512, N=1280, K=11520, ks=3, st=1), [(24, 8), (22, 4), (22, 1)]),
-    (dict(M=512, N=1280, K=11520, ks=3, st=2), [(24, 8), (22, 4)]),
-    (dict(M=32768, N=640, K=5760, ks=3, ups=1), [(44, 1), (24, 1)]),
+    (dict(M=512, N=1280, K=11520, ks=3, st=2), [(24, 8), (22, 4), (48, 8)]),
+    (dict(M=32768, N=640, K=5760, ks=3, ups=1), [(44, 1), (24, 1), (48, 1)]),
     (dict(M=8192, N=1280, K=11520, ks=3, ups=1), [(44, 2), (24, 2)]),
-    (dict(M=32768, N=2560, K=320, ks=0), [(44, 1), (24, 1), (22, 1)]),          # GEGLU
+    (dict(M=32768, N=2560, K=320, ks=0), [(44, 1), (24, 1), (22, 1), (48, 1)]),   # GEGLU
     (dict(M=2048, N=10240, K=1280, ks=0), [(44, 1), (24, 1)]),                  # GEGLU
     (dict(M=32768, N=320, K=1280, ks=0), [(44, 1), (24, 1), (22, 1)]),
-    (dict(M=32768, N=960, K=320, ks=0), [(44, 1), (24, 1), (22, 1)]),
-    (dict(M=8192, N=640, K=2560, ks=0), [(44, 1), (44, 2), (24, 2), (22, 1)]),
+    (dict(M=32768, N=960, K=320, ks=0), [(44, 1), (24, 1), (22, 1), (48, 1)]),
+    (dict(M=8192, N=640, K=2560, ks=0), [(44, 1), (44, 2), (24, 2), (22, 1), (48, 1), (48, 2)]),
     (dict(M=2048, N=1280, K=5120, ks=0), [(24, 4), (22, 2), (22, 4)]),
     (dict(M=512, N=1280, K=1280, ks=0), [(22, 1), (22, 4), (24, 2)]),
 ]
@@ -286,3 +287,22 @@ def test_unet_c5_shape_nonzero_uncond_vs_oracle(net, param_shapes):
     for s in (1, 2):
         ref = O.unet_apply(sd, "diffuser.image.", x[s:s + 1], t[s:s + 1], c[s:s + 1])
         check(f"C5 UNet eps sample {s} (96x96 latent)", eps[s:s + 1], ref)
+
+
+def test_wide_512x768_unet_and_vae_vs_oracle(net, param_shapes):
+    """app.py:197-207 lets H and W differ (any multiples of 64 in [512, 1536]): a 64 x 96 latent (non-square:
+    6144 tokens, image width 96 is not a patch-kernel width at the 64^2 level) -- UNet eps and the decoded
+    image against the oracle, not just finiteness"""
+    import pfd_oracle as O
+    _threads()
+    g = torch.Generator().manual_seed(21)
+    x = torch.randn((1, 4, 64, 96), generator=g)
+    cond = torch.randn((1, 148, 768), generator=g)
+    xx, t, c = torch.cat([x, x]), torch.full((2,), 401, dtype=torch.long), torch.cat([torch.zeros_like(cond), cond])
+    eps = net.apply_model({'type': 'image', 'x': xx.cuda().half()}, t.cuda(), {'type': 'image', 'c': c.cuda().half()})
+    ref = O.unet_apply(seeded_sd(param_shapes, "diffuser.image."), "diffuser.image.", xx[1:], t[1:], c[1:])
+    check("UNet eps at a 64x96 latent (512x768 image)", eps[1:], ref)
+    z = x * 0.9
+    img = net.vae_decode(z.cuda().half(), 'image')
+    assert img.shape == (1, 3, 512, 768)
+    check("VAE decode 512x768", img, O.vae_decode(seeded_sd(param_shapes, "vae.image."), "vae.image.", z))

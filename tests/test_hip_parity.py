@@ -284,6 +284,34 @@ def test_pipeline_graphed_stages_match_eager(net, golden):
     assert len(graphed._vae_stage.graphs) == 1
 
 
+def test_concurrent_requests_from_worker_threads(net, golden):
+    """Gradio calls `action_inference` from worker threads on ONE shared global model with no lock
+    (app.py:277, 405-410).  The HIP path shares per-device scratch (split-K slabs, packed-weight caches,
+    captured graphs): every public entry point serialises on lib.hip.ops.DEVICE_LOCK, so two requests
+    issued at the same time must each get exactly the result they get alone."""
+    import threading
+    from lib.pipeline import PromptFreePipeline
+    img = T(golden["see.img"])
+    pipe = PromptFreePipeline(net)
+    alone = [pipe.generate(img, 2, 64, 64, steps=3, scale=2.0, seed=s)[1].clone() for s in (11, 12, 13, 14)]
+    out, errs = {}, []
+
+    def worker(i, seed):
+        try:
+            for _ in range(2):
+                out[i] = pipe.generate(img, 2, 64, 64, steps=3, scale=2.0, seed=seed)[1].clone()
+        except Exception as e:   # noqa: BLE001
+            errs.append(e)
+    th = [threading.Thread(target=worker, args=(i, s)) for i, s in enumerate((11, 12, 13, 14))]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert not errs, errs
+    for i in range(4):
+        assert torch.equal(out[i], alone[i]), i
+
+
 def test_config_c1_end_to_end_vs_oracle(net, param_shapes):
     """BASELINE config C1 (256x256, 10-step DDIM, batch 1 -- the reference's own CPU-runnable case), whole
     pipeline: SeeCoder context -> 10 CFG steps -> VAE decode, HIP path vs the CPU oracle run on this host on
