@@ -29,8 +29,9 @@
 
 namespace {
 
-constexpr int KV_TILE = 64;
-constexpr int VT_LD = KV_TILE + 4;  // halfs; 136-B rows: conflict-free ds_read_b64 over 32 rows
+#ifndef ATT_ABL
+#define ATT_ABL 0   // measurement-only ablation bits: 1 no exp, 2 no PV MFMAs, 4 no K/V loads + staging, 8 no QK MFMAs
+#endif
 
 struct AttnParams {
   const half_t* Q;
@@ -43,8 +44,14 @@ struct AttnParams {
   float scale_log2;
 };
 
-template <int D>
-__global__ __launch_bounds__(256) void attention_kernel(const AttnParams p) {
+// Occupancy: D = 40 needs 136 VGPRs when left alone (3 waves per SIMD); asked for 4 waves per SIMD the
+// allocation fits 128 without scratch and self-attention at N = 4096 gains 4.6 % (452 -> 473 TF), the 148-key
+// cross-attention 16 % (profiles/r02_attention_ablation.log).  A 128-key tile (half the barriers, 62 KB LDS,
+// 184 VGPRs) measured 2 % slower.  Larger head dims keep their natural allocation.
+template <int D, int KV_TILE>
+__global__ __launch_bounds__(256, (D <= 40 ? 4 : 1)) void attention_kernel(const AttnParams p) {
+  constexpr int NU = KV_TILE / 32;    // 32-key halves per tile
+  constexpr int VT_LD = KV_TILE + 4;  // halfs; 136-B rows: conflict-free ds_read_b64 over 32 rows
   constexpr int DQK = (D + 15) / 16 * 16;
   constexpr int DV = (D + 31) / 32 * 32;
   constexpr int K_LD = DQK + 8;  // halfs; (DQK+8)*2 B is an odd multiple of 16 B for D in {40,80,96,160}
@@ -53,7 +60,7 @@ __global__ __launch_bounds__(256) void attention_kernel(const AttnParams p) {
   constexpr bool SUM_MFMA = DV > D;       // a spare V^T row carries the softmax denominator
   constexpr int KCH = D / 8;              // 16-B chunks per K row
   constexpr int K_CHUNKS = KV_TILE * KCH; // per tile
-  constexpr int V_CHUNKS = D * 8;
+  constexpr int V_CHUNKS = D * (KV_TILE / 8);
   constexpr int K_PT = (K_CHUNKS + 255) / 256;
   constexpr int V_PT = (V_CHUNKS + 255) / 256;
   constexpr int K_TILE_HALFS = KV_TILE * K_LD;
@@ -80,7 +87,7 @@ __global__ __launch_bounds__(256) void attention_kernel(const AttnParams p) {
   __syncthreads();
   if (SUM_MFMA) {
     for (int i = tid; i < 2 * KV_TILE; i += 256)
-      Vts[(i >> 6) * V_TILE_HALFS + D * VT_LD + (i & 63)] = (half_t)1.f;
+      Vts[(i / KV_TILE) * V_TILE_HALFS + D * VT_LD + (i % KV_TILE)] = (half_t)1.f;
   }
 
   // Q fragments: B operand, col = q = lane&31, k = d
@@ -125,7 +132,7 @@ __global__ __launch_bounds__(256) void attention_kernel(const AttnParams p) {
 #pragma unroll
     for (int j = 0; j < V_PT; ++j) {
       const int ch = tid + 256 * j;
-      const int d = ch >> 3, cc = ch & 7;
+      const int d = ch / (KV_TILE / 8), cc = ch % (KV_TILE / 8);
       vreg[j] = make_uint4(0, 0, 0, 0);
       if (ch < V_CHUNKS)   // key chunks past Nk are clamped (their P is 0); the ragged tile zeroes them below
         vreg[j] = *reinterpret_cast<const uint4*>(vbase + (long)d * p.ldvt + min(kv0 + cc * 8, v_last));
@@ -140,7 +147,7 @@ __global__ __launch_bounds__(256) void attention_kernel(const AttnParams p) {
     if (kv0 + KV_TILE > p.Nk) {  // ragged last tile only (wave-uniform)
 #pragma unroll
       for (int j = 0; j < V_PT; ++j) {
-        const int valid = p.Nk - (kv0 + ((tid + 256 * j) & 7) * 8);  // valid halfs in this 8-chunk
+        const int valid = p.Nk - (kv0 + ((tid + 256 * j) % (KV_TILE / 8)) * 8);  // valid halfs in this 8-chunk
         unsigned w[4] = {vreg[j].x, vreg[j].y, vreg[j].z, vreg[j].w};
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
@@ -159,7 +166,7 @@ __global__ __launch_bounds__(256) void attention_kernel(const AttnParams p) {
 #pragma unroll
     for (int j = 0; j < V_PT; ++j) {
       const int ch = tid + 256 * j;
-      const int d = ch >> 3, cc = ch & 7;
+      const int d = ch / (KV_TILE / 8), cc = ch % (KV_TILE / 8);
       if (ch < V_CHUNKS) {
         uint2* dst = reinterpret_cast<uint2*>(Vd + d * VT_LD + cc * 8);
         dst[0] = make_uint2(vreg[j].x, vreg[j].y);
@@ -175,29 +182,30 @@ __global__ __launch_bounds__(256) void attention_kernel(const AttnParams p) {
     const half_t* Vt = Vts + stage * V_TILE_HALFS;
 
     // ---- S^T = K . Q^T for the two 32-key halves of the tile ----
-    float16_t st[2];
+    float16_t st[NU];
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {
+    for (int u = 0; u < NU; ++u) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) st[u][r] = 0.f;
       const half_t* kp = Kt + (u * 32 + l31) * K_LD + hi * 8;
 #pragma unroll
       for (int s = 0; s < NS; ++s) {
         const half8_t kf = *reinterpret_cast<const half8_t*>(kp + s * 16);
-        st[u] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[s], st[u], 0, 0, 0);
+        if (!(ATT_ABL & 8)) st[u] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[s], st[u], 0, 0, 0);
+        else st[u][s] += (float)kf[0] * (float)qf[s][0];
       }
     }
     // ---- online softmax over this tile's 64 keys ----
     if (kv0 + KV_TILE > p.Nk) {  // ragged last tile: keys past Nk never win the max nor add weight
 #pragma unroll
-      for (int u = 0; u < 2; ++u)
+      for (int u = 0; u < NU; ++u)
 #pragma unroll
         for (int r = 0; r < 16; ++r)
           if (kv0 + u * 32 + mfma32_row(r, hi) >= p.Nk) st[u][r] = -INFINITY;
     }
     float mx = st[0][0];
 #pragma unroll
-    for (int u = 0; u < 2; ++u)
+    for (int u = 0; u < NU; ++u)
 #pragma unroll
       for (int r = 0; r < 16; ++r) mx = fmaxf(mx, st[u][r]);
     mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
@@ -213,14 +221,14 @@ __global__ __launch_bounds__(256) void attention_kernel(const AttnParams p) {
     }
     const float mc = m_run * c;
     float rs = 0.f;
-    half8_t pf[2][2];
+    half8_t pf[NU][2];
 #pragma unroll
-    for (int u = 0; u < 2; ++u)
+    for (int u = 0; u < NU; ++u)
 #pragma unroll
       for (int bb = 0; bb < 2; ++bb)
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-          const float e = __builtin_amdgcn_exp2f(fmaf(st[u][bb * 8 + j], c, -mc));
+          const float e = (ATT_ABL & 1) ? fmaf(st[u][bb * 8 + j], c, -mc) : __builtin_amdgcn_exp2f(fmaf(st[u][bb * 8 + j], c, -mc));
           if (!SUM_MFMA) rs += e;
           pf[u][bb][j] = (half_t)e;
         }
@@ -234,7 +242,7 @@ __global__ __launch_bounds__(256) void attention_kernel(const AttnParams p) {
     for (int i = 0; i < ND; ++i) {
       const half_t* vp = Vt + (i * 32 + l31) * VT_LD + 4 * hi;
 #pragma unroll
-      for (int u = 0; u < 2; ++u)
+      for (int u = 0; u < NU; ++u)
 #pragma unroll
         for (int bb = 0; bb < 2; ++bb) {
           const half4_t lo4 = *reinterpret_cast<const half4_t*>(vp + u * 32 + bb * 16);
@@ -242,7 +250,8 @@ __global__ __launch_bounds__(256) void attention_kernel(const AttnParams p) {
           half8_t vf;
           vf[0] = lo4[0]; vf[1] = lo4[1]; vf[2] = lo4[2]; vf[3] = lo4[3];
           vf[4] = hi4[0]; vf[5] = hi4[1]; vf[6] = hi4[2]; vf[7] = hi4[3];
-          o_acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf[u][bb], o_acc[i], 0, 0, 0);
+          if (!(ATT_ABL & 2)) o_acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf[u][bb], o_acc[i], 0, 0, 0);
+          else o_acc[i][0] += (float)pf[u][bb][0] + (float)vf[0];
         }
     }
   };
@@ -256,9 +265,9 @@ __global__ __launch_bounds__(256) void attention_kernel(const AttnParams p) {
   __syncthreads();
   for (int t = 0; t < ntiles; ++t) {
     const int stage = t & 1;
-    if (t + 1 < ntiles) load_tile(kregA, vregA, (t + 1) * KV_TILE);  // in flight during this tile's MFMAs
+    if (t + 1 < ntiles && !(ATT_ABL & 4)) load_tile(kregA, vregA, (t + 1) * KV_TILE);  // in flight during this tile's MFMAs
     compute_tile(t, stage);
-    if (t + 1 < ntiles) store_tile(kregA, vregA, stage ^ 1, (t + 1) * KV_TILE);
+    if (t + 1 < ntiles && !(ATT_ABL & 4)) store_tile(kregA, vregA, stage ^ 1, (t + 1) * KV_TILE);
     __syncthreads();
   }
 
@@ -296,7 +305,7 @@ int launch(const AttnParams& p, hipStream_t s) {
   if (prof)
     pfd_prof_begin(8, 4.0 * p.B * p.H * (double)p.Nq * p.Nk * D,
                    2.0 * p.B * p.H * D * (2.0 * p.Nq + 2.0 * p.Nk), s);
-  hipLaunchKernelGGL((attention_kernel<D>), grid, dim3(256), 0, s, p);
+  hipLaunchKernelGGL((attention_kernel<D, 64>), grid, dim3(256), 0, s, p);
   if (prof) pfd_prof_end(s);
   return pfd_check_launch("pfd_attention_f16");
 }
