@@ -117,7 +117,7 @@ int pfd_gemm_f16(const PfdGemmDesc* d, pfd_stream_t stream);
  *   tile in {22, 21, 12, 11}: register-staged kernel, (64*TM) x (64*TN) x 64 tile, tile = 10*TM+TN
  *   tile = 1000 + 100*v + s : LDS-DMA wide-tile kernel (needs N % 160 == 0 or N % 128 == 0),
  *          v in {44, 24, 22} = 256 / 128 / 64 rows x (160 | 128) columns block tile (0 = heuristic;
- *          26, 27 = deeper operand rings of 24 / 22; 99 = the 3x3 patch kernel), split-K factor s in
+ *          48 = 256 rows with 4 dedicated LDS-DMA loader waves; 99 = the 3x3 patch kernel), split-K factor s in
  *          0..8 (0 = heuristic), e.g. 1000 + 4400 + 2 = 5402. */
 int pfd_gemm_f16_ex(const PfdGemmDesc* d, int32_t tile, pfd_stream_t stream);
 
@@ -140,6 +140,7 @@ int32_t pfd_gemm_geglu_group(int32_t N);
  * einsum and the two rearranges), xformers memory_efficient_attention :264, and
  * nn.MultiheadAttention's core in seecoder.py:133,186.
  * D in {40, 80, 96, 160}; ldq/ldk/ldo % 8 == 0, ldvt/vt_bs % 8 == 0; Nq, Nk arbitrary.
+ * Every V^T row must be readable up to the next multiple of 8 keys (the values there are masked).
  * ---------------------------------------------------------------------------------- */
 typedef struct PfdAttnDesc {
   const void* Q;

@@ -210,7 +210,7 @@ class MultiheadAttention(nn.MultiheadAttention, _Packed):
         q = ops.gemm(q_in, p["wq"], bias=p["bq"])
         k = ops.gemm(k_in, p["wk"], bias=p["bk"])
         Nk8 = _round_up(Nk, 8)
-        vt = torch.empty((Cd, Nk8), dtype=torch.float16, device=q.device)
+        vt = torch.zeros((Cd, Nk8), dtype=torch.float16, device=q.device)   # pad columns must be finite (pfd_hip.h)
         ops.gemm(p["wv"], v_in, bias=p["bv"], bias_per_row=True, out=vt[:, :Nk])
         o = ops.attention(q, k, vt, 1, H, Nq, Nk, D, D ** -0.5, ldq=Cd, ldk=Cd, ldvt=Nk8, q_bs=0, k_bs=0, vt_bs=0)
         return ops.gemm(o, p["wo"], bias=p["bo"], res=res)

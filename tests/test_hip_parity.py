@@ -293,13 +293,13 @@ def test_concurrent_requests_from_worker_threads(net, golden):
     from lib.pipeline import PromptFreePipeline
     img = T(golden["see.img"])
     pipe = PromptFreePipeline(net)
-    alone = [pipe.generate(img, 2, 64, 64, steps=3, scale=2.0, seed=s)[1].clone() for s in (11, 12, 13, 14)]
+    alone = [pipe.generate(img, 2, 64, 64, steps=4, scale=2.0, seed=s)[1].clone() for s in (11, 12, 13, 14)]
     out, errs = {}, []
 
     def worker(i, seed):
         try:
             for _ in range(2):
-                out[i] = pipe.generate(img, 2, 64, 64, steps=3, scale=2.0, seed=seed)[1].clone()
+                out[i] = pipe.generate(img, 2, 64, 64, steps=4, scale=2.0, seed=seed)[1].clone()
         except Exception as e:   # noqa: BLE001
             errs.append(e)
     th = [threading.Thread(target=worker, args=(i, s)) for i, s in enumerate((11, 12, 13, 14))]
