@@ -34,7 +34,7 @@ extern "C" {
 #define PFD_ESHAPE (-2)   /* shape outside what the kernels are built for           */
 #define PFD_ELAUNCH (-3)  /* hipGetLastError() != hipSuccess after the launch       */
 
-#define PFD_ABI_VERSION 4
+#define PFD_ABI_VERSION 5
 
 typedef void* pfd_stream_t; /* hipStream_t */
 
@@ -235,11 +235,12 @@ int pfd_timestep_embedding_f16(const int64_t* t, void* out, int32_t B, int32_t d
  * eps: NHWC f16 [nb*B, h, w, C] (uncond batch first; nb=1 -> e = s*eps, ddim.py:142-143)
  * x, x_prev, pred_x0: NCHW fp32 [B,C,h,w]; noise may be NULL (eta == 0).
  * coef: device fp32 [5] = {a_t, a_prev, sigma_t, sqrt(1-a_t), guidance scale}.
- * xin_next (may be NULL): NHWC f16 [nb*B,h,w,C] = x_prev duplicated nb times, i.e. the
- * next step's UNet input (ddim.py:145 fused). */
+ * xin_next (may be NULL): NHWC f16 [rep*B,h,w,C] = x_prev duplicated `rep` times: rep = nb is the
+ * next step's CFG-doubled UNet input (ddim.py:145 fused); rep = 1 when the UNet shares the layers in
+ * front of its first cross-attention between the two halves of the pair. */
 int pfd_cfg_ddim_step(const void* eps, int32_t nb, const float* x, const float* noise,
-                      const float* coef, float* x_prev, float* pred_x0, void* xin_next, int32_t B,
-                      int32_t C, int32_t h, int32_t w, pfd_stream_t stream);
+                      const float* coef, float* x_prev, float* pred_x0, void* xin_next, int32_t rep,
+                      int32_t B, int32_t C, int32_t h, int32_t w, pfd_stream_t stream);
 /* y = a + b (f16, fp32 add), n elements; b may be NULL (copy). */
 int pfd_add_f16(const void* a, const void* b, void* y, int64_t n, pfd_stream_t stream);
 /* y = alpha*a + beta*b (f16 storage, fp32 math), n elements; b may be NULL (y = alpha*a).  The

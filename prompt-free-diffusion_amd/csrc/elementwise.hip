@@ -91,7 +91,7 @@ __global__ void timestep_embedding_kernel(const int64_t* __restrict__ t, half_t*
 __global__ void cfg_ddim_kernel(const half_t* __restrict__ eps, int nb, const float* __restrict__ x,
                                 const float* __restrict__ noise, const float* __restrict__ coef,
                                 float* __restrict__ x_prev, float* __restrict__ pred_x0,
-                                half_t* __restrict__ xin_next, int B, int C, int h, int w) {
+                                half_t* __restrict__ xin_next, int rep, int B, int C, int h, int w) {
   const long n = (long)B * C * h * w;
   const float a_t = coef[0], a_prev = coef[1], sigma = coef[2], s1mat = coef[3], scale = coef[4];
   const float isq_at = 1.0f / sqrtf(a_t);
@@ -122,7 +122,7 @@ __global__ void cfg_ddim_kernel(const half_t* __restrict__ eps, int nb, const fl
     pred_x0[i] = p0;
     if (xin_next) {
       const half_t hv = (half_t)xp;
-      for (int r = 0; r < nb; ++r) xin_next[(long)r * n + ei] = hv;
+      for (int r = 0; r < rep; ++r) xin_next[(long)r * n + ei] = hv;
     }
   }
 }
@@ -274,13 +274,13 @@ extern "C" int pfd_timestep_embedding_f16(const int64_t* t, void* out, int32_t B
 }
 
 extern "C" int pfd_cfg_ddim_step(const void* eps, int32_t nb, const float* x, const float* noise, const float* coef,
-                                 float* x_prev, float* pred_x0, void* xin_next, int32_t B, int32_t C, int32_t h,
-                                 int32_t w, pfd_stream_t stream) {
+                                 float* x_prev, float* pred_x0, void* xin_next, int32_t rep, int32_t B, int32_t C,
+                                 int32_t h, int32_t w, pfd_stream_t stream) {
   if (!eps || !x || !coef || !x_prev || !pred_x0) return PFD_EINVAL;
-  if (nb < 1 || nb > 2 || B <= 0 || C <= 0 || h <= 0 || w <= 0) return PFD_EINVAL;
+  if (nb < 1 || nb > 2 || B <= 0 || C <= 0 || h <= 0 || w <= 0 || (xin_next && (rep < 1 || rep > 2))) return PFD_EINVAL;
   const long n = (long)B * C * h * w;
   hipLaunchKernelGGL(cfg_ddim_kernel, dim3(grid_for(n, 256)), dim3(256), 0, (hipStream_t)stream,
-                     (const half_t*)eps, nb, x, noise, coef, x_prev, pred_x0, (half_t*)xin_next, B, C, h, w);
+                     (const half_t*)eps, nb, x, noise, coef, x_prev, pred_x0, (half_t*)xin_next, rep, B, C, h, w);
   return pfd_check_launch("pfd_cfg_ddim_step");
 }
 

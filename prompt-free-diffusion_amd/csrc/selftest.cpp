@@ -480,7 +480,7 @@ static void run_elementwise() {
     std::vector<float> coef = {0.45f, 0.52f, 0.1f, sqrtf(1 - 0.45f), 2.0f};
     Dev<h16> de(eps), dxin(2 * n);
     Dev<float> dx(x), dn(nz), dc(coef), dxp(n), dp0(n);
-    int rc = pfd_cfg_ddim_step(de.p, 2, dx.p, dn.p, dc.p, dxp.p, dp0.p, dxin.p, B, C, h, w, nullptr);
+    int rc = pfd_cfg_ddim_step(de.p, 2, dx.p, dn.p, dc.p, dxp.p, dp0.p, dxin.p, 2, B, C, h, w, nullptr);
     auto gxp = dxp.get(), gp0 = dp0.get();
     auto gxin = dxin.get();
     std::vector<double> rxp(n), rp0(n), rxin(2 * n);

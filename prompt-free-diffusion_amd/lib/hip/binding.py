@@ -14,7 +14,7 @@ import os
 _LIB = None
 _LIB_PATH = os.path.normpath(os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "..", "libpfd_hip.so"))
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 ACT_NONE, ACT_GELU, ACT_RELU, ACT_SILU, ACT_GEGLU = 0, 1, 2, 3, 4
 
@@ -70,7 +70,7 @@ SIGNATURES = {
     "pfd_nhwc_to_nchw": (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _f32, _f32, _f32, _f32, _vp]),
     "pfd_im2col_f16": (_i32, [_vp, _i64, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
     "pfd_timestep_embedding_f16": (_i32, [_vp, _vp, _i32, _i32, _f32, _vp]),
-    "pfd_cfg_ddim_step": (_i32, [_vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp]),
+    "pfd_cfg_ddim_step": (_i32, [_vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp]),
     "pfd_add_f16": (_i32, [_vp, _vp, _vp, _i64, _vp]),
     "pfd_axpby_f16": (_i32, [_vp, _f32, _vp, _f32, _vp, _i64, _vp]),
     "pfd_add_rowvec_f16": (_i32, [_vp, _i64, _vp, _vp, _i64, _i32, _i32, _vp]),

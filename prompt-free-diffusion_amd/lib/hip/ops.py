@@ -351,15 +351,17 @@ def timestep_embedding(t, dim, max_period=10000.0):
     return out
 
 
-def cfg_ddim_step(eps, nb, x, coef, *, noise=None, want_next=True):
+def cfg_ddim_step(eps, nb, x, coef, *, noise=None, want_next=True, rep=None):
     """Fused CFG combine + DDIM update.  eps NHWC f16 [nb*B,h,w,C]; x NCHW fp32 [B,C,h,w];
-    coef fp32[5] device.  Returns (x_prev fp32 NCHW, pred_x0 fp32 NCHW, xin_next f16 NHWC|None)."""
+    coef fp32[5] device.  Returns (x_prev fp32 NCHW, pred_x0 fp32 NCHW, xin_next f16 NHWC|None);
+    xin_next holds `rep` copies of the batch (default nb: the CFG-doubled UNet input)."""
     B, Cc, h, w = x.shape
+    rep = nb if rep is None else rep
     x_prev = torch.empty_like(x)
     pred_x0 = torch.empty_like(x)
-    xin = torch.empty((nb * B, h, w, Cc), dtype=torch.float16, device=x.device) if want_next else None
+    xin = torch.empty((rep * B, h, w, Cc), dtype=torch.float16, device=x.device) if want_next else None
     rc = _lib().pfd_cfg_ddim_step(eps.data_ptr(), nb, x.data_ptr(), _ptr(noise), coef.data_ptr(), x_prev.data_ptr(),
-                                  pred_x0.data_ptr(), _ptr(xin), B, Cc, h, w, _stream())
+                                  pred_x0.data_ptr(), _ptr(xin), rep, B, Cc, h, w, _stream())
     _b.check(rc, "pfd_cfg_ddim_step")
     return x_prev, pred_x0, xin
 

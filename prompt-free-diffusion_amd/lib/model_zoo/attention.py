@@ -244,8 +244,12 @@ class BasicTransformerBlock(nn.Module):
         self.norm3 = L.LayerNorm(dim)
         self.checkpoint = checkpoint  # inference only: never used
 
-    def hip(self, x, B, N, context):
-        x = self.attn1.hip(self.norm1.hip(x), B, N, context if self.disable_self_attn else None, res=x)
+    def hip_self(self, x, B, N, context):
+        """x + attn1(LN(x)): the part of the block that does not see the context (unless disable_self_attn)"""
+        return self.attn1.hip(self.norm1.hip(x), B, N, context if self.disable_self_attn else None, res=x)
+
+    def hip_rest(self, x, B, N, context):
+        """cross-attention and feed-forward residual branches"""
         z = getattr(context, 'zero_lead', 0) if context is not None else 0
         if 0 < z < B:   # LayerNorm only feeds to_q: skip it for the zero-context samples too
             xn = torch.empty_like(x)
@@ -253,8 +257,10 @@ class BasicTransformerBlock(nn.Module):
             x = self.attn2.hip(xn, B, N, context, res=x)
         else:
             x = self.attn2.hip(self.norm2.hip(x), B, N, context, res=x)
-        x = self.ff.hip(self.norm3.hip(x), res=x)
-        return x
+        return self.ff.hip(self.norm3.hip(x), res=x)
+
+    def hip(self, x, B, N, context):
+        return self.hip_rest(self.hip_self(x, B, N, context), B, N, context)
 
     def forward(self, x, context=None):
         B, N, _ = x.shape
@@ -289,12 +295,24 @@ class SpatialTransformer(nn.Module):
         for p in self.proj_out.parameters():  # zero-initialised in the reference (attention.py:343-347)
             p.detach().zero_()
 
-    def hip(self, x, context=None):
-        """x: NHWC fp16 [B,H,W,C]; context: ContextKV | None"""
+    def hip(self, x, context=None, cfg_pair=False):
+        """x: NHWC fp16 [B,H,W,C]; context: ContextKV | None.
+        cfg_pair: x holds ONE copy of a classifier-free-guidance batch whose unconditional and conditional halves
+        are identical up to here (same latent, same timestep: ddim.py:145-149 `torch.cat([x] * 2)`); everything
+        before the first cross-attention -- GroupNorm, proj_in, self-attention -- is computed once and the batch
+        is doubled right before the context enters.  Returns the full (doubled) batch."""
         B, H, W_, Cc = x.shape
         N = H * W_
         h = self.proj_in.hip(self.norm.hip(x)).view(B * N, -1)
-        for blk in self.transformer_blocks:
+        blocks = list(self.transformer_blocks)
+        if cfg_pair:
+            if blocks[0].disable_self_attn:
+                raise ValueError("cfg_pair needs a context-free self-attention in the first block")
+            h = blocks[0].hip_self(h, B, N, context)
+            h, x, B = torch.cat([h, h]), torch.cat([x, x]), 2 * B      # the only two copies (21 MB each at 64^2)
+            h = blocks[0].hip_rest(h, B, N, context)
+            blocks = blocks[1:]
+        for blk in blocks:
             h = blk.hip(h, B, N, context)
         return self.proj_out.hip(h.view(B, H, W_, -1), res=x)
 

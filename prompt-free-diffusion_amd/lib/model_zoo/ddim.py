@@ -144,18 +144,23 @@ class DDIMSampler(object):
             # every sample of a step): [total_steps, sum Cout]
             emb_all, _ = model.diffuser[x_type].emb_projections(t_table[:, 0].contiguous())
             inter_xt, inter_x0 = [], []
-            xin = ops.to_nhwc(x, rep=nb)
+            # CFG: the UNet input is [x | x] with one timestep (:145-149); the layers in front of the first
+            # cross-attention give the same result for both halves and are run once (exact, see
+            # UNetModel2D_Next.hip): the step kernel then emits ONE fp16 copy of the next input
+            pair = nb == 2 and self.share_cfg_prefix
+            rep = 1 if pair else nb
+            xin = ops.to_nhwc(x, rep=rep)
             for i in range(total_steps):
                 index = total_steps - i - 1
                 eps = model.apply_model_nhwc(x_type, xin, t_table[i], c_type, ctx, control=ctl,
-                                             emb_table=emb_all[i:i + 1])
+                                             emb_table=emb_all[i:i + 1], cfg_pair=pair)
                 noise = None
                 if self.ddim_sigmas[index] != 0.:
                     noise = noise_like(x) * temperature
                     if noise_dropout > 0.:
                         noise = torch.nn.functional.dropout(noise, p=noise_dropout)
                     noise = noise.contiguous()
-                x, pred_x0, xin = ops.cfg_ddim_step(eps, nb, x, coef[index], noise=noise, want_next=True)
+                x, pred_x0, xin = ops.cfg_ddim_step(eps, nb, x, coef[index], noise=noise, want_next=True, rep=rep)
                 if index % log_every_t == 0 or index == total_steps - 1:
                     inter_xt.append(x)
                     inter_x0.append(pred_x0)
@@ -166,7 +171,8 @@ class DDIMSampler(object):
         use_graph = self.use_graph and not stochastic and callback is None and x.is_cuda
         if use_graph:
             key = (tuple(x.shape), tuple(c_in.shape), None if hint is None else tuple(hint.shape), total_steps,
-                   float(scale), nb, x_type, c_type, int(log_every_t), zero_lead, hash(np.asarray(timesteps).tobytes()),
+                   float(scale), nb, x_type, c_type, int(log_every_t), zero_lead, bool(self.share_cfg_prefix),
+                   hash(np.asarray(timesteps).tobytes()),
                    self._weights_signature())
             ent = self._graphs.get(key)
             if ent is None:
@@ -292,6 +298,7 @@ class DDIMSampler(object):
     use_graph = False
     _graphs = None
     zero_uncond_shortcut = True
+    share_cfg_prefix = True
 
     def enable_graph(self, on=True):
         """Replay the whole DDIM trajectory as one captured hipGraph (eta = 0 only).  The graph is

@@ -46,14 +46,14 @@ class TimestepBlock(nn.Module):
 class TimestepEmbedSequential(nn.Sequential, TimestepBlock):
     """Children get the time embedding / the context according to their kind."""
 
-    def hip(self, x, semb, context=None, x2=None, emb=None):
+    def hip(self, x, semb, context=None, x2=None, emb=None, cfg_pair=False):
         """semb: SiLU(time embedding) [B, 4C] or None when `emb` = (table [rows, sumC], {id(block): col}, shared)
         already holds every ResBlock's emb_layers output (UNetModel2D_Next.emb_projections)"""
         for layer in self:
             if isinstance(layer, ResBlock):
                 x, x2 = layer.hip(x, semb, x2=x2, emb=emb), None
             elif isinstance(layer, SpatialTransformer):
-                x = layer.hip(x, context)
+                x = layer.hip(x, context, cfg_pair=cfg_pair)
             elif isinstance(layer, nn.Sequential):  # UNet head: GN -> SiLU -> conv
                 x = layer[2].hip(layer[0].hip(x, silu=True))
             elif isinstance(layer, nn.SiLU):
@@ -337,26 +337,36 @@ class UNetModel2D_Next(nn.Module, L._Packed):
         w, bias, cols = self._emb_pack()
         return ops.gemm(self.silu_time_embedding(timesteps), w, bias=bias), cols
 
-    def hip(self, x, timesteps, context, control=None, context_net=None, emb_table=None):
+    def hip(self, x, timesteps, context, control=None, context_net=None, emb_table=None, cfg_pair=False):
         """The forward that pfd.apply_model defines (pfd.py:314-365, :466-528), NHWC fp16 in/out.
         control: list of 13 NHWC residuals from ControlNet (popped from the end) or None.
         context_net: the UNet that owns the context blocks (defaults to self).
         emb_table: optional [1, sum Cout] row of `emb_projections` valid for EVERY sample of the
-        batch (the sampler precomputes all steps at once); otherwise computed here per sample."""
+        batch (the sampler precomputes all steps at once); otherwise computed here per sample.
+        cfg_pair: x is ONE copy [B/2, ...] of a classifier-free-guidance batch [x | x] with a shared timestep
+        (what ddim.py:145-149 builds with torch.cat([x] * 2)): the layers in front of the first cross-attention
+        (stem conv, first ResBlock, first transformer's GroupNorm / proj_in / self-attention) give identical
+        results for both halves and run once; returns eps for the full batch [uncond | cond].  Exact."""
         cnet = self if context_net is None else context_net
         if emb_table is not None:
             emb = (emb_table, self._emb_pack()[2], True)
         else:
-            table, cols = self.emb_projections(timesteps)
+            table, cols = self.emb_projections(timesteps)     # one row per sample of the FULL batch
             emb = (table, cols, False)
         semb = None
         d_iter = iter(self.data_blocks)
+        pair = [bool(cfg_pair)]          # still running on one copy of the pair
         if isinstance(context, ContextMix):      # multi-context: every context layer mixes n transformers
+            if cfg_pair:
+                raise NotImplementedError("cfg_pair with multi-context mixing")
             c_iters = [iter(n.context_blocks) for n in context.nets]
             ctx_layer = lambda hh: context.mix([next(it) for it in c_iters], hh, semb)  # noqa: E731
         else:
             c_iter = iter(cnet.context_blocks)
-            ctx_layer = lambda hh: next(c_iter).hip(hh, semb, context)  # noqa: E731
+
+            def ctx_layer(hh):
+                p, pair[0] = pair[0], False
+                return next(c_iter).hip(hh, semb, context, cfg_pair=p)
         ccs = list(control) if control is not None else None
         hs = []
         h = x
@@ -366,7 +376,9 @@ class UNetModel2D_Next(nn.Module, L._Packed):
             elif ltype == 'c':
                 h = ctx_layer(h)
             else:
-                hs.append(h)
+                hs.append(torch.cat([h, h]) if pair[0] else h)   # a skip saved before the doubling: stored doubled
+        if pair[0]:
+            raise ValueError("cfg_pair: no context layer in the input half of this UNet")
         for ltype in self.m_order:
             h = next(d_iter).hip(h, semb, emb=emb) if ltype == 'd' else ctx_layer(h)
         if ccs is not None:

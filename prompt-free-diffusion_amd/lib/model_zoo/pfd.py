@@ -158,8 +158,10 @@ class PromptFreeDiffusion(nn.Module):
 
     @ops.serialised
     @torch.no_grad()
-    def apply_model_nhwc(self, x_type, x_nhwc, timesteps, c_type, context, control=None, emb_table=None):
-        """x_nhwc fp16 [B,h,w,C]; context ContextKV; -> eps NHWC fp16"""
+    def apply_model_nhwc(self, x_type, x_nhwc, timesteps, c_type, context, control=None, emb_table=None,
+                         cfg_pair=False):
+        """x_nhwc fp16 [B,h,w,C]; context ContextKV; -> eps NHWC fp16.
+        cfg_pair: x_nhwc is one copy [B/2,...] of a CFG batch [x | x] (see UNetModel2D_Next.hip)"""
         unet = self.diffuser[x_type]
         gnet = unet if self.global_layer_ptr is None else self.diffuser[self.global_layer_ptr]
         if gnet is not unet:
@@ -168,9 +170,10 @@ class PromptFreeDiffusion(nn.Module):
             if control is not None:
                 raise NotImplementedError("ControlNet with multi-context mixing (the reference has no such path)")
             return unet.hip(x_nhwc, timesteps, context, emb_table=emb_table)
-        ccs = self._control_residuals(x_nhwc, timesteps, context, control)
+        x_full = torch.cat([x_nhwc, x_nhwc]) if (cfg_pair and control is not None) else x_nhwc
+        ccs = self._control_residuals(x_full, timesteps, context, control)
         return unet.hip(x_nhwc, timesteps, context, control=ccs, context_net=self.diffuser[c_type],
-                        emb_table=emb_table)
+                        emb_table=emb_table, cfg_pair=cfg_pair)
 
     def prepare_context_mix(self, c_info_list, mixing_type='attention'):
         """[{'type', 'c', 'ratio'}] -> ContextMix with every context's K / V^T hoisted (pfd.py:366-386)"""

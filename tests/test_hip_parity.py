@@ -374,6 +374,34 @@ def test_tall_and_wide_resolutions(net, h, w):
     assert float(im.min()) >= 0.0 and float(im.max()) <= 1.0 and float(im.float().std()) > 1e-3
 
 
+def test_cfg_prefix_sharing_matches_the_doubled_batch(net, golden):
+    """The CFG batch is [x | x] with one timestep (ddim.py:145-149): stem conv, first ResBlock and the first
+    transformer's GroupNorm / proj_in / self-attention are the same for both halves, so the sampler runs them once
+    (`share_cfg_prefix`).  Same kernels and summation order per sample => the trajectory must agree with the
+    doubled-batch run to fp16 rounding of different tile choices (usually bit for bit); with and without ControlNet."""
+    from lib.model_zoo.ddim import DDIMSampler
+    cond = T(golden["see.ctx"]).cuda().half().repeat(2, 1, 1)
+    hint = T(golden["ctl.hint"]).cuda()
+
+    def run(share, control, shape):
+        s = DDIMSampler(net)
+        s.share_cfg_prefix = share
+        xT = torch.randn(shape, generator=torch.Generator().manual_seed(3))
+        c_info = {'type': 'image', 'conditioning': cond, 'unconditional_conditioning': torch.zeros_like(cond),
+                  'unconditional_guidance_scale': 2.0}
+        if control is not None:
+            c_info['control'] = control
+        x, _ = s.sample(steps=4, shape=shape, x_info={'type': 'image', 'xt': xT.cuda()}, c_info=c_info, eta=0.,
+                        verbose=False)
+        return x.float()
+
+    for control, shape in ((None, [2, 4, 8, 8]), (None, [2, 4, 32, 32]), (hint, [2, 4, 16, 24])):
+        a, b = run(True, control, shape), run(False, control, shape)
+        d = float((a - b).abs().max())
+        print(f"[parity] CFG prefix sharing vs doubled batch {shape} control={control is not None}: max|diff| {d:.2e}")
+        assert d <= 4e-3 * max(1.0, float(b.abs().max()))
+
+
 def test_zero_uncond_shortcut_is_exact(net, golden):
     """skipping cross-attention for the all-zero unconditional context must be bit-identical"""
     from lib.model_zoo.ddim import DDIMSampler
