@@ -312,6 +312,41 @@ def test_concurrent_requests_from_worker_threads(net, golden):
         assert torch.equal(out[i], alone[i]), i
 
 
+def test_serving_queue_batches_requests_and_matches_direct_calls(net, golden):
+    """lib.serving.PromptFreeServer: FIFO in front of the shared model; compatible queued requests share one DDIM
+    batch (each sample keeps its own SeeCoder context and x_T stream), results equal the direct per-request
+    calls; uint8 output = ToPILImage's arithmetic (app.py:273-275) on the float image"""
+    import threading
+    from lib.pipeline import PromptFreePipeline
+    from lib.serving import PromptFreeServer
+    img1, img2 = T(golden["see.img"]), T(golden["see2.img"])
+    srv = PromptFreeServer(net, use_graph=False, max_batch=4)
+    try:
+        gate = threading.Event()
+        srv.call(lambda n: gate.wait(30))                  # hold the worker so that the requests queue up
+        f1 = srv.submit(img1, 1, 64, 64, steps=4, seed=5, as_uint8=False)
+        f2 = srv.submit(img2, 2, 64, 64, steps=4, seed=6, as_uint8=False)
+        f3 = srv.submit(img1, 1, 64, 128, steps=4, seed=7)                     # other size: its own batch, uint8
+        f4 = srv.submit(img1, 1, 64, 100, steps=4)                              # rejected at submit time
+    except ValueError:
+        f4 = None
+    gate.set()
+    o1, o2, o3 = f1.result(120), f2.result(120), f3.result(120)
+    assert f4 is None and srv.batches == [3, 1]
+    pipe = PromptFreePipeline(net)
+    d1 = pipe.generate(img1, 1, 64, 64, steps=4, scale=2.0, seed=5)[0]
+    d2 = pipe.generate(img2, 2, 64, 64, steps=4, scale=2.0, seed=6)[0]
+    d3 = pipe.generate(img1, 1, 64, 128, steps=4, scale=2.0, seed=7)[0]
+    check("served request 1 vs direct call", o1, d1.float().cpu(), 5e-3)
+    check("served request 2 vs direct call", o2, d2.float().cpu(), 5e-3)
+    assert o3.dtype == torch.uint8 and o3.shape == (1, 64, 128, 3)
+    want = d3.mul(255).byte().permute(0, 2, 3, 1)          # torchvision ToPILImage: pic.mul(255).byte(), CHW -> HWC
+    assert int((o3.int() - want.int()).abs().max()) <= 1 and float((o3 == want).float().mean()) > 0.98
+    u8 = pipe.generate(img1, 1, 64, 128, steps=4, scale=2.0, seed=7, as_uint8=True)[0]
+    assert torch.equal(u8, want)                          # same latents -> identical bytes
+    srv.close()
+
+
 def test_config_c1_end_to_end_vs_oracle(net, param_shapes):
     """BASELINE config C1 (256x256, 10-step DDIM, batch 1 -- the reference's own CPU-runnable case), whole
     pipeline: SeeCoder context -> 10 CFG steps -> VAE decode, HIP path vs the CPU oracle run on this host on
