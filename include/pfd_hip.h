@@ -253,12 +253,14 @@ int pfd_axpby_f16(const void* a, float alpha, const void* b, float beta, void* y
 int pfd_add_rowvec_f16(const void* x, int64_t ldx, const void* v, void* y, int64_t ldy, int32_t R,
                        int32_t C, pfd_stream_t stream);
 
-/* NHWC f16 -> packed uint8 image(s) [B, H, W, C]: v = clamp(x*mul + add, 0, 1) rounded to f16, then
- * uint8(v * 255) with the f16 product truncated -- bit for bit what the reference's output stage does to
- * the decoded image: AutoencoderKL.decode's (x+1)/2 + clamp (autokl.py:47,53) followed by
- * torchvision's ToPILImage, i.e. `pic.mul(255).byte()` on the f16 tensor (app.py:273-275).  The
- * request front-end hands the bytes to the client without a float image ever leaving the device. */
-int pfd_image_u8_f16(const void* x, void* y, int64_t n, float mul, float add, pfd_stream_t stream);
+/* NHWC f16 -> packed uint8 image(s) [B, H, W, C]: v = clamp(x*mul + add, 0, 1), then uint8(v * 255)
+ * truncated -- bit for bit what the reference's output stage does to the decoded image:
+ * AutoencoderKL.decode's (x+1)/2 + clamp (autokl.py:47,53) followed by torchvision's ToPILImage, i.e.
+ * `pic.mul(255).byte()` (app.py:273-275).  f16_image != 0: the image tensor is fp16 (fp16 model, app.py
+ * default): v and the product v*255 are each rounded to f16 first, as on that tensor; 0: fp32 image.
+ * The request front-end hands the bytes to the client without a float image ever leaving the device. */
+int pfd_image_u8_f16(const void* x, void* y, int64_t n, float mul, float add, int32_t f16_image,
+                     pfd_stream_t stream);
 
 /* y = act(x) elementwise (act in NONE|GELU|RELU|SILU), n f16 elements.  The SiLU in front
  * of every ResBlock emb_layers Linear (openaimodel.py:217-218) applied once to the shared

@@ -202,8 +202,18 @@ __global__ void act_kernel(const half_t* __restrict__ x, half_t* __restrict__ y,
   }
 }
 
+// fp16 rounding that the compiler cannot elide: hipcc evaluates _Float16 expressions with excess (fp32) precision
+// and drops the intermediate narrowing, which changes 4 % of the bytes below (trunc(v * 255) vs trunc(f16(v * 255)))
+__device__ __forceinline__ float round_f16(float x) {
+  const unsigned short bits = __builtin_bit_cast(unsigned short, (half_t)x);
+  unsigned short b2;
+  asm volatile("v_mov_b32 %0, %1" : "=v"(b2) : "v"(bits));
+  return (float)__builtin_bit_cast(half_t, b2);
+}
+
 // 8 pixels-channels per thread: one 16-byte load, one 8-byte store
-__global__ void image_u8_kernel(const half_t* __restrict__ x, uint8_t* __restrict__ y, long n, float mul, float add) {
+__global__ void image_u8_kernel(const half_t* __restrict__ x, uint8_t* __restrict__ y, long n, float mul, float add,
+                                int f16_image) {
   const long nv = n / 8;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < nv; i += (long)gridDim.x * blockDim.x) {
     Pack16 p;
@@ -211,16 +221,19 @@ __global__ void image_u8_kernel(const half_t* __restrict__ x, uint8_t* __restric
     union { uint2 u; uint8_t b[8]; } o;
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
-      const half_t v = (half_t)fminf(fmaxf((float)p.e[e] * mul + add, 0.f), 1.f);   // the f16 image the reference holds
-      const half_t m = v * (half_t)255.f;                                          // f16 product (round to nearest even)
-      o.b[e] = (uint8_t)(float)m;                                                  // .byte(): truncation
+      float v = fminf(fmaxf((float)p.e[e] * mul + add, 0.f), 1.f);
+      if (f16_image) v = round_f16(v);                                 // the image tensor the reference holds (model dtype)
+      const float m = v * 255.f;                                       // pic.mul(255) in that dtype ...
+      o.b[e] = (uint8_t)(f16_image ? round_f16(m) : m);                // ... then .byte(): truncation
     }
     reinterpret_cast<uint2*>(y)[i] = o.u;
   }
   if (blockIdx.x == 0 && threadIdx.x < (n & 7)) {
     const long i = nv * 8 + threadIdx.x;
-    const half_t v = (half_t)fminf(fmaxf((float)x[i] * mul + add, 0.f), 1.f);
-    y[i] = (uint8_t)(float)(v * (half_t)255.f);
+    float v = fminf(fmaxf((float)x[i] * mul + add, 0.f), 1.f);
+    if (f16_image) v = round_f16(v);
+    const float m = v * 255.f;
+    y[i] = (uint8_t)(f16_image ? round_f16(m) : m);
   }
 }
 
@@ -315,11 +328,12 @@ extern "C" int pfd_add_rowvec_f16(const void* x, int64_t ldx, const void* v, voi
   return pfd_check_launch("pfd_add_rowvec_f16");
 }
 
-extern "C" int pfd_image_u8_f16(const void* x, void* y, int64_t n, float mul, float add, pfd_stream_t stream) {
+extern "C" int pfd_image_u8_f16(const void* x, void* y, int64_t n, float mul, float add, int32_t f16_image,
+                                pfd_stream_t stream) {
   if (!x || !y || n <= 0) return PFD_EINVAL;
   if ((reinterpret_cast<uintptr_t>(x) & 15) || (reinterpret_cast<uintptr_t>(y) & 7)) return PFD_EINVAL;
   hipLaunchKernelGGL(image_u8_kernel, dim3(grid_for(n / 8 + 1, 256)), dim3(256), 0, (hipStream_t)stream,
-                     (const half_t*)x, (uint8_t*)y, (long)n, mul, add);
+                     (const half_t*)x, (uint8_t*)y, (long)n, mul, add, f16_image);
   return pfd_check_launch("pfd_image_u8_f16");
 }
 

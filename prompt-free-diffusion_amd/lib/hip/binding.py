@@ -75,7 +75,7 @@ SIGNATURES = {
     "pfd_axpby_f16": (_i32, [_vp, _f32, _vp, _f32, _vp, _i64, _vp]),
     "pfd_add_rowvec_f16": (_i32, [_vp, _i64, _vp, _vp, _i64, _i32, _i32, _vp]),
     "pfd_act_f16": (_i32, [_vp, _vp, _i64, _i32, _vp]),
-    "pfd_image_u8_f16": (_i32, [_vp, _vp, _i64, _f32, _f32, _vp]),
+    "pfd_image_u8_f16": (_i32, [_vp, _vp, _i64, _f32, _f32, _i32, _vp]),
     "pfd_prof_enable": (_i32, [_i32]),
     "pfd_prof_read": (_i32, [_i32, C.POINTER(C.c_double), C.POINTER(_i64), C.POINTER(C.c_double),
                              C.POINTER(C.c_double)]),

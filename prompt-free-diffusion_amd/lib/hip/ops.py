@@ -331,14 +331,16 @@ def to_nchw(x, dtype=torch.float16, mul=1.0, add=0.0, lo=-65504.0, hi=65504.0):
     return out if out.dtype == dtype else out.to(dtype)
 
 
-def image_u8(x, mul=1.0, add=0.0):
-    """NHWC fp16 [B,H,W,C] -> uint8 [B,H,W,C]: uint8(f16(clamp(x*mul+add, 0, 1)) * 255), the reference's
-    ToPILImage arithmetic (app.py:273-275) on the device"""
+def image_u8(x, mul=1.0, add=0.0, f16_image=True):
+    """NHWC fp16 [B,H,W,C] -> uint8 [B,H,W,C]: uint8(clamp(x*mul+add, 0, 1) * 255), the reference's ToPILImage
+    arithmetic (app.py:273-275) on the device; f16_image: the image the reference would hold is fp16 (both the
+    image and the product are rounded to f16 before the truncation), else fp32"""
     _chk16(x, "image_u8 x")
     if not x.is_contiguous():
         raise ValueError("image_u8: dense NHWC expected")
     out = torch.empty(x.shape, dtype=torch.uint8, device=x.device)
-    _b.check(_lib().pfd_image_u8_f16(x.data_ptr(), out.data_ptr(), x.numel(), float(mul), float(add), _stream()),
+    _b.check(_lib().pfd_image_u8_f16(x.data_ptr(), out.data_ptr(), x.numel(), float(mul), float(add),
+                                     1 if f16_image else 0, _stream()),
              "pfd_image_u8_f16")
     return out
 

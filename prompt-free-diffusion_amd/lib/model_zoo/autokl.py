@@ -70,7 +70,7 @@ class AutoencoderKL(nn.Module):
         out_uint8: packed uint8 [B, H, W, 3] instead (the bytes `ToPILImage` would produce, app.py:273-275)"""
         h = self.decode_nhwc(ops.to_nhwc(z, mul=float(in_scale)))
         if out_uint8:
-            return ops.image_u8(h, mul=0.5, add=0.5)
+            return ops.image_u8(h, mul=0.5, add=0.5, f16_image=z.dtype == torch.float16)
         return ops.to_nchw(h, z.dtype, mul=0.5, add=0.5, lo=0.0, hi=1.0)
 
     def decode_nhwc(self, z_nhwc):
