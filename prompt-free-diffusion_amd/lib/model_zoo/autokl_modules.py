@@ -68,8 +68,13 @@ class ResnetBlock(nn.Module):
 
 
 class AttnBlock(nn.Module):
-    """single-head spatial self-attention with d = C = 512: scores via GEMM, scaled row softmax,
-    PV via GEMM against the transposed V the v-projection writes directly."""
+    """single-head spatial self-attention with d = C = 512 (autokl_modules.py:186-197): scores via GEMM, scaled
+    row softmax, PV via GEMM against the transposed V the v-projection writes directly.  The [N, N] score
+    matrix is materialised in fp16 -- NOT a flash kernel (the d = 512 accumulator does not fit the register
+    budget of pfd_attention_f16's one-wave-per-32-queries layout) -- but only for `ROWS` query rows at a time:
+    at the 36 864 tokens of a 1536^2 output that is 0.3 GB of scratch instead of the 2.7 GB per image the
+    reference materialises (in fp32).  The block is 34 of the decoder's 2514 GFLOP per 512^2 image."""
+    ROWS = 4096
 
     def __init__(self, in_channels):
         super().__init__()
@@ -92,10 +97,15 @@ class AttnBlock(nn.Module):
         vt = ops.gemm(wv, hn.view(B * N, Cc), bias=bv, bias_per_row=True)      # [C, B*N]
         o = torch.empty((B, N, Cc), dtype=torch.float16, device=x.device)
         scale = float(int(Cc) ** (-0.5))
+        rows = min(N, self.ROWS)
+        s = torch.empty((rows, N), dtype=torch.float16, device=x.device)        # one scratch for all chunks
         for b in range(B):
-            s = ops.gemm(q[b], k[b])                                            # [N, N] scores
-            p = ops.softmax_rows(s, scale, out=s)
-            ops.gemm(p, vt[:, b * N:(b + 1) * N], out=o[b])
+            for r0 in range(0, N, rows):
+                r1 = min(N, r0 + rows)
+                sc = s[:r1 - r0]
+                ops.gemm(q[b, r0:r1], k[b], out=sc)                              # scores of this row block
+                ops.softmax_rows(sc, scale, out=sc)
+                ops.gemm(sc, vt[:, b * N:(b + 1) * N], out=o[b, r0:r1])
         return self.proj_out.hip(o.view(B, H, W_, Cc), res=x)
 
 

@@ -146,15 +146,19 @@ class ControlNet(nn.Module):
                 h = layer.hip(h, act=ops.ACT_SILU if fuse_silu else ops.ACT_NONE)
         return PreparedHint(h)
 
-    def hip(self, x, hint, timesteps, context):
+    def hip(self, x, hint, timesteps, context, cfg_pair=False):
         """x NHWC fp16 [B,h,w,4]; hint NCHW tensor | PreparedHint; context ContextKV.
-        Returns the 13 residuals (NHWC fp16), to be popped from the end."""
+        Returns the 13 residuals (NHWC fp16), to be popped from the end.
+        cfg_pair: x is ONE copy [B/2,...] of a classifier-free-guidance batch [x | x] with a shared timestep: the
+        stem conv (+ hint), the first ResBlock and the first transformer's self-attention part run once
+        (UNetModel2D_Next.hip); `timesteps` and the returned residuals are for the full batch."""
         guided = self.prepare_hint(hint).feat
         t_emb = timestep_embedding(timesteps, self.model_channels)
         semb = self.time_embed[2].hip(self.time_embed[0].hip(t_emb, act=ops.ACT_SILU), act=ops.ACT_SILU)
         B = x.shape[0]
         outs = []
         h = x
+        pair = bool(cfg_pair)
         for i, (module, zero_conv) in enumerate(zip(self.input_blocks, self.zero_convs)):
             if i == 0:
                 conv = module[0]
@@ -171,6 +175,14 @@ class ControlNet(nn.Module):
                         ops.add(h[b:b + k], guided, out=h[b:b + k])
                 else:   # the reference's `h + guided_hint` raises a broadcast error here (controlnet.py:315)
                     raise ValueError(f"control hint batch {guided.shape[0]} does not broadcast to batch {B}")
+                o = zero_conv[0].hip(h)
+                outs.append(torch.cat([o, o]) if pair else o)
+                continue
+            if pair:
+                if not any(isinstance(m, SpatialTransformer) for m in module):
+                    raise ValueError("cfg_pair: the block after the stem has no transformer to double the batch in")
+                h = module.hip(h, semb, context, cfg_pair=True)       # leaves with the full batch
+                pair = False
             else:
                 h = module.hip(h, semb, context)
             outs.append(zero_conv[0].hip(h))

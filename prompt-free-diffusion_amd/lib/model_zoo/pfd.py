@@ -153,7 +153,7 @@ class PromptFreeDiffusion(nn.Module):
         request instead of once per step; `apply_model` accepts either form in c_info['c']."""
         return as_context_kv(c)
 
-    def _control_residuals(self, x_nhwc, timesteps, context, control):
+    def _control_residuals(self, x_nhwc, timesteps, context, control, cfg_pair=False):
         return None
 
     @ops.serialised
@@ -170,8 +170,7 @@ class PromptFreeDiffusion(nn.Module):
             if control is not None:
                 raise NotImplementedError("ControlNet with multi-context mixing (the reference has no such path)")
             return unet.hip(x_nhwc, timesteps, context, emb_table=emb_table)
-        x_full = torch.cat([x_nhwc, x_nhwc]) if (cfg_pair and control is not None) else x_nhwc
-        ccs = self._control_residuals(x_full, timesteps, context, control)
+        ccs = self._control_residuals(x_nhwc, timesteps, context, control, cfg_pair)
         return unet.hip(x_nhwc, timesteps, context, control=ccs, context_net=self.diffuser[c_type],
                         emb_table=emb_table, cfg_pair=cfg_pair)
 
@@ -219,7 +218,7 @@ class PromptFreeDiffusion_with_control(PromptFreeDiffusion):
         self.control_scales = [1.0] * 13  # never applied by the reference either (pfd.py:463)
         self.parameter_group['ctl'] = [self.ctl]
 
-    def _control_residuals(self, x_nhwc, timesteps, context, control):
+    def _control_residuals(self, x_nhwc, timesteps, context, control, cfg_pair=False):
         if control is None:
             return None
-        return self.ctl.hip(x_nhwc, control, timesteps, context)
+        return self.ctl.hip(x_nhwc, control, timesteps, context, cfg_pair=cfg_pair)
