@@ -765,6 +765,172 @@ __global__ __launch_bounds__(512) void conv3x3_patch_kernel(const G160Params p) 
   epilogue160<WMB, 5, 512>(acc, p, lane, m0, n0, wm, wn, split, smem, tid);
 }
 
+// ------------------------------------------------------------------------------------------------
+// Wave-specialised patch kernel: the 8 consumer waves of conv3x3_patch_kernel + 4 loader waves (one per SIMD)
+// that issue every LDS-DMA piece -- per tap 20 weight pieces (5 per loader) and, for the next channel block's
+// patch, slots [6 tap, 6 tap + 6) of its 50 pieces.  Same LDS layout, swizzles, barrier count (one per tap, all
+// 12 waves) and epilogue; the consumers' instruction stream is ds_read + MFMA only.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(768) void conv3x3_patch_ws_kernel(const G160Params p) {
+  constexpr int NCW = 8, NLW = 4, WMB = 4;
+  constexpr int PATCH_BYTES = PATCH_ROWS * ROWB;  // 51200
+  constexpr int WT_BYTES = BN * ROWB;             // 20480
+  constexpr int OFF_W = 2 * PATCH_BYTES;
+  constexpr int SMEM = OFF_W + 2 * WT_BYTES;      // 143360
+  constexpr int P_INSTR = PATCH_ROWS / 8;          // 50 DMA pieces per patch
+  __shared__ __attribute__((aligned(1024))) char smem[SMEM];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int nblk = p.tiles_m * p.tiles_n;
+  const int t = xcd_remap(blockIdx.x, nblk);
+  const int tile_m = p.nmajor ? t % p.tiles_m : t / p.tiles_n;
+  const int tile_n = p.nmajor ? t / p.tiles_m : t - tile_m * p.tiles_n;
+  const int m0 = tile_m * 256;
+  const int n0 = tile_n * BN;
+  const int split = blockIdx.z;
+  const int ncb = p.Cin / BK;
+  const int cb_begin = split * p.kt_per_split;
+  const int cb_end = min(ncb, cb_begin + p.kt_per_split);
+  const int W = p.Wd, H = p.H;
+  const int TH = 256 / W, PW = W + 2;
+  const int hw = H * W;
+  const int b = m0 / hw;
+  const int y0 = (m0 - b * hw) / W;
+  const int nsteps = (cb_end - cb_begin) * 9;
+
+  auto block_barrier = [&]() {
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+  };
+
+  if (wave >= NCW) {
+    // ================================ loader waves ================================
+    const int lw = wave - NCW;
+    const int srow = lane >> 3, cpos = lane & 7;
+    const int prow_count = (TH + 2) * PW;
+    const half_t* img = p.A + (long)b * hw * p.lda;
+    // patch piece q covers LDS rows 8 q .. 8 q + 7; this loader owns q = 6 tap + lw (all loaders) and
+    // q = 6 tap + 4 + lw (loaders 0-1), tap = 0..8, q < 50
+    auto piece_off = [&](int q) -> int {   // element offset of this lane's source chunk from `img`, -1 = zero padding
+      const int r = q * 8 + srow;
+      const int py = r / PW, px = r - py * PW;
+      const int y = y0 - 1 + py, x = px - 1;
+      const int c = (cpos - (r & ~1)) & 7;   // rotation swizzle of the patch rows
+      const bool ok = q < P_INSTR && r < prow_count && y >= 0 && y < H && x >= 0 && x < W;
+      return ok ? (int)((y * W + x) * p.lda + c * 8) : -1;
+    };
+    int off_a[9], off_b[9];
+#pragma unroll
+    for (int tp = 0; tp < 9; ++tp) {
+      off_a[tp] = piece_off(6 * tp + lw);
+      off_b[tp] = piece_off(6 * tp + 4 + lw);
+    }
+    auto issue_patch = [&](int buf, int cb, int q, int off) {
+      glds16(off >= 0 ? (const void*)(img + off + cb * BK) : (const void*)g_zero_page,
+             smem + buf * PATCH_BYTES + q * 1024);
+    };
+    const half_t* wp[5];
+#pragma unroll
+    for (int j = 0; j < 5; ++j) {
+      const int r = (lw + NLW * j) * 8 + srow;
+      const int c = cpos ^ ((r >> 1) & 7);
+      wp[j] = p.W + (long)(n0 + r) * p.ldw + c * 8;
+    }
+    auto issue_w = [&](int stage, int tap, int cb) {
+      const int k0 = tap * p.Cin + cb * BK;
+#pragma unroll
+      for (int j = 0; j < 5; ++j) glds16(wp[j] + k0, smem + OFF_W + stage * WT_BYTES + (lw + NLW * j) * 1024);
+    };
+    if (nsteps > 0) {
+#pragma unroll
+      for (int tp = 0; tp < 9; ++tp) {     // the whole first patch
+        if (6 * tp + lw < P_INSTR) issue_patch(0, cb_begin, 6 * tp + lw, off_a[tp]);
+        if (lw < 2 && 6 * tp + 4 + lw < P_INSTR) issue_patch(0, cb_begin, 6 * tp + 4 + lw, off_b[tp]);
+      }
+      issue_w(0, 0, cb_begin);
+    }
+    int stage = 0;
+    for (int cb = cb_begin; cb < cb_end; ++cb) {
+      const int pbuf = (cb - cb_begin) & 1;
+      const bool more = cb + 1 < cb_end;
+#pragma unroll
+      for (int tap = 0; tap < 9; ++tap) {
+        __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): this wave's pieces for this tap (and patch) are in LDS
+        block_barrier();                      // (A)
+        if (tap < 8) issue_w(stage ^ 1, tap + 1, cb);
+        else if (more) issue_w(stage ^ 1, 0, cb + 1);
+        if (more) {
+          if (6 * tap + lw < P_INSTR) issue_patch(pbuf ^ 1, cb + 1, 6 * tap + lw, off_a[tap]);
+          if (lw < 2 && 6 * tap + 4 + lw < P_INSTR) issue_patch(pbuf ^ 1, cb + 1, 6 * tap + 4 + lw, off_b[tap]);
+        }
+        stage ^= 1;
+      }
+    }
+    block_barrier();                          // (B) consumers finished the last tap: LDS is free
+    block_barrier();                          // (C) the staging image is written
+  } else {
+    // ================================ consumer waves ================================
+    const int wm = wave >> 1, wn = wave & 1;
+    const int l15 = lane & 15, g = lane >> 4;
+    int rbase[WMB];
+#pragma unroll
+    for (int i = 0; i < WMB; ++i) {
+      const int ql = wm * 64 + i * 16;
+      const int ty = ql / W, tx = ql - ty * W;
+      rbase[i] = ty * PW + tx + l15;
+    }
+    const int sw = (l15 >> 1) & 7;
+    const int boff0 = wn * 80 * ROWB + l15 * ROWB + (((0 + g) ^ sw) << 4);
+    const int boff1 = wn * 80 * ROWB + l15 * ROWB + (((4 + g) ^ sw) << 4);
+    float4_t acc[WMB][5];
+#pragma unroll
+    for (int i = 0; i < WMB; ++i)
+#pragma unroll
+      for (int j = 0; j < 5; ++j) acc[i][j] = (float4_t){0.f, 0.f, 0.f, 0.f};
+    int stage = 0;
+    for (int cb = cb_begin; cb < cb_end; ++cb) {
+      const char* patch = smem + ((cb - cb_begin) & 1) * PATCH_BYTES;
+      int toff = 0;
+#pragma nounroll
+      for (int ky = 0; ky < 3; ++ky) {
+#pragma nounroll
+        for (int kx = 0; kx < 3; ++kx) {
+          block_barrier();                    // (A)
+          const char* wt = smem + OFF_W + stage * WT_BYTES;
+#pragma unroll
+          for (int ks = 0; ks < 2; ++ks) {
+            half8_t af[WMB], bf[5];
+#pragma unroll
+            for (int i = 0; i < WMB; ++i) {
+              const int r = rbase[i] + toff;
+              af[i] = *reinterpret_cast<const half8_t*>(patch + r * ROWB + ((((ks * 4 + g) + (r & ~1)) & 7) << 4));
+            }
+            const int bo = ks ? boff1 : boff0;
+#pragma unroll
+            for (int j = 0; j < 5; ++j) bf[j] = *reinterpret_cast<const half8_t*>(wt + bo + j * 16 * ROWB);
+#pragma unroll
+            for (int i = 0; i < WMB; ++i)
+#pragma unroll
+              for (int j = 0; j < 5; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[j], af[i], acc[i][j], 0, 0, 0);
+          }
+          stage ^= 1;
+          toff += 1;
+        }
+        toff += PW - 3;
+      }
+    }
+    block_barrier();                          // (B)
+    epilogue_stage<WMB, 5>(acc, p, lane, m0, n0, wm, wn, split, smem);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    block_barrier();                          // (C)
+  }
+  epilogue_store<256, 5, 768>(p, m0, n0, smem, tid);
+}
+
 // sum the split-K slabs and apply the epilogue (bias, row vector, activation, residual)
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const G160Params p) {
   const long nvec = (long)p.M * (p.N / 8);
@@ -868,7 +1034,7 @@ int launch160ws(G160Params& p, int bucket, hipStream_t s) {
   return pfd_check_launch("pfd_gemm_f16(wave-specialised)");
 }
 
-int launch_patch(G160Params& p, hipStream_t s) {
+int launch_patch(G160Params& p, hipStream_t s, bool ws = false) {
   p.tiles_m = p.M / 256;
   p.tiles_n = p.N / BN;
   p.nmajor = pick_nmajor(p);
@@ -880,7 +1046,8 @@ int launch_patch(G160Params& p, hipStream_t s) {
   if (prof)
     pfd_prof_begin(19, 2.0 * p.M * p.N * p.K,
                    2.0 * p.B * p.H * p.Wd * p.Cin + 2.0 * p.N * p.K + 2.0 * p.M * p.N * (p.R ? 2 : 1), s);
-  hipLaunchKernelGGL(conv3x3_patch_kernel, grid, dim3(512), 0, s, p);
+  if (ws) hipLaunchKernelGGL(conv3x3_patch_ws_kernel, grid, dim3(768), 0, s, p);
+  else hipLaunchKernelGGL(conv3x3_patch_kernel, grid, dim3(512), 0, s, p);
   if (p.splits > 1) {
     const long nvec = (long)p.M * (p.N / 8);
     int g = (int)((nvec + 255) / 256);
@@ -929,7 +1096,7 @@ int pfd_gemm160_try(const PfdGemmDesc* d, int variant, int splits, hipStream_t s
   const int tn = p.N / bn;
   auto tiles = [&](int bm) { return (long)((p.M + bm - 1) / bm) * tn; };
   // 3x3 / s1 / p1 convolution on a 16-, 32- or 64-wide image: the patch kernel (variant 0 or 99)
-  if (bn == 160 && (variant == 0 || variant == 99) && p.ksize == 3 && p.stride == 1 && p.pad == 1 && !p.ups &&
+  if (bn == 160 && (variant == 0 || variant == 99 || variant == 98) && p.ksize == 3 && p.stride == 1 && p.pad == 1 && !p.ups &&
       (p.Wd == 16 || p.Wd == 32 || p.Wd == 64) && p.Ho == p.H && p.Wo == p.Wd && p.H % (256 / p.Wd) == 0 &&
       p.M % 256 == 0 && p.act != PFD_ACT_GEGLU) {
     const int ncb = p.Cin / BK;
@@ -945,9 +1112,12 @@ int pfd_gemm160_try(const PfdGemmDesc* d, int variant, int splits, hipStream_t s
     }
     if (splits > 1 && (!d->ws || (size_t)splits * p.M * p.N * 4 > d->ws_bytes)) splits = 1;
     p.splits = splits;
-    return launch_patch(p, s) < 0 ? PFD_ELAUNCH : 0;
+    // default: the wave-specialised form (4 loader waves): +4 ... 13 % on every patch-eligible conv of the UNet, most
+    // on the long-K ones (32768 x 320 x 8640: 149 -> 131 us = 1435 TF; profiles/r02_patch_ws_ab.log); 99 forces the
+    // 8-wave form
+    return launch_patch(p, s, variant != 99) < 0 ? PFD_ELAUNCH : 0;
   }
-  if (variant == 99) return 1;
+  if (variant == 99 || variant == 98) return 1;
   const bool auto_variant = variant == 0;
   const int nk_all = p.K / BK;
   if (auto_variant) {
@@ -961,6 +1131,12 @@ int pfd_gemm160_try(const PfdGemmDesc* d, int variant, int splits, hipStream_t s
     const long t128 = tiles(128);
     const bool few = nk_all >= 16 ? t128 < 256 : t128 < 384;
     variant = tiles(256) >= 200 ? 44 : (nk_all <= 24 && few) ? 22 : 24;
+    // round 2 (coalesced epilogue, cold replay of the sampler's launch list, profiles/r02_gemm_replay_variants.log):
+    // short-K linears on >= 8192 rows are epilogue / HBM bound: two co-resident 128-row blocks overlap one
+    // block's store pass with the other's K loop (GEGLU 32768x2560x320: 87 -> 79 us, qkv 8192x1920x640: 42 -> 35);
+    // mid-K problems with <= 256 tiles of 128 rows take 64-row tiles (8192x640x2560: 54 -> 46 us)
+    if (p.ksize == 0 && variant == 44 && p.M >= 8192 && nk_all <= 20) variant = 24;
+    if (p.ksize == 0 && variant == 24 && nk_all <= 40 && t128 <= 256 && tiles(64) >= 384) variant = 22;
     // implicit-GEMM convolutions (stride 2, fused upsample, widths the patch kernel does not take) run long K loops
     // of 53 KB stages: with the DMA pieces on four dedicated loader waves they gain 5-17 % (32768 x 640 x 5760
     // upsample conv: 225 -> 192 us = 1260 TF); the short-K linears do not (profiles/r02_wave_specialised_ab.log)

@@ -148,12 +148,12 @@ def _tile(variant, splits=0):
 
 
 # (record filter, [(variant, splits)]): 44 = 256-row tiles, 24 = 128, 22 = 64, 99 = 3x3 patch kernel,
-# 48 = 256-row tiles with 4 dedicated loader waves
+# 48 = 256-row tiles with 4 dedicated loader waves, 98 = the patch kernel with 4 loader waves
 FORCED = [
-    (dict(M=32768, N=320, K=2880, ks=3), [(99, 1), (99, 2), (44, 1), (44, 2), (24, 1), (22, 1), (48, 1), (48, 2)]),
-    (dict(M=32768, N=320, K=8640, ks=3), [(99, 1), (99, 4), (44, 1)]),
-    (dict(M=8192, N=640, K=5760, ks=3, ups=0), [(99, 1), (99, 2), (99, 4), (44, 2), (24, 2), (22, 1)]),
-    (dict(M=2048, N=1280, K=11520, ks=3, ups=0), [(99, 1), (99, 4), (99, 8), (24, 4), (24, 8), (22, 4)]),
+    (dict(M=32768, N=320, K=2880, ks=3), [(99, 1), (99, 2), (98, 1), (98, 2), (44, 1), (44, 2), (24, 1), (22, 1), (48, 1), (48, 2)]),
+    (dict(M=32768, N=320, K=8640, ks=3), [(99, 1), (99, 4), (98, 1), (44, 1)]),
+    (dict(M=8192, N=640, K=5760, ks=3, ups=0), [(99, 1), (99, 2), (99, 4), (98, 2), (98, 4), (44, 2), (24, 2), (22, 1)]),
+    (dict(M=2048, N=1280, K=11520, ks=3, ups=0), [(99, 1), (99, 4), (99, 8), (98, 1), (98, 8), (24, 4), (24, 8), (22, 4)]),
     (dict(M=2048, N=1280, K=23040, ks=3), [(99, 8), (24, 8)]),
     (dict(M=512, N=1280, K=11520, ks=3, st=1), [(24, 8), (22, 4), (22, 1)]),
     (dict(M=512, N=1280, K=11520, ks=3, st=2), [(24, 8), (22, 4), (48, 8)]),

@@ -1,6 +1,7 @@
 #!/usr/bin/env python
-"""Record the GEMM/conv launch list of ONE UNet forward at BASELINE config C2 (512x512, batch 4 -> UNet batch 8)
-into profiles/unet_c2_gemm_shapes.txt (PFD_TRACE_GEMM).  `selftest --replay` relaunches exactly these shapes in a
+"""Record the GEMM/conv launch list of ONE UNet forward at BASELINE config C2 (512x512, batch 4 -> UNet batch 8),
+exactly as the DDIM sampler runs it (zero-unconditional shortcut, shared embedding table, the layers in front of the
+first cross-attention run once for the CFG pair), into profiles/unet_c2_gemm_shapes.txt (PFD_TRACE_GEMM).  `selftest --replay` relaunches exactly these shapes in a
 torch-free process so rocprofv3 --pmc can count their HBM traffic (PMC on the python process crashes rocprofv3 here)."""
 import os
 import sys
@@ -25,13 +26,11 @@ ctx = net.prepare_context(c)
 ctx.zero_lead = B // 2   # the bench runs CFG with the all-zero unconditional context (app.py:236)
 unet = net.diffuser['image']
 emb_all, _ = unet.emb_projections(t[:1])
-xin = ops.to_nhwc(x)
-for k, v in list(ctx._kv.items()):
-    pass
+xin = ops.to_nhwc(x[:B // 2])     # ONE copy of the [x | x] pair
 # warm the context K/V cache and packed weights outside the recorded forward
-net.apply_model_nhwc('image', xin, t, 'image', ctx, emb_table=emb_all)
+net.apply_model_nhwc('image', xin, t, 'image', ctx, emb_table=emb_all, cfg_pair=True)
 torch.cuda.synchronize()
 open(out, "w").close()
-net.apply_model_nhwc('image', xin, t, 'image', ctx, emb_table=emb_all)
+net.apply_model_nhwc('image', xin, t, 'image', ctx, emb_table=emb_all, cfg_pair=True)
 torch.cuda.synchronize()
 print("wrote", out, sum(1 for _ in open(out)), "launches")

@@ -28,6 +28,9 @@ def bucket(name):
     if m:
         tile = {"44": "256x160", "24": "128x160", "22": "64x160"}[m.group(1) + m.group(2)]
         return f"gemm160_kernel<{m.group(1)},{m.group(2)}{',conv' if m.group(3) == 'true' else ''}>({tile})"
+    m = re.match(r"void gemm160ws_kernel<(true|false)", name)
+    if m:
+        return f"gemm160_kernel<4,4{',conv' if m.group(1) == 'true' else ''}>(256x160)"
     m = re.match(r"void gemm_conv_kernel<(\d), (\d), (true|false)>", name)
     if m:
         return f"gemm_conv_kernel<{m.group(1)},{m.group(2)},{m.group(3)}>"
