@@ -3,6 +3,8 @@
 // scaled row softmax.  All statistics in fp32; every global access is a 16-byte vector.
 //
 // GroupNorm algorithmic HBM bytes per element: 2 (stats read) + 2 (apply read) + 2 (write).
+#include <stdlib.h>
+
 #include "pfd_common.h"
 
 namespace {
@@ -512,7 +514,8 @@ extern "C" int pfd_groupnorm_f16(const void* x1, int32_t C1, int64_t ldx1, const
   const int RT = nvec < 256 ? 256 / nvec : 1;
   // aim for ~512 blocks over the chip, at least 4 row sweeps per block (every apply block re-reduces
   // its sample's nchunks x G partials, so nchunks stays moderate)
-  int nchunks = (512 + B - 1) / B;
+  static const int target_blocks = getenv("PFD_GN_BLOCKS") ? atoi(getenv("PFD_GN_BLOCKS")) : 512;
+  int nchunks = (target_blocks + B - 1) / B;
   const int max_by_rows = (HW + RT * 4 - 1) / (RT * 4);
   if (nchunks > max_by_rows) nchunks = max_by_rows;
   if (nchunks > GN_MAX_CHUNKS) nchunks = GN_MAX_CHUNKS;

@@ -34,7 +34,7 @@ def bucket(name):
     m = re.match(r"void gemm_conv_kernel<(\d), (\d), (true|false)>", name)
     if m:
         return f"gemm_conv_kernel<{m.group(1)},{m.group(2)},{m.group(3)}>"
-    if "conv3x3_patch_kernel" in name:
+    if "conv3x3_patch" in name:
         return "conv3x3_patch_kernel(256x160)"
     if "splitk_reduce_kernel" in name:
         return "splitk_reduce_kernel"

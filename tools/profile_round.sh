@@ -1,0 +1,19 @@
+#!/bin/bash
+# rocprofv3 evidence for one round: kernel-trace stats of the bench command + PMC passes (HBM traffic, SQ) over the
+# torch-free replay of the UNet launch list.   usage: tools/profile_round.sh <out dir under gpurun_out> <tag>
+set -u
+REPO=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+OUT=$REPO/gpurun_out/$1; TAG=$2
+mkdir -p $OUT; cd /tmp; export TMPDIR=/tmp
+S=$REPO/prompt-free-diffusion_amd/csrc/build/selftest
+L=$REPO/profiles/unet_c2_gemm_shapes.txt
+rocprofv3 --kernel-trace --stats -d $OUT/kt -o kt -- python $REPO/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-prof > $OUT/kt_bench.json 2> $OUT/kt.log
+rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $OUT/pmc_fetch -o f -- $S --replay $L > $OUT/pmc_fetch.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $OUT/pmc_write -o w -- $S --replay $L > $OUT/pmc_write.log 2>&1
+rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_VALU SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT --kernel-trace -d $OUT/pmc_sq -o q -- $S --replay $L > $OUT/pmc_sq.log 2>&1
+cd $REPO
+python tools/rocpd_stats.py $(find $OUT/kt -name '*results.db' | head -1) $OUT/${TAG}_rocprof_kernel_stats.md > /dev/null 2>&1
+python tools/pmc_bucket.py $(find $OUT/pmc_fetch -name '*results.db' | head -1) $(find $OUT/pmc_write -name '*results.db' | head -1) $OUT/pmc_traffic.json $OUT/${TAG}_pmc_traffic_per_bucket.md > $OUT/pmc_bucket.log 2>&1
+python tools/pmc_sq.py $(find $OUT/pmc_sq -name '*results.db' | head -1) $OUT/${TAG}_pmc_sq_gemm.md > /dev/null 2>&1
+find $OUT -name '*results.db' -size +20M -delete    # keep gpurun_out under its 64 MiB cap
+ls -la $OUT
