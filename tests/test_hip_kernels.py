@@ -195,3 +195,25 @@ def test_errors_are_loud():
         ops.gemm(_dev(8, 100), _dev(8, 100))          # K % 64 != 0 -> PFD_ESHAPE
     with pytest.raises(RuntimeError):
         ops.gemm(torch.zeros(8, 64, dtype=torch.float16), torch.zeros(8, 64, dtype=torch.float16))  # CPU tensors
+
+
+def test_operand_validation_is_loud():
+    """elementwise ops do not broadcast silently, caller-provided outputs are validated, the narrow
+    convolution honours out=, a control hint that does not broadcast to the batch raises"""
+    from lib.hip import layers as L
+    from lib.hip import ops
+    a, b = _dev(4, 64), _dev(2, 64)
+    with pytest.raises(ValueError):
+        ops.add(a, b)
+    with pytest.raises(ValueError):
+        ops.axpby(a, 1.0, b, 1.0)
+    with pytest.raises(ValueError):
+        ops.gemm(_dev(8, 64), _dev(160, 64), out=torch.empty((8, 128), dtype=torch.float16, device="cuda"))
+    with pytest.raises(TypeError):
+        ops.gemm(_dev(8, 64), _dev(160, 64), out=torch.empty((8, 160), dtype=torch.float32, device="cuda"))
+    conv = L.Conv2d(4, 64, 3, padding=1).half().cuda()
+    x = _dev(1, 8, 8, 4)
+    out = torch.zeros((1, 8, 8, 64), dtype=torch.float16, device="cuda")
+    y = conv.hip(x, out=out)
+    assert y.data_ptr() == out.data_ptr() and float(out.abs().max()) > 0
+    close(out, conv.hip(x))

@@ -208,6 +208,20 @@ def test_keymaps_match_the_reference_converters(state_spec):
     assert set(out) == set(vk) and out['decoder.mid.attn_1.q.weight'].shape == (2, 2, 1, 1)
 
 
+def test_invalidate_packed_covers_data_edits():
+    """edits through `param.data` move neither the pointer nor `_version`: invalidate_packed() drops the
+    kernel-layout copies and bumps the generation every packed-cache / hipGraph key includes"""
+    from lib.hip import layers as L
+    lin = L.Linear(4, 4)
+    sig0 = L._sig(lin.weight)
+    lin.weight.data.mul_(2.0)
+    assert L._sig(lin.weight) == sig0                      # the blind spot
+    lin.__dict__["_pk_cache"] = {"w": (sig0, "stale")}
+    g = L.generation()
+    L.invalidate_packed(lin)
+    assert L.generation() == g + 1 and "_pk_cache" not in lin.__dict__ and L._sig(lin.weight) != sig0
+
+
 def test_safetensors_hot_swap_is_strict_and_in_place(tmp_path):
     from safetensors.torch import save_file
     from lib import weights_io as W
@@ -240,6 +254,15 @@ def test_safetensors_hot_swap_is_strict_and_in_place(tmp_path):
         with pytest.raises(RuntimeError):
             W.load_diffuser(net, f)
         assert all(torch.equal(net.state_dict()[k], snap[k]) for k in snap)
+    # a whole-composite checkpoint (keys outside `diffuser.` that the net knows) is tolerated like app.py:139-156
+    # tolerates it (`sd.update(sd_extra)`): out-of-prefix keys are left alone, unknown ones still fail
+    full = dict(sd, **{'ctl.weight': torch.full((4, 4), 7.0), 'ctx.image.bias': torch.zeros(2)})
+    save_file(full, f)
+    ctl_before = net.ctl.weight.detach().clone()
+    assert W.load_diffuser(net, f) == len(sd) and torch.equal(net.ctl.weight, ctl_before)
+    save_file(dict(full, **{'nonsense.key': torch.zeros(1)}), f)
+    with pytest.raises(RuntimeError):
+        W.load_diffuser(net, f)
     # .pth goes through the same path; unknown extensions fail like app.py:91
     torch.save({k: torch.ones_like(v) for k, v in net.ctl.state_dict().items()}, str(tmp_path / "ctl.pth"))
     W.load_ctl(net, str(tmp_path / "ctl.pth"))
