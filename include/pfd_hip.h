@@ -34,7 +34,7 @@ extern "C" {
 #define PFD_ESHAPE (-2)   /* shape outside what the kernels are built for           */
 #define PFD_ELAUNCH (-3)  /* hipGetLastError() != hipSuccess after the launch       */
 
-#define PFD_ABI_VERSION 5
+#define PFD_ABI_VERSION 6
 
 typedef void* pfd_stream_t; /* hipStream_t */
 
@@ -111,6 +111,20 @@ typedef struct PfdGemmDesc {
   int64_t ldct;
   int32_t n_split;
   int32_t reserved0;
+  /* optional GroupNorm(+SiLU) prologue (ABI 6; `GroupNorm32 -> SiLU -> conv3x3` of ResBlock._forward,
+   * openaimodel.py:200-226, 254-274): with gn_table != NULL the convolution reads
+   *     act(x[b, y, x, c] * gn_table[b][0][c] + gn_table[b][1][c])   rounded to f16
+   * instead of x, where x is the virtual channel concat [A (gn_c1 channels, row stride lda) | A2 (Cin - gn_c1
+   * channels, row stride lda2)] (A2 may be NULL when gn_c1 == Cin) and the zero padding pads the NORMALISED image.
+   * gn_table is the f32 [B, 2, Cin] array (scale plane, shift plane) pfd_groupnorm_table_f16 writes; gn_act is PFD_ACT_NONE or PFD_ACT_SILU.
+   * Served by the 3x3 patch kernel only: ksize 3, stride 1, pad 1, no upsample, Wd in {16, 32, 64},
+   * H % (256 / Wd) == 0, N % 160 == 0, gn_c1 % 64 == 0, act != GEGLU; anything else is PFD_ESHAPE (callers run
+   * pfd_groupnorm_f16 and a plain convolution instead; there is no slow path behind this one). */
+  const void* gn_table;
+  const void* A2;
+  int64_t lda2;
+  int32_t gn_c1;
+  int32_t gn_act;
 } PfdGemmDesc;
 int pfd_gemm_f16(const PfdGemmDesc* d, pfd_stream_t stream);
 /* Same, with the kernel variant forced (tests and tuning only); 0 = the library's heuristic.
@@ -188,6 +202,11 @@ int pfd_swin_window_attention_f16(const PfdSwinAttnDesc* d, pfd_stream_t stream)
  * C1, C2 % 8 == 0; (C1+C2) % G == 0.
  * ---------------------------------------------------------------------------------- */
 size_t pfd_groupnorm_ws_bytes(int32_t B, int32_t C, int32_t HW);
+/* GroupNorm statistics only: writes table[b][0][c] = rstd * gamma[c], table[b][1][c] = beta[c] - mean * rstd * gamma[c]
+ * (f32 [B, 2, C1+C2], 16-byte aligned) for PfdGemmDesc.gn_table -- same arguments and workspace as pfd_groupnorm_f16 minus y / act. */
+int pfd_groupnorm_table_f16(const void* x1, int32_t C1, int64_t ldx1, const void* x2, int32_t C2, int64_t ldx2,
+                            const void* gamma, const void* beta, void* table, int32_t B, int32_t HW, int32_t G,
+                            float eps, void* ws, size_t ws_bytes, pfd_stream_t stream);
 int pfd_groupnorm_f16(const void* x1, int32_t C1, int64_t ldx1, const void* x2, int32_t C2,
                       int64_t ldx2, const void* gamma, const void* beta, void* y, int64_t ldy,
                       int32_t B, int32_t HW, int32_t G, float eps, int32_t act /*NONE|SILU*/,

@@ -318,6 +318,10 @@ extern "C" int pfd_gemm_f16_ex(const PfdGemmDesc* d, int32_t tile, pfd_stream_t 
     if (rc <= 0) return rc;
     if (tile >= 1000 || d->Ct) return PFD_ESHAPE;  // forced (or transposed tail) but not applicable
   }
+  if (d->gn_table) {
+    pfd_set_error("pfd_gemm_f16: the GroupNorm prologue is served by the 3x3 patch kernel only (see PfdGemmDesc.gn_table)");
+    return PFD_ESHAPE;
+  }
   GemmParams p;
   p.A = (const half_t*)d->A;
   p.W = (const half_t*)d->W;

@@ -56,11 +56,26 @@ struct G160Params {
   int B, H, Wd, Cin, Ho, Wo;
   int tiles_m, tiles_n, splits, kt_per_split;
   int nmajor;  // XCD-contiguous tile order: 0 = all N tiles of an M tile together, 1 = all M tiles of an N tile
+  // GroupNorm(+SiLU) folded into the patch convolution's input staging (PfdGemmDesc.gn_table)
+  const float* gn_table;   // [B][2][Cin]: scale plane, shift plane
+  const half_t* A2;        // channels >= gn_c1 of the virtual concat
+  long lda2;
+  int gn_c1, gn_act;
 };
 
 __device__ __forceinline__ void glds16(const void* src, void* lds_dst) {
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                    (__attribute__((address_space(3))) void*)lds_dst, 16, 0, 0);
+}
+
+// 16-byte LDS store the compiler cannot see: next to pending LDS-DMA pieces hipcc orders every ds_write it knows
+// about behind `s_waitcnt vmcnt(0)` (the DMA is a pending LDS write on the VM counter), which would drain the
+// loader's whole prefetch queue once per store.  The caller waits lgkmcnt(0) before the barrier that publishes it.
+__device__ __forceinline__ void lds_store16_opaque(void* lds_dst, uint4 v) {
+  typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+  const unsigned addr = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)lds_dst;
+  const u32x4 d = {v.x, v.y, v.z, v.w};
+  asm volatile("ds_write_b128 %0, %1" ::"v"(addr), "v"(d) : "memory");
 }
 
 // Epilogue shared by the wide-tile kernels.  The MFMAs are issued with the operands SWAPPED (W fragment as
@@ -104,10 +119,15 @@ __device__ __forceinline__ bool epilogue_stage(const float4_t (&acc)[WMB][NT], c
 
   if (p.Ct && n0 >= p.n_split) {  // transposed tail (tile-uniform): Ct[(n - n_split) * ldct + m] (+ bias)
     float bv[NT][4];
+    const half_t* bp = p.bias ? p.bias + nw : g_zero_page;   // unconditional 8-byte loads (see pass 1 below)
+    const int bstep = p.bias ? 16 : 0;
 #pragma unroll
-    for (int j = 0; j < NT; ++j)
+    for (int j = 0; j < NT; ++j) {
+      Pack8 b;
+      b.u = *reinterpret_cast<const uint2*>(bp + j * bstep);
 #pragma unroll
-      for (int r = 0; r < 4; ++r) bv[j][r] = p.bias ? (float)p.bias[nw + j * 16 + r] : 0.f;
+      for (int r = 0; r < 4; ++r) bv[j][r] = (float)b.e[r];
+    }
 #pragma unroll
     for (int i = 0; i < WMB; ++i) {
       const int m = mw + i * 16;
@@ -129,15 +149,20 @@ __device__ __forceinline__ bool epilogue_stage(const float4_t (&acc)[WMB][NT], c
   //  contiguous row segments and the residual is read the same way.)
   const bool geglu = p.act == PFD_ACT_GEGLU;
   const int lrow = wm * WMB * 16 + l15;
+  // Every global load of this pass is UNCONDITIONAL and issued before the first use: `if (ptr) v = load` is compiled
+  // as branch + load + s_waitcnt vmcnt(0), so the NT bias loads and WMB x NT row-vector loads went out one L2 round
+  // trip at a time (up to 25 per tile, on tiles whose whole K loop is 5 steps).  An absent bias reads the zero page
+  // with stride 0; a row past M reads row M - 1 (its result is never stored).
+  const half_t* bp = p.bias ? p.bias + nw : g_zero_page;
+  const int bstep = p.bias ? 16 : 0;
+  Pack8 bq[NT];
+#pragma unroll
+  for (int j = 0; j < NT; ++j) bq[j].u = *reinterpret_cast<const uint2*>(bp + j * bstep);
   float bv[NT][4];
 #pragma unroll
-  for (int j = 0; j < NT; ++j) {
-    Pack8 b;
-    b.u = make_uint2(0, 0);
-    if (p.bias) b.u = *reinterpret_cast<const uint2*>(p.bias + nw + j * 16);
+  for (int j = 0; j < NT; ++j)
 #pragma unroll
-    for (int r = 0; r < 4; ++r) bv[j][r] = (float)b.e[r];
-  }
+    for (int r = 0; r < 4; ++r) bv[j][r] = (float)bq[j].e[r];
   if (geglu) {
     // packed weight rows come in groups of four: x(2c), x(2c+1), gate(2c), gate(2c+1) -- exactly the four
     // columns a lane owns, so out(2c..2c+1) = x * gelu(gate) needs no exchange
@@ -155,30 +180,70 @@ __device__ __forceinline__ bool epilogue_stage(const float4_t (&acc)[WMB][NT], c
     }
   } else {
     constexpr int RS = stage_row_bytes(BN);
-#pragma unroll
-    for (int i = 0; i < WMB; ++i) {
-      const int m = mw + i * 16;
-      Pack8 lv[NT];
-      const half_t* rvp = (p.rowvec && m < p.M) ? p.rowvec + (long)(m / p.rows_per_rv) * p.ldrv + nw : nullptr;
-#pragma unroll
-      for (int j = 0; j < NT; ++j) {
-        lv[j].u = make_uint2(0, 0);
-        if (rvp) lv[j].u = *reinterpret_cast<const uint2*>(rvp + j * 16);
-      }
-      char* sp = smem + (lrow + i * 16) * RS + (wn * (16 * NT) + 4 * g) * 2;
+    char* sp0 = smem + lrow * RS + (wn * (16 * NT) + 4 * g) * 2;
+    // one copy of the staging loop per activation (p.act is launch-uniform): `if (p.act == ...) else if ...` per
+    // element is a chain of scalar compares and branches per element, 80 elements per lane
+    auto put_row = [&](auto act, auto itag, const Pack8(&rv)[NT]) __attribute__((always_inline)) {
+      constexpr int ACT = decltype(act)::value;
+      constexpr int i = decltype(itag)::value;
+      char* sp = sp0 + i * 16 * RS;
 #pragma unroll
       for (int j = 0; j < NT; ++j) {
         Pack8 o;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          float v = acc[i][j][r] + bv[j][r] + (float)lv[j].e[r];
-          if (p.act == PFD_ACT_GELU) v = pfd_gelu(v);
-          else if (p.act == PFD_ACT_RELU) v = fmaxf(v, 0.f);
-          else if (p.act == PFD_ACT_SILU) v = pfd_silu(v);
+          float v = acc[i][j][r] + bv[j][r] + (float)rv[j].e[r];
+          if constexpr (ACT == PFD_ACT_GELU) v = pfd_gelu(v);
+          else if constexpr (ACT == PFD_ACT_RELU) v = fmaxf(v, 0.f);
+          else if constexpr (ACT == PFD_ACT_SILU) v = pfd_silu(v);
           o.e[r] = (half_t)v;
         }
         *reinterpret_cast<uint2*>(sp + j * 32) = o.u;
       }
+    };
+    auto load_rv = [&](Pack8(&rv)[NT], int m) __attribute__((always_inline)) {   // row vector of output row m (clamped)
+      const half_t* rvp = p.rowvec + (long)(min(m, p.M - 1) / p.rows_per_rv) * p.ldrv + nw;
+#pragma unroll
+      for (int j = 0; j < NT; ++j) rv[j].u = *reinterpret_cast<const uint2*>(rvp + j * 16);
+    };
+    auto for_rows = [&](auto&& f) __attribute__((always_inline)) {
+      f(std::integral_constant<int, 0>{});
+      if constexpr (WMB > 1) f(std::integral_constant<int, 1>{});
+      if constexpr (WMB > 2) f(std::integral_constant<int, 2>{});
+      if constexpr (WMB > 3) f(std::integral_constant<int, 3>{});
+      static_assert(WMB <= 4, "row tiles per wave");
+    };
+    auto run = [&](auto act) __attribute__((always_inline)) {
+      Pack8 cur[NT];
+      const int first = m0 + wm * WMB * 16;
+      if (!p.rowvec) {
+#pragma unroll
+        for (int j = 0; j < NT; ++j) cur[j].u = make_uint2(0, 0);
+        for_rows([&](auto it) __attribute__((always_inline)) { put_row(act, it, cur); });
+      } else if (min(first, p.M - 1) / p.rows_per_rv == min(first + WMB * 16 - 1, p.M - 1) / p.rows_per_rv) {
+        // every row of this wave belongs to one sample (the convolutions' per-sample time embedding): NT loads
+        load_rv(cur, first);
+        for_rows([&](auto it) __attribute__((always_inline)) { put_row(act, it, cur); });
+      } else {
+        // rows of several samples: per-lane vectors, the next row tile's loads in flight under the current one
+        Pack8 nxt[NT];
+        load_rv(cur, mw);
+        for_rows([&](auto it) __attribute__((always_inline)) {
+          constexpr int i = decltype(it)::value;
+          if constexpr (i + 1 < WMB) load_rv(nxt, mw + (i + 1) * 16);
+          put_row(act, it, cur);
+          if constexpr (i + 1 < WMB) {
+#pragma unroll
+            for (int j = 0; j < NT; ++j) cur[j].u = nxt[j].u;
+          }
+        });
+      }
+    };
+    switch (p.act) {
+      case PFD_ACT_GELU: run(std::integral_constant<int, PFD_ACT_GELU>{}); break;
+      case PFD_ACT_RELU: run(std::integral_constant<int, PFD_ACT_RELU>{}); break;
+      case PFD_ACT_SILU: run(std::integral_constant<int, PFD_ACT_SILU>{}); break;
+      default: run(std::integral_constant<int, PFD_ACT_NONE>{}); break;
     }
   }
   return true;
@@ -195,20 +260,36 @@ __device__ __forceinline__ void epilogue_store(const G160Params& p, int m0, int 
     constexpr int RS = stage_row_bytes(COLS);
     constexpr int CPR = COLS / 8;   // 16-byte chunks per row
     const int nc0 = geglu ? n0 / 2 : n0;
-    for (int c = tid; c < BM * CPR; c += NTHREADS) {
-      const int row = c / CPR, cc = c - row * CPR;
-      const int m = m0 + row;
-      if (m >= p.M) continue;
-      Pack16 v;
-      v.u = *reinterpret_cast<const uint4*>(smem + row * RS + cc * 16);
-      const long n = nc0 + cc * 8;
-      if (p.R) {
-        Pack16 r;
-        r.u = *reinterpret_cast<const uint4*>(p.R + (long)m * p.ldr + n);
+    constexpr int TOTAL = BM * CPR;
+    constexpr int ITERS = (TOTAL + NTHREADS - 1) / NTHREADS;
+    constexpr int U = ITERS < 5 ? ITERS : 5;   // chunks per thread whose residual loads are in flight together
+    const bool has_r = p.R != nullptr;
+    for (int it0 = 0; it0 < ITERS; it0 += U) {
+      Pack16 r[U];
+      // the residual chunks of this group first, unconditional (clamped chunk / row): one load inside `if (p.R)` per
+      // loop iteration is one L2 round trip per 16 bytes per thread
+      if (has_r) {
 #pragma unroll
-        for (int e = 0; e < 8; ++e) v.e[e] = (half_t)((float)v.e[e] + (float)r.e[e]);
+        for (int u = 0; u < U; ++u) {
+          const int c = min(tid + (it0 + u) * NTHREADS, TOTAL - 1);
+          const int row = c / CPR, cc = c - row * CPR;
+          r[u].u = *reinterpret_cast<const uint4*>(p.R + (long)min(m0 + row, p.M - 1) * p.ldr + nc0 + cc * 8);
+        }
       }
-      *reinterpret_cast<uint4*>(p.C + (long)m * p.ldc + n) = v.u;
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int c = tid + (it0 + u) * NTHREADS;
+        const int row = c / CPR, cc = c - row * CPR;
+        const int m = m0 + row;
+        if (it0 + u >= ITERS || c >= TOTAL || m >= p.M) continue;
+        Pack16 v;
+        v.u = *reinterpret_cast<const uint4*>(smem + row * RS + cc * 16);
+        if (has_r) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v.e[e] = (half_t)((float)v.e[e] + (float)r[u].e[e]);
+        }
+        *reinterpret_cast<uint4*>(p.C + (long)m * p.ldc + nc0 + cc * 8) = v.u;
+      }
     }
   };
   if (geglu) store_pass(std::integral_constant<int, BN / 2>{});
@@ -771,6 +852,8 @@ __global__ __launch_bounds__(512) void conv3x3_patch_kernel(const G160Params p) 
 // patch, slots [6 tap, 6 tap + 6) of its 50 pieces.  Same LDS layout, swizzles, barrier count (one per tap, all
 // 12 waves) and epilogue; the consumers' instruction stream is ds_read + MFMA only.
 // ------------------------------------------------------------------------------------------------
+// GN: 0 = plain input, 1 = GroupNorm affine map in the staging path, 2 = affine map + SiLU
+template <int GN>
 __global__ __launch_bounds__(768) void conv3x3_patch_ws_kernel(const G160Params p) {
   constexpr int NCW = 8, NLW = 4, WMB = 4;
   constexpr int PATCH_BYTES = PATCH_ROWS * ROWB;  // 51200
@@ -844,29 +927,137 @@ __global__ __launch_bounds__(768) void conv3x3_patch_ws_kernel(const G160Params 
 #pragma unroll
       for (int j = 0; j < 5; ++j) glds16(wp[j] + k0, smem + OFF_W + stage * WT_BYTES + (lw + NLW * j) * 1024);
     };
-    if (nsteps > 0) {
+    if constexpr (GN != 0) {
+      // GroupNorm-apply (+ SiLU) in the staging path: the patch pieces go global -> VGPR -> affine map / activation in
+      // fp32 -> fp16 -> ds_write (same lane-linear image the DMA writes), the weights stay on LDS-DMA.  A lane's
+      // chunk index c = (cpos - (srow & ~1)) & 7 does not depend on the piece (8 q is a multiple of 8), so it maps
+      // the SAME eight channels of every channel block: their {scale, shift} pairs are loaded once per block.
+      // Pixels are requested one tap ahead of their transform, so a load has a whole tap (~1 us) in flight.
+      const int c8 = ((cpos - (srow & ~1)) & 7) * 8;
+      const float* tab = p.gn_table + (long)b * 2 * p.Cin + c8;
+      const half_t* img2 = p.A2 + (long)b * hw * p.lda2;
+      auto piece_pix = [&](int q) -> int {   // pixel index of this lane's patch row inside the sample, -1 = zero padding
+        const int r = q * 8 + srow;
+        const int py = r / PW, px = r - py * PW;
+        const int y = y0 - 1 + py, x = px - 1;
+        const bool ok = q < P_INSTR && r < prow_count && y >= 0 && y < H && x >= 0 && x < W;
+        return ok ? y * W + x : -1;
+      };
+      int pix_a[9], pix_b[9];
 #pragma unroll
-      for (int tp = 0; tp < 9; ++tp) {     // the whole first patch
-        if (6 * tp + lw < P_INSTR) issue_patch(0, cb_begin, 6 * tp + lw, off_a[tp]);
-        if (lw < 2 && 6 * tp + 4 + lw < P_INSTR) issue_patch(0, cb_begin, 6 * tp + 4 + lw, off_b[tp]);
+      for (int tp = 0; tp < 9; ++tp) {
+        pix_a[tp] = piece_pix(6 * tp + lw);
+        pix_b[tp] = piece_pix(6 * tp + 4 + lw);
       }
-      issue_w(0, 0, cb_begin);
-    }
-    int stage = 0;
-    for (int cb = cb_begin; cb < cb_end; ++cb) {
-      const int pbuf = (cb - cb_begin) & 1;
-      const bool more = cb + 1 < cb_end;
+      float4_t sc[2], sh[2];                  // this lane's eight {scale}, {shift}: pairs of channels sit in
+      auto load_tab = [&](int cb) {           // adjacent registers, so the affine map is four v_pk_fma_f32
 #pragma unroll
-      for (int tap = 0; tap < 9; ++tap) {
-        __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): this wave's pieces for this tap (and patch) are in LDS
-        block_barrier();                      // (A)
-        if (tap < 8) issue_w(stage ^ 1, tap + 1, cb);
-        else if (more) issue_w(stage ^ 1, 0, cb + 1);
-        if (more) {
-          if (6 * tap + lw < P_INSTR) issue_patch(pbuf ^ 1, cb + 1, 6 * tap + lw, off_a[tap]);
-          if (lw < 2 && 6 * tap + 4 + lw < P_INSTR) issue_patch(pbuf ^ 1, cb + 1, 6 * tap + 4 + lw, off_b[tap]);
+        for (int j = 0; j < 2; ++j) {
+          sc[j] = *reinterpret_cast<const float4_t*>(tab + cb * BK + 4 * j);
+          sh[j] = *reinterpret_cast<const float4_t*>(tab + p.Cin + cb * BK + 4 * j);
         }
-        stage ^= 1;
+      };
+      auto xform = [&](uint4 raw, bool ok) -> uint4 {
+        Pack16 in, out;
+        in.u = raw;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          float v = (float)in.e[e] * sc[e >> 2][e & 3] + sh[e >> 2][e & 3];
+          if constexpr (GN == 2) v = pfd_silu(v);
+          out.e[e] = (half_t)v;
+        }
+        return ok ? out.u : make_uint4(0, 0, 0, 0);   // zero padding stays zero (it pads the NORMALISED image)
+      };
+      auto put = [&](int buf, int q, uint4 v) {
+        lds_store16_opaque(smem + buf * PATCH_BYTES + q * 1024 + lane * 16, v);
+      };
+      auto fetch = [&](int cb, int pix) -> uint4 {   // the virtual channel concat [A | A2] is resolved per channel block
+        const int ch = cb * BK;
+        const int px = pix < 0 ? 0 : pix;             // padding rows load pixel 0 (always mapped) and are zeroed by xform:
+        const half_t* src = ch < p.gn_c1 ? img + (long)px * p.lda + (ch + c8)    // no branch around a load
+                                         : img2 + (long)px * p.lda2 + (ch - p.gn_c1 + c8);
+        return *reinterpret_cast<const uint4*>(src);
+      };
+      uint4 ra = make_uint4(0, 0, 0, 0), rb = ra;
+      if (nsteps > 0) {
+        issue_w(0, 0, cb_begin);
+        load_tab(cb_begin);
+        {                                    // the whole first patch: every load first, then the transforms
+          uint4 fa[9], fb[9];
+#pragma unroll
+          for (int tp = 0; tp < 9; ++tp) {
+            fa[tp] = fetch(cb_begin, pix_a[tp]);
+            fb[tp] = lw < 2 ? fetch(cb_begin, pix_b[tp]) : make_uint4(0, 0, 0, 0);
+          }
+#pragma unroll
+          for (int tp = 0; tp < 9; ++tp) {
+            if (6 * tp + lw < P_INSTR) put(0, 6 * tp + lw, xform(fa[tp], pix_a[tp] >= 0));
+            if (lw < 2 && 6 * tp + 4 + lw < P_INSTR) put(0, 6 * tp + 4 + lw, xform(fb[tp], pix_b[tp] >= 0));
+          }
+        }
+        if (cb_begin + 1 < cb_end) {         // request tap 0's pieces of the second patch + its table
+          load_tab(cb_begin + 1);
+          ra = fetch(cb_begin + 1, pix_a[0]);
+          if (lw < 2) rb = fetch(cb_begin + 1, pix_b[0]);
+        }
+      }
+      int stage = 0;
+      for (int cb = cb_begin; cb < cb_end; ++cb) {
+        const int pbuf = (cb - cb_begin) & 1;
+        const bool more = cb + 1 < cb_end;
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+          __builtin_amdgcn_s_waitcnt(0x0070);   // vmcnt(0) lgkmcnt(0): W pieces landed, pixels arrived, ds_writes done
+          block_barrier();                      // (A)
+          if (tap < 8) issue_w(stage ^ 1, tap + 1, cb);
+          else if (more) issue_w(stage ^ 1, 0, cb + 1);
+          if (more) {
+            // request the next pieces BEFORE transforming the ones that arrived: their latency runs under the VALU work
+            uint4 na = ra, nb = rb;
+            if (tap < 8) {                        // the next tap's pieces (same patch)
+              na = fetch(cb + 1, pix_a[tap + 1]);
+              if (lw < 2) nb = fetch(cb + 1, pix_b[tap + 1]);
+            } else if (cb + 2 < cb_end) {         // ... or tap 0 of the patch after
+              na = fetch(cb + 2, pix_a[0]);
+              if (lw < 2) nb = fetch(cb + 2, pix_b[0]);
+            }
+            const uint4 va = xform(ra, pix_a[tap] >= 0);
+            uint4 vb = make_uint4(0, 0, 0, 0);
+            if (lw < 2) vb = xform(rb, pix_b[tap] >= 0);
+            if (tap == 8 && cb + 2 < cb_end) load_tab(cb + 2);   // after the last transform with the current table
+            if (6 * tap + lw < P_INSTR) put(pbuf ^ 1, 6 * tap + lw, va);
+            if (lw < 2 && 6 * tap + 4 + lw < P_INSTR) put(pbuf ^ 1, 6 * tap + 4 + lw, vb);
+            ra = na;
+            rb = nb;
+          }
+          stage ^= 1;
+        }
+      }
+    } else {
+      if (nsteps > 0) {
+#pragma unroll
+        for (int tp = 0; tp < 9; ++tp) {     // the whole first patch
+          if (6 * tp + lw < P_INSTR) issue_patch(0, cb_begin, 6 * tp + lw, off_a[tp]);
+          if (lw < 2 && 6 * tp + 4 + lw < P_INSTR) issue_patch(0, cb_begin, 6 * tp + 4 + lw, off_b[tp]);
+        }
+        issue_w(0, 0, cb_begin);
+      }
+      int stage = 0;
+      for (int cb = cb_begin; cb < cb_end; ++cb) {
+        const int pbuf = (cb - cb_begin) & 1;
+        const bool more = cb + 1 < cb_end;
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+          __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): this wave's pieces for this tap (and patch) are in LDS
+          block_barrier();                      // (A)
+          if (tap < 8) issue_w(stage ^ 1, tap + 1, cb);
+          else if (more) issue_w(stage ^ 1, 0, cb + 1);
+          if (more) {
+            if (6 * tap + lw < P_INSTR) issue_patch(pbuf ^ 1, cb + 1, 6 * tap + lw, off_a[tap]);
+            if (lw < 2 && 6 * tap + 4 + lw < P_INSTR) issue_patch(pbuf ^ 1, cb + 1, 6 * tap + 4 + lw, off_b[tap]);
+          }
+          stage ^= 1;
+        }
       }
     }
     block_barrier();                          // (B) consumers finished the last tap: LDS is free
@@ -933,40 +1124,47 @@ __global__ __launch_bounds__(768) void conv3x3_patch_ws_kernel(const G160Params 
 
 // sum the split-K slabs and apply the epilogue (bias, row vector, activation, residual)
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const G160Params p) {
-  const long nvec = (long)p.M * (p.N / 8);
+  const int nv = p.N / 8;
+  const long nvec = (long)p.M * nv;
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (long)gridDim.x * 256) {
-    const int m = (int)(i / (p.N / 8));
-    const int n = (int)(i - (long)m * (p.N / 8)) * 8;
+    const int m = (int)(i / nv);
+    const int n = (int)(i - (long)m * nv) * 8;
+    // every load is unconditional (an absent operand reads the zero page) and the slabs go out four splits at a time:
+    // `if (p.bias) load` / a load per loop iteration are one round trip each (see epilogue_stage)
+    Pack16 bb, rv, rr;
+    bb.u = *reinterpret_cast<const uint4*>(p.bias ? p.bias + n : g_zero_page);
+    rv.u = *reinterpret_cast<const uint4*>(p.rowvec ? p.rowvec + (long)(m / p.rows_per_rv) * p.ldrv + n : g_zero_page);
+    rr.u = *reinterpret_cast<const uint4*>(p.R ? p.R + (long)m * p.ldr + n : g_zero_page);
     float v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    for (int s = 0; s < p.splits; ++s) {
-      const float4_t a = *reinterpret_cast<const float4_t*>(p.ws + ((long)s * p.M + m) * p.N + n);
-      const float4_t b = *reinterpret_cast<const float4_t*>(p.ws + ((long)s * p.M + m) * p.N + n + 4);
-      v[0] += a[0]; v[1] += a[1]; v[2] += a[2]; v[3] += a[3];
-      v[4] += b[0]; v[5] += b[1]; v[6] += b[2]; v[7] += b[3];
-    }
-    if (p.bias) {
-      Pack16 b;
-      b.u = *reinterpret_cast<const uint4*>(p.bias + n);
+    for (int s0 = 0; s0 < p.splits; s0 += 4) {
+      float4_t a[4], b[4];
 #pragma unroll
-      for (int e = 0; e < 8; ++e) v[e] += (float)b.e[e];
-    }
-    if (p.rowvec) {
-      Pack16 b;
-      b.u = *reinterpret_cast<const uint4*>(p.rowvec + (long)(m / p.rows_per_rv) * p.ldrv + n);
+      for (int u = 0; u < 4; ++u) {
+        const float* src = p.ws + ((long)min(s0 + u, p.splits - 1) * p.M + m) * p.N + n;
+        a[u] = *reinterpret_cast<const float4_t*>(src);
+        b[u] = *reinterpret_cast<const float4_t*>(src + 4);
+      }
 #pragma unroll
-      for (int e = 0; e < 8; ++e) v[e] += (float)b.e[e];
+      for (int u = 0; u < 4; ++u) {
+        const float w = s0 + u < p.splits ? 1.f : 0.f;   // the clamped duplicates add nothing
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          v[e] += a[u][e] * w;
+          v[4 + e] += b[u][e] * w;
+        }
+      }
     }
+    Pack16 o;
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
-      if (p.act == PFD_ACT_GELU) v[e] = pfd_gelu(v[e]);
-      else if (p.act == PFD_ACT_RELU) v[e] = fmaxf(v[e], 0.f);
-      else if (p.act == PFD_ACT_SILU) v[e] = pfd_silu(v[e]);
+      float x = v[e] + (float)bb.e[e];
+      x += (float)rv.e[e];
+      if (p.act == PFD_ACT_GELU) x = pfd_gelu(x);
+      else if (p.act == PFD_ACT_RELU) x = fmaxf(x, 0.f);
+      else if (p.act == PFD_ACT_SILU) x = pfd_silu(x);
+      o.e[e] = (half_t)(x + (float)rr.e[e]);
     }
-    for (int e = 0; e < 8; ++e) {
-      float x = v[e];
-      if (p.R) x += (float)p.R[(long)m * p.ldr + n + e];
-      p.C[(long)m * p.ldc + n + e] = (half_t)x;
-    }
+    *reinterpret_cast<uint4*>(p.C + (long)m * p.ldc + n) = o.u;
   }
 }
 
@@ -1046,7 +1244,9 @@ int launch_patch(G160Params& p, hipStream_t s, bool ws = false) {
   if (prof)
     pfd_prof_begin(19, 2.0 * p.M * p.N * p.K,
                    2.0 * p.B * p.H * p.Wd * p.Cin + 2.0 * p.N * p.K + 2.0 * p.M * p.N * (p.R ? 2 : 1), s);
-  if (ws) hipLaunchKernelGGL(conv3x3_patch_ws_kernel, grid, dim3(768), 0, s, p);
+  if (p.gn_table && p.gn_act == PFD_ACT_SILU) hipLaunchKernelGGL(conv3x3_patch_ws_kernel<2>, grid, dim3(768), 0, s, p);
+  else if (p.gn_table) hipLaunchKernelGGL(conv3x3_patch_ws_kernel<1>, grid, dim3(768), 0, s, p);
+  else if (ws) hipLaunchKernelGGL(conv3x3_patch_ws_kernel<0>, grid, dim3(768), 0, s, p);
   else hipLaunchKernelGGL(conv3x3_patch_kernel, grid, dim3(512), 0, s, p);
   if (p.splits > 1) {
     const long nvec = (long)p.M * (p.N / 8);
@@ -1093,6 +1293,16 @@ int pfd_gemm160_try(const PfdGemmDesc* d, int variant, int splits, hipStream_t s
   p.B = d->B; p.H = d->H; p.Wd = d->Wd; p.Cin = d->Cin; p.Ho = d->Ho; p.Wo = d->Wo;
   p.tiles_m = p.tiles_n = 0;
   p.kt_per_split = 0;
+  p.gn_table = (const float*)d->gn_table; p.A2 = (const half_t*)d->A2; p.lda2 = d->lda2;
+  p.gn_c1 = d->gn_c1; p.gn_act = d->gn_act;
+  if (p.gn_table) {   // GroupNorm prologue: patch kernel or nothing (validated here, PFD_ESHAPE by the caller otherwise)
+    if (bn != 160 || (variant != 0 && variant != 98)) return 1;
+    if (p.gn_c1 <= 0 || p.gn_c1 > p.Cin || (p.gn_c1 % BK) || (p.gn_c1 < p.Cin && !p.A2)) return 1;
+    if ((p.lda2 & 7) || (reinterpret_cast<uintptr_t>(p.A2) & 15) || (reinterpret_cast<uintptr_t>(p.gn_table) & 15))
+      return 1;
+    if (p.gn_act != PFD_ACT_NONE && p.gn_act != PFD_ACT_SILU) return 1;
+    if (p.gn_c1 == p.Cin) { p.A2 = p.A; p.lda2 = p.lda; }
+  }
   const int tn = p.N / bn;
   auto tiles = [&](int bm) { return (long)((p.M + bm - 1) / bm) * tn; };
   // 3x3 / s1 / p1 convolution on a 16-, 32- or 64-wide image: the patch kernel (variant 0 or 99)
@@ -1117,7 +1327,7 @@ int pfd_gemm160_try(const PfdGemmDesc* d, int variant, int splits, hipStream_t s
     // 8-wave form
     return launch_patch(p, s, variant != 99) < 0 ? PFD_ELAUNCH : 0;
   }
-  if (variant == 99 || variant == 98) return 1;
+  if (variant == 99 || variant == 98 || p.gn_table) return 1;
   const bool auto_variant = variant == 0;
   const int nk_all = p.K / BK;
   if (auto_variant) {

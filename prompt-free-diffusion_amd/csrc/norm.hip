@@ -11,6 +11,9 @@ namespace {
 
 constexpr int GN_MAX_CHUNKS = 256;
 constexpr int GN_MAX_G = 64;
+#ifndef GN_ROWS
+#define GN_ROWS 8   // rows a statistics thread keeps in flight
+#endif
 
 struct GnSrc {
   const half_t* x1;
@@ -47,23 +50,29 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(GnSrc s, int HW, int G, i
 #pragma unroll
     for (int e = 0; e < 8; ++e) sm[e] = sq[e] = 0.f;
     if (rt < RT && v < nvec) {
-      // four rows in flight per thread: the kernel is a pure stream and one 16-byte load per thread
-      // (~4 MB in flight chip-wide) cannot cover the HBM latency
-      for (int r = r_beg + rt; r < r_end; r += 4 * RT) {
-        Pack16 p[4];
+      // GN_ROWS rows in flight per thread: the kernel is a pure stream and one 16-byte load per thread
+      // (~4 MB in flight chip-wide) cannot cover the HBM latency.  Every load is UNCONDITIONAL (row clamped into
+      // the chunk, the sample's source resolved once per thread): a load inside `if (row < end)` is compiled as
+      // branch + load + s_waitcnt vmcnt(0), i.e. one load in flight however many are written down.
+      const int c = v * 8;
+      const half_t* src = c < s.C1 ? s.x1 + c : s.x2 + (c - s.C1);
+      const long ld = c < s.C1 ? s.ld1 : s.ld2;
+      src += (long)b * HW * ld;
+      for (int r = r_beg + rt; r < r_end; r += GN_ROWS * RT) {
+        Pack16 p[GN_ROWS];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          p[u].u = make_uint4(0, 0, 0, 0);
-          if (r + u * RT < r_end) p[u].u = gn_load(s, (long)b * HW + r + u * RT, v);
-        }
+        for (int u = 0; u < GN_ROWS; ++u)
+          p[u].u = *reinterpret_cast<const uint4*>(src + (long)min(r + u * RT, r_end - 1) * ld);
 #pragma unroll
-        for (int u = 0; u < 4; ++u)
+        for (int u = 0; u < GN_ROWS; ++u) {
+          const float m = r + u * RT < r_end ? 1.f : 0.f;   // clamped duplicates add nothing
 #pragma unroll
           for (int e = 0; e < 8; ++e) {
-            const float x = (float)p[u].e[e];
+            const float x = (float)p[u].e[e] * m;
             sm[e] += x;
             sq[e] += x * x;
           }
+        }
       }
     }
 #pragma unroll
@@ -180,6 +189,47 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(GnSrc s, const half_t* __
   }
 }
 
+// GroupNorm folded into the consumer (pfd_groupnorm_table_f16): instead of writing the normalised tensor, write the
+// per-(sample, channel) affine map  y = x * scale + shift  as two planes [B][2][C]  (scale = rstd * gamma, shift = beta - mean * scale; the
+// same fp32 expressions, reduced in the same order, as gn_apply_kernel) -- the 3x3 patch convolution applies it
+// (+ SiLU) while it stages its input patch (gemm_glds.hip, conv3x3_patch_ws_kernel<true>).
+__global__ __launch_bounds__(256) void gn_table_kernel(const half_t* __restrict__ gamma, const half_t* __restrict__ beta,
+                                                       const float* __restrict__ partial, float* __restrict__ table,
+                                                       int C, int G, int nchunks, float count, float eps) {
+  __shared__ float ra[256], rq[256], gmean[GN_MAX_G], grstd[GN_MAX_G];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const int cpg = C / G;
+  const int P = 256 / G;
+  const int g = tid % G, part = tid / G;
+  float a = 0.f, q = 0.f;
+  if (part < P) {
+    for (int k = part; k < nchunks; k += P) {
+      const float2 v = *reinterpret_cast<const float2*>(partial + (((long)b * nchunks + k) * G + g) * 2);
+      a += v.x;
+      q += v.y;
+    }
+  }
+  ra[tid] = a;
+  rq[tid] = q;
+  __syncthreads();
+  if (tid < G) {
+    for (int k = 1; k < P; ++k) {
+      a += ra[k * G + tid];
+      q += rq[k * G + tid];
+    }
+    const float mean = a / count;
+    gmean[tid] = mean;
+    grstd[tid] = rsqrtf(fmaxf(q / count - mean * mean, 0.f) + eps);
+  }
+  __syncthreads();
+  for (int c = tid; c < C; c += 256) {
+    const int gg = c / cpg;
+    const float w = grstd[gg] * (float)gamma[c];
+    table[(long)b * 2 * C + c] = w;                                  // scale plane
+    table[(long)b * 2 * C + C + c] = (float)beta[c] - gmean[gg] * w;    // shift plane
+  }
+}
+
 // ---- GroupNorm, small-slab form: one block per (sample, group) keeps the group's HW x C/G slab in
 // registers (<= 32 chunks of 4 halves per thread), so statistics + normalise + activation are ONE launch
 // and the input is read once (4 B/element).  Serves the 8^2 / 16^2 / 32^2 UNet levels, where the
@@ -252,17 +302,17 @@ __global__ __launch_bounds__(256) void gn_small_kernel(GnSrc s, const half_t* __
 // ---- LayerNorm: one wave per row, the row lives in registers (<= 8 vecs of 8 per lane) ----
 constexpr int LN_MAXV = 8;
 
+template <bool GATHER, int NV>
 __global__ __launch_bounds__(256) void layernorm_kernel(const half_t* __restrict__ x, long ldx,
                                                         const half_t* __restrict__ gamma,
                                                         const half_t* __restrict__ beta, half_t* __restrict__ y,
-                                                        long ldy, int M, int C, float eps, int gather4, int B,
-                                                        int H, int W) {
+                                                        long ldy, int M, int C, float eps, int B, int H, int W) {
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= M) return;
   const int nvec = C / 8;
-  int gb = 0, gy = 0, gx = 0, Cq = 0;
-  if (gather4) {
+  int gb = 0, gy = 0, gx = 0, Cq = 1;
+  if constexpr (GATHER) {
     const int Ho = (H + 1) / 2, Wo = (W + 1) / 2;
     gb = row / (Ho * Wo);
     const int rem = row - gb * Ho * Wo;
@@ -270,34 +320,45 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const half_t* __restrict
     gx = rem - gy * Wo;
     Cq = C / 4;
   }
-  float vals[LN_MAXV][8];
+  // all loads of the row first, unconditional (clamped address; lanes past the row / the image are masked when the
+  // values are used): a load inside an `if` is compiled as branch + load + s_waitcnt vmcnt(0), one load in flight
+  Pack16 p[NV];
+  bool ok[NV];
+#pragma unroll
+  for (int k = 0; k < NV; ++k) {
+    const int v = lane + 64 * k;
+    const int vc = min(v, nvec - 1);
+    const half_t* src = x + (long)row * ldx + vc * 8;
+    ok[k] = v < nvec;
+    if constexpr (GATHER) {
+      const int c = vc * 8;
+      const int part = c / Cq;
+      const int iy = 2 * gy + (part & 1), ix = 2 * gx + (part >> 1);
+      ok[k] = ok[k] && iy < H && ix < W;
+      src = x + (((long)gb * H + min(iy, H - 1)) * W + min(ix, W - 1)) * ldx + (c - part * Cq);
+    }
+    p[k].u = *reinterpret_cast<const uint4*>(src);
+  }
+  Pack16 g[NV], bt[NV];   // requested before the reductions (unconditional, clamped), used after them
+#pragma unroll
+  for (int k = 0; k < NV; ++k) {
+    const int vc = min(lane + 64 * k, nvec - 1);
+    g[k].u = *reinterpret_cast<const uint4*>(gamma + vc * 8);
+    bt[k].u = *reinterpret_cast<const uint4*>(beta + vc * 8);
+  }
+  float vals[NV][8];
   float sum = 0.f;
 #pragma unroll
-  for (int k = 0; k < LN_MAXV; ++k) {
-    const int v = lane + 64 * k;
-    Pack16 p;
-    p.u = make_uint4(0, 0, 0, 0);
-    if (v < nvec) {
-      if (gather4) {
-        const int c = v * 8;
-        const int part = c / Cq;
-        const int iy = 2 * gy + (part & 1), ix = 2 * gx + (part >> 1);
-        if (iy < H && ix < W)
-          p.u = *reinterpret_cast<const uint4*>(x + (((long)gb * H + iy) * W + ix) * ldx + (c - part * Cq));
-      } else {
-        p.u = *reinterpret_cast<const uint4*>(x + (long)row * ldx + v * 8);
-      }
-    }
+  for (int k = 0; k < NV; ++k)
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
-      vals[k][e] = (float)p.e[e];
+      vals[k][e] = ok[k] ? (float)p[k].e[e] : 0.f;   // out-of-image taps of the PatchMerging gather read zero
       sum += vals[k][e];
     }
-  }
   const float mean = wave_sum(sum) / (float)C;
   float sq = 0.f;
 #pragma unroll
-  for (int k = 0; k < LN_MAXV; ++k) {
+  for (int k = 0; k < NV; ++k) {
     if (lane + 64 * k < nvec) {
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
@@ -308,14 +369,13 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const half_t* __restrict
   }
   const float rstd = rsqrtf(wave_sum(sq) / (float)C + eps);
 #pragma unroll
-  for (int k = 0; k < LN_MAXV; ++k) {
+  for (int k = 0; k < NV; ++k) {
     const int v = lane + 64 * k;
     if (v < nvec) {
-      Pack16 g, bt, o;
-      g.u = *reinterpret_cast<const uint4*>(gamma + v * 8);
-      bt.u = *reinterpret_cast<const uint4*>(beta + v * 8);
+      Pack16 o;
 #pragma unroll
-      for (int e = 0; e < 8; ++e) o.e[e] = (half_t)((vals[k][e] - mean) * rstd * (float)g.e[e] + (float)bt.e[e]);
+      for (int e = 0; e < 8; ++e)
+        o.e[e] = (half_t)((vals[k][e] - mean) * rstd * (float)g[k].e[e] + (float)bt[k].e[e]);
       *reinterpret_cast<uint4*>(y + (long)row * ldy + v * 8) = o.u;
     }
   }
@@ -333,24 +393,24 @@ __global__ __launch_bounds__(256) void layernorm_rows_kernel(const half_t* __res
   const int row0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * ROWS;
   if (row0 >= M) return;
   const int nvec = C / 8;
+  // every load below is unconditional (index clamped, result zeroed by a select): a load inside an `if` is compiled
+  // as branch + load + s_waitcnt vmcnt(0) and the ROWS x NV loads would go out one at a time
+  const uint4 zero4 = make_uint4(0, 0, 0, 0);
   Pack16 p[ROWS][NV];
 #pragma unroll
   for (int r = 0; r < ROWS; ++r)
 #pragma unroll
     for (int k = 0; k < NV; ++k) {
       const int v = lane + 64 * k;
-      p[r][k].u = make_uint4(0, 0, 0, 0);
-      if (v < nvec && row0 + r < M) p[r][k].u = *reinterpret_cast<const uint4*>(x + (long)(row0 + r) * ldx + v * 8);
+      const uint4 t = *reinterpret_cast<const uint4*>(x + (long)min(row0 + r, M - 1) * ldx + min(v, nvec - 1) * 8);
+      p[r][k].u = (v < nvec && row0 + r < M) ? t : zero4;
     }
   Pack16 g[NV], bt[NV];
 #pragma unroll
   for (int k = 0; k < NV; ++k) {
-    const int v = lane + 64 * k;
-    g[k].u = bt[k].u = make_uint4(0, 0, 0, 0);
-    if (v < nvec) {
-      g[k].u = *reinterpret_cast<const uint4*>(gamma + v * 8);
-      bt[k].u = *reinterpret_cast<const uint4*>(beta + v * 8);
-    }
+    const int v = min(lane + 64 * k, nvec - 1);   // lanes past the row hold a copy they never store
+    g[k].u = *reinterpret_cast<const uint4*>(gamma + v * 8);
+    bt[k].u = *reinterpret_cast<const uint4*>(beta + v * 8);
   }
 #pragma unroll
   for (int r = 0; r < ROWS; ++r) {
@@ -396,15 +456,16 @@ __global__ __launch_bounds__(256) void softmax_rows_kernel(const half_t* __restr
   const int nvec = N / 8;
   float vals[SM_MAXV][8];
   float mx = -INFINITY;
+  Pack16 p[SM_MAXV];
+#pragma unroll
+  for (int k = 0; k < SM_MAXV; ++k)   // all loads first, unconditional (clamped): see layernorm_rows_kernel
+    p[k].u = *reinterpret_cast<const uint4*>(x + (long)row * ldx + min(tid + 256 * k, nvec - 1) * 8);
 #pragma unroll
   for (int k = 0; k < SM_MAXV; ++k) {
-    const int v = tid + 256 * k;
-    if (v < nvec) {
-      Pack16 p;
-      p.u = *reinterpret_cast<const uint4*>(x + (long)row * ldx + v * 8);
+    if (tid + 256 * k < nvec) {
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
-        vals[k][e] = (float)p.e[e] * scale;
+        vals[k][e] = (float)p[k].e[e] * scale;
         mx = fmaxf(mx, vals[k][e]);
       }
     }
@@ -481,6 +542,22 @@ __global__ __launch_bounds__(256) void softmax_rows_long_kernel(const half_t* __
 
 }  // namespace
 
+// chunking of the two-launch form: ~512 blocks over the chip, at least 4 row sweeps per block (every apply block
+// re-reduces its sample's nchunks x G partials, so nchunks stays moderate)
+static void gn_chunks(int B, int C, int HW, int* nchunks_out, int* rpc_out) {
+  const int nvec = C / 8;
+  const int RT = nvec < 256 ? 256 / nvec : 1;
+  static const int target_blocks = getenv("PFD_GN_BLOCKS") ? atoi(getenv("PFD_GN_BLOCKS")) : 512;
+  int nchunks = (target_blocks + B - 1) / B;
+  const int max_by_rows = (HW + RT * 4 - 1) / (RT * 4);
+  if (nchunks > max_by_rows) nchunks = max_by_rows;
+  if (nchunks > GN_MAX_CHUNKS) nchunks = GN_MAX_CHUNKS;
+  if (nchunks < 1) nchunks = 1;
+  const int rpc = (HW + nchunks - 1) / nchunks;
+  *nchunks_out = (HW + rpc - 1) / rpc;
+  *rpc_out = rpc;
+}
+
 extern "C" size_t pfd_groupnorm_ws_bytes(int32_t B, int32_t C, int32_t HW) {
   (void)C;
   (void)HW;
@@ -510,18 +587,8 @@ extern "C" int pfd_groupnorm_f16(const void* x1, int32_t C1, int64_t ldx1, const
     if (prof) pfd_prof_end(s);
     return pfd_check_launch("pfd_groupnorm_f16(small)");
   }
-  const int nvec = C / 8;
-  const int RT = nvec < 256 ? 256 / nvec : 1;
-  // aim for ~512 blocks over the chip, at least 4 row sweeps per block (every apply block re-reduces
-  // its sample's nchunks x G partials, so nchunks stays moderate)
-  static const int target_blocks = getenv("PFD_GN_BLOCKS") ? atoi(getenv("PFD_GN_BLOCKS")) : 512;
-  int nchunks = (target_blocks + B - 1) / B;
-  const int max_by_rows = (HW + RT * 4 - 1) / (RT * 4);
-  if (nchunks > max_by_rows) nchunks = max_by_rows;
-  if (nchunks > GN_MAX_CHUNKS) nchunks = GN_MAX_CHUNKS;
-  if (nchunks < 1) nchunks = 1;
-  const int rpc = (HW + nchunks - 1) / nchunks;
-  nchunks = (HW + rpc - 1) / rpc;
+  int nchunks, rpc;
+  gn_chunks(B, C, HW, &nchunks, &rpc);
   float* partial = (float*)ws;
   if (prof) pfd_prof_begin(10, 8.0 * B * HW * C, 6.0 * B * HW * C, s);  // 2B stats read + 2B read + 2B write
   hipLaunchKernelGGL(gn_stats_kernel, dim3(nchunks, B), dim3(256), 0, s, src, HW, G, rpc, partial);
@@ -530,6 +597,30 @@ extern "C" int pfd_groupnorm_f16(const void* x1, int32_t C1, int64_t ldx1, const
                      (float)HW * (float)(C / G), eps);
   if (prof) pfd_prof_end(s);
   return pfd_check_launch("pfd_groupnorm_f16");
+}
+
+extern "C" int pfd_groupnorm_table_f16(const void* x1, int32_t C1, int64_t ldx1, const void* x2, int32_t C2,
+                                       int64_t ldx2, const void* gamma, const void* beta, void* table, int32_t B,
+                                       int32_t HW, int32_t G, float eps, void* ws, size_t ws_bytes,
+                                       pfd_stream_t stream) {
+  if (!x1 || !gamma || !beta || !table || !ws) return PFD_EINVAL;
+  if (C2 > 0 && !x2) return PFD_EINVAL;
+  if (C2 < 0 || C1 <= 0 || B <= 0 || HW <= 0 || G <= 0 || G > GN_MAX_G) return PFD_EINVAL;
+  const int C = C1 + C2;
+  if ((C1 & 7) || (C2 & 7) || (C % G) || C > 4096) return PFD_ESHAPE;
+  if ((ldx1 & 7) || (ldx2 & 7) || (reinterpret_cast<uintptr_t>(table) & 15)) return PFD_EINVAL;
+  if (ws_bytes < pfd_groupnorm_ws_bytes(B, C, HW)) return PFD_EINVAL;
+  hipStream_t s = (hipStream_t)stream;
+  GnSrc src{(const half_t*)x1, (const half_t*)x2, ldx1, ldx2, C1, C2};
+  int nchunks, rpc;
+  gn_chunks(B, C, HW, &nchunks, &rpc);
+  const bool prof = pfd_prof_on();
+  if (prof) pfd_prof_begin(10, 4.0 * B * HW * C, 2.0 * B * HW * C, s);   // one read of the input
+  hipLaunchKernelGGL(gn_stats_kernel, dim3(nchunks, B), dim3(256), 0, s, src, HW, G, rpc, (float*)ws);
+  hipLaunchKernelGGL(gn_table_kernel, dim3(B), dim3(256), 0, s, (const half_t*)gamma, (const half_t*)beta,
+                     (const float*)ws, (float*)table, C, G, nchunks, (float)HW * (float)(C / G), eps);
+  if (prof) pfd_prof_end(s);
+  return pfd_check_launch("pfd_groupnorm_table_f16");
 }
 
 extern "C" int pfd_layernorm_f16(const void* x, int64_t ldx, const void* gamma, const void* beta, void* y,
@@ -555,9 +646,25 @@ extern "C" int pfd_layernorm_f16(const void* x, int64_t ldx, const void* gamma, 
 #undef PFD_LN_ROWS
     return pfd_check_launch("pfd_layernorm_f16(rows)");
   }
-  hipLaunchKernelGGL(layernorm_kernel, dim3((M + 3) / 4), dim3(256), 0, (hipStream_t)stream,
-                     (const half_t*)x, (long)ldx, (const half_t*)gamma, (const half_t*)beta, (half_t*)y,
-                     (long)ldy, M, C, eps, gather4, B, H, W);
+  // NV = 16-byte vectors per lane (64 lanes per row), rounded up to an instantiated count
+  const int nv = (C / 8 + 63) / 64;
+#define PFD_LN(G, NV)                                                                                              \
+  hipLaunchKernelGGL((layernorm_kernel<G, NV>), dim3((M + 3) / 4), dim3(256), 0, (hipStream_t)stream,              \
+                     (const half_t*)x, (long)ldx, (const half_t*)gamma, (const half_t*)beta, (half_t*)y, (long)ldy, \
+                     M, C, eps, B, H, W)
+#define PFD_LN_NV(G)                                                                                               \
+  do {                                                                                                             \
+    if (nv <= 1) PFD_LN(G, 1);                                                                                     \
+    else if (nv <= 2) PFD_LN(G, 2);                                                                                \
+    else if (nv <= 3) PFD_LN(G, 3);                                                                                \
+    else if (nv <= 4) PFD_LN(G, 4);                                                                                \
+    else if (nv <= 6) PFD_LN(G, 6);                                                                                \
+    else PFD_LN(G, 8);                                                                                             \
+  } while (0)
+  if (gather4) PFD_LN_NV(true);
+  else PFD_LN_NV(false);
+#undef PFD_LN_NV
+#undef PFD_LN
   return pfd_check_launch("pfd_layernorm_f16");
 }
 

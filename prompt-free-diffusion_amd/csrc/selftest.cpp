@@ -368,6 +368,60 @@ static void run_gn_case(int B, int HW, int C1, int C2, int G, int act, float eps
   report(name, got, ref, 4e-3, 3e-3);
 }
 
+// conv3x3(act(GroupNorm([x1 | x2]))) two ways: pfd_groupnorm_f16 + plain patch conv vs pfd_groupnorm_table_f16 + the
+// conv's GroupNorm prologue.  Same statistics code, same fp32 affine map, same kernel behind it: the outputs must be
+// identical, not merely close.
+static void run_gn_conv_case(int B, int H, int W, int C1, int C2, int N, int act, bool with_res) {
+  const int C = C1 + C2, HW = H * W, G = 32, M = B * HW, K = 9 * C;
+  const float eps = 1e-5f;
+  auto x1 = rand_h((size_t)M * C1, 2.f), x2 = rand_h((size_t)M * std::max(C2, 8), 1.f);
+  for (auto& v : x1) v = (h16)((float)v + 0.7f);
+  auto gm = rand_h(C, 1.f), bt = rand_h(C, 0.5f);
+  auto Wt = rand_h((size_t)N * K, 0.05f), bias = rand_h(N, 0.5f), R = rand_h((size_t)M * N, 1.f);
+  auto rv = rand_h((size_t)B * N, 0.5f);
+  Dev<h16> d1(x1), d2(x2), dg(gm), db(bt), dy((size_t)M * C), dW(Wt), dB(bias), dR(R), dRV(rv);
+  Dev<h16> dC0((size_t)M * N), dC1((size_t)M * N);
+  Dev<float> dT((size_t)B * C * 2);
+  const size_t wsb = pfd_groupnorm_ws_bytes(B, C, HW);
+  Dev<char> dws(wsb);
+  Dev<float> dWS((size_t)8 * M * N + 64);
+  char name[160];
+  snprintf(name, sizeof(name), "gn-prologue conv B%d %dx%d C%d+%d N%d act%d res%d", B, H, W, C1, C2, N, act, (int)with_res);
+  int rc = pfd_groupnorm_f16(d1.p, C1, C1, C2 ? d2.p : nullptr, C2, C2, dg.p, db.p, dy.p, C, B, HW, G, eps, act, dws.p,
+                             wsb, nullptr);
+  PfdGemmDesc d;
+  memset(&d, 0, sizeof(d));
+  d.ws = dWS.p; d.ws_bytes = ((size_t)8 * M * N + 64) * sizeof(float);
+  d.A = dy.p; d.W = dW.p; d.bias = dB.p; d.rowvec = dRV.p; d.R = with_res ? dR.p : nullptr; d.C = dC0.p;
+  d.lda = C; d.ldw = K; d.ldr = N; d.ldc = N; d.ldrv = N;
+  d.M = M; d.N = N; d.K = K; d.rows_per_rv = HW;
+  d.ksize = 3; d.stride = 1; d.pad = 1; d.B = B; d.H = H; d.Wd = W; d.Cin = C; d.Ho = H; d.Wo = W;
+  if (rc == 0) rc = pfd_gemm_f16_ex(&d, 10800, nullptr);
+  if (rc == 0)
+    rc = pfd_groupnorm_table_f16(d1.p, C1, C1, C2 ? d2.p : nullptr, C2, C2, dg.p, db.p, dT.p, B, HW, G, eps, dws.p, wsb,
+                                 nullptr);
+  d.A = d1.p; d.lda = C1; d.A2 = C2 ? d2.p : nullptr; d.lda2 = C2; d.gn_c1 = C1; d.gn_table = dT.p; d.gn_act = act;
+  d.C = dC1.p;
+  if (rc == 0) rc = pfd_gemm_f16(&d, nullptr);
+  ++g_total;
+  if (rc != 0) { ++g_fail; printf("FAIL %-58s rc=%d (%s)\n", name, rc, pfd_last_error()); return; }
+  auto c0 = dC0.get(), c1 = dC1.get();
+  size_t bad = 0;
+  double worst = 0, mag = 0;
+  for (size_t i = 0; i < c0.size(); ++i) {
+    const double a = (double)c0[i], b = (double)c1[i];
+    if (!(a == b)) { ++bad; worst = std::max(worst, fabs(a - b)); }
+    mag = std::max(mag, fabs(a));
+  }
+  if (bad) { ++g_fail; printf("FAIL %-58s %zu of %zu differ, max |d| %.4g (max |ref| %.3g)\n", name, bad, c0.size(), worst, mag); }
+  else printf("ok   %-58s identical (%zu values, max |ref| %.3g)\n", name, c0.size(), mag);
+  // a shape the patch kernel does not take must be refused, not served by something else
+  d.Wd = 8; d.H = H * W / 8; d.Ho = d.H; d.Wo = 8;
+  ++g_total;
+  const int rc2 = pfd_gemm_f16(&d, nullptr);
+  if (rc2 != PFD_ESHAPE) { ++g_fail; printf("FAIL %-58s W=8 with gn_table: rc=%d, expected PFD_ESHAPE\n", name, rc2); }
+}
+
 static void run_ln_case(int M, int C, int gather4, int B, int H, int W) {
   const int Cq = C / 4;
   auto x = rand_h(gather4 ? (size_t)B * H * W * Cq : (size_t)M * C, 2.f);
@@ -557,6 +611,41 @@ static void bench_gemm(const char* label, int M, int N, int K, int ksize, int B,
   fflush(stdout);
 }
 
+static void bench_gn_conv(const char* label, int B, int H, int C1, int C2, int N) {
+  const int C = C1 + C2, HW = H * H, M = B * HW, K = 9 * C, G = 32;
+  auto x1 = rand_h((size_t)M * C1), x2 = rand_h((size_t)M * std::max(C2, 8)), gm = rand_h(C), bt = rand_h(C);
+  auto Wt = rand_h((size_t)N * K, 0.05f), bias = rand_h(N);
+  Dev<h16> d1(x1), d2(x2), dg(gm), db(bt), dy((size_t)M * C), dW(Wt), dB(bias), dC((size_t)M * N);
+  Dev<float> dT((size_t)B * C * 2);
+  const size_t wsb = pfd_groupnorm_ws_bytes(B, C, HW);
+  Dev<char> dws(wsb);
+  PfdGemmDesc d;
+  memset(&d, 0, sizeof(d));
+  d.W = dW.p; d.bias = dB.p; d.C = dC.p; d.ldw = K; d.ldc = N; d.M = M; d.N = N; d.K = K; d.rows_per_rv = 1;
+  d.ksize = 3; d.stride = 1; d.pad = 1; d.B = B; d.H = H; d.Wd = H; d.Cin = C; d.Ho = H; d.Wo = H;
+  int rc = 0;
+  d.A = dy.p; d.lda = C;
+  const float gn = time_ms([&] {
+    rc |= pfd_groupnorm_f16(d1.p, C1, C1, C2 ? d2.p : nullptr, C2, C2, dg.p, db.p, dy.p, C, B, HW, G, 1e-5f, PFD_ACT_SILU,
+                            dws.p, wsb, nullptr); }, 20);
+  const float conv = time_ms([&] { rc |= pfd_gemm_f16(&d, nullptr); }, 20);
+  const float two = time_ms([&] {
+    rc |= pfd_groupnorm_f16(d1.p, C1, C1, C2 ? d2.p : nullptr, C2, C2, dg.p, db.p, dy.p, C, B, HW, G, 1e-5f, PFD_ACT_SILU,
+                            dws.p, wsb, nullptr);
+    rc |= pfd_gemm_f16(&d, nullptr); }, 20);
+  d.A = d1.p; d.lda = C1; d.A2 = C2 ? d2.p : nullptr; d.lda2 = C2; d.gn_c1 = C1; d.gn_table = dT.p; d.gn_act = PFD_ACT_SILU;
+  const float tab = time_ms([&] {
+    rc |= pfd_groupnorm_table_f16(d1.p, C1, C1, C2 ? d2.p : nullptr, C2, C2, dg.p, db.p, dT.p, B, HW, G, 1e-5f, dws.p, wsb,
+                                  nullptr); }, 20);
+  const float pconv = time_ms([&] { rc |= pfd_gemm_f16(&d, nullptr); }, 20);
+  const float fused = time_ms([&] {
+    rc |= pfd_groupnorm_table_f16(d1.p, C1, C1, C2 ? d2.p : nullptr, C2, C2, dg.p, db.p, dT.p, B, HW, G, 1e-5f, dws.p, wsb,
+                                  nullptr);
+    rc |= pfd_gemm_f16(&d, nullptr); }, 20);
+  printf("bench gn+conv %-30s rc=%d  groupnorm %.1f + conv %.1f = %.1f us | table %.1f + prologue conv %.1f = %.1f us\n",
+         label, rc, gn * 1e3, conv * 1e3, two * 1e3, tab * 1e3, pconv * 1e3, fused * 1e3);
+}
+
 static void bench_attn(const char* label, int B, int H, int Nq, int Nk, int D) {
   const int C = H * D, Nkp = (Nk + 7) / 8 * 8;
   auto Q = rand_h((size_t)B * Nq * C), K = rand_h((size_t)B * Nk * C), Vt = rand_h((size_t)C * B * Nkp);
@@ -737,6 +826,15 @@ int main(int argc, char** argv) {
     bench_gemm("conv3x3 320->320 @64^2 implicit GEMM", 0, 320, 0, 3, 8, 64, 320, 5400);
     return 0;
   }
+  if (argc > 1 && !strcmp(argv[1], "--bench-gn-conv")) {   // GroupNorm + conv: two launches + a tensor vs table + prologue
+    bench_gn_conv("320->320 @64^2", 16, 64, 320, 0, 320);
+    bench_gn_conv("640->320 @64^2 (skip concat)", 16, 64, 320, 320, 320);
+    bench_gn_conv("960->320 @64^2 (skip concat)", 16, 64, 640, 320, 320);
+    bench_gn_conv("640->640 @32^2", 16, 32, 640, 0, 640);
+    bench_gn_conv("1280->640 @32^2 (skip concat)", 16, 32, 640, 640, 640);
+    bench_gn_conv("1920->640 @32^2 (skip concat)", 16, 32, 1280, 640, 640);
+    return 0;
+  }
   if (argc > 1 && !strcmp(argv[1], "--bench-attn")) {
     bench_attn("self-attn 64^2 d40", 8, 8, 4096, 4096, 40);
     bench_attn("self-attn 32^2 d80", 8, 8, 1024, 1024, 80);
@@ -819,15 +917,17 @@ int main(int argc, char** argv) {
       GemmCase v{77, 960, 320, 0, false, false, false, false, 3400}; v.n_split = 640; run_gemm_case(v);
       GemmCase w{130, 480, 64, 0, true, false, false, false, 3200}; w.n_split = 320; run_gemm_case(w);
     }
-    // deep operand ring (counted vmcnt): K shorter than, equal to and longer than the ring, + split-K, conv
-    run_gemm_case({130, 320, 128, 0, true, true, false, false, 3600});
-    run_gemm_case({300, 160, 256, PFD_ACT_GELU, true, true, true, false, 3700});
-    run_gemm_case({300, 320, 1024, 0, true, true, true, false, 3600});
-    run_gemm_case({77, 160, 1344, 0, true, false, false, false, 3700});
-    run_gemm_case({520, 320, 2048, 0, true, true, false, false, 3604});
-    run_gemm_case({130, 160, 1536, 0, true, false, false, false, 3703});
-    run_gemm_case({0, 320, 0, 0, true, true, false, false, 3602, 0, 3, 1, 1, 0, 2, 8, 8, 256});
-    run_gemm_case({0, 160, 0, PFD_ACT_SILU, true, false, true, false, 3700, 0, 3, 2, 1, 0, 2, 10, 8, 128});
+    // wave-specialised forms: 256-row tile with loader waves (48), patch kernel with loader waves (98) / without (99)
+    run_gemm_case({300, 320, 1024, 0, true, true, true, false, 5800});
+    run_gemm_case({0, 320, 0, 0, true, true, false, false, 5800, 0, 3, 1, 1, 0, 2, 8, 8, 256});
+    run_gemm_case({0, 160, 0, PFD_ACT_SILU, true, false, true, false, 5800, 0, 3, 2, 1, 0, 2, 10, 8, 128});
+    run_gemm_case({0, 320, 0, 0, true, true, false, false, 10800, 0, 3, 1, 1, 0, 1, 32, 32, 128});
+    run_gemm_case({0, 160, 0, 0, true, false, true, false, 10802, 0, 3, 1, 1, 0, 1, 64, 64, 128});
+    // GroupNorm(+SiLU) prologue of the patch kernel == pfd_groupnorm_f16 followed by the plain convolution, bit for bit
+    run_gn_conv_case(2, 16, 16, 64, 0, 160, PFD_ACT_SILU, false);
+    run_gn_conv_case(1, 32, 32, 128, 64, 320, PFD_ACT_SILU, true);
+    run_gn_conv_case(2, 64, 64, 64, 128, 160, PFD_ACT_NONE, true);
+    run_gn_conv_case(3, 32, 32, 320, 0, 320, PFD_ACT_SILU, true);
     run_gemm_case({0, 160, 0, PFD_ACT_SILU, true, false, false, false, 0, 0, 3, 2, 1, 0, 2, 10, 8, 128});  // stride 2
     run_gemm_case({0, 160, 0, 0, true, true, false, false, 3402, 0, 3, 1, 1, 1, 1, 5, 6, 128});           // upsample + split
     run_gemm_case({0, 320, 0, 0, true, false, false, false, 0, 8, 3, 2, 0, 0, 1, 9, 9, 64});               // pad 0, ld+8

@@ -14,7 +14,7 @@ import os
 _LIB = None
 _LIB_PATH = os.path.normpath(os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "..", "libpfd_hip.so"))
 
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 ACT_NONE, ACT_GELU, ACT_RELU, ACT_SILU, ACT_GEGLU = 0, 1, 2, 3, 4
 
@@ -31,6 +31,7 @@ class PfdGemmDesc(C.Structure):
         ("B", _i32), ("H", _i32), ("Wd", _i32), ("Cin", _i32), ("Ho", _i32), ("Wo", _i32),
         ("ws", _vp), ("ws_bytes", _sz),
         ("Ct", _vp), ("ldct", _i64), ("n_split", _i32), ("reserved0", _i32),
+        ("gn_table", _vp), ("A2", _vp), ("lda2", _i64), ("gn_c1", _i32), ("gn_act", _i32),
     ]
 
 
@@ -62,6 +63,8 @@ SIGNATURES = {
     "pfd_attention_f16": (_i32, [C.POINTER(PfdAttnDesc), _vp]),
     "pfd_swin_window_attention_f16": (_i32, [C.POINTER(PfdSwinAttnDesc), _vp]),
     "pfd_groupnorm_ws_bytes": (_sz, [_i32, _i32, _i32]),
+    "pfd_groupnorm_table_f16": (_i32, [_vp, _i32, _i64, _vp, _i32, _i64, _vp, _vp, _vp, _i32, _i32, _i32, _f32, _vp, _sz,
+                                       _vp]),
     "pfd_groupnorm_f16": (_i32, [_vp, _i32, _i64, _vp, _i32, _i64, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _f32,
                                  _i32, _vp, _sz, _vp]),
     "pfd_layernorm_f16": (_i32, [_vp, _i64, _vp, _vp, _vp, _i64, _i32, _i32, _f32, _i32, _i32, _i32, _i32, _vp]),

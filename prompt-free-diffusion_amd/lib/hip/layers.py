@@ -105,10 +105,14 @@ class Conv2d(nn.Conv2d, _Packed):
     def _pk(self):
         return self._packed("w", lambda: (pack_conv_weight(self.weight), pack_vec(self.bias)), self.weight, self.bias)
 
-    def hip(self, x, *, ups=False, rowvec=None, res=None, act=ACT_NONE, out=None, out_hw=None, rows_per_rv=None):
+    def hip(self, x, *, ups=False, rowvec=None, res=None, act=ACT_NONE, out=None, out_hw=None, rows_per_rv=None,
+            gn=None):
         w, b = self._pk()
         k, s, p = self.kernel_size[0], self.stride[0], self.padding[0]
         cin = self.in_channels
+        if gn is not None:     # GroupNorm prologue: x (| gn[1]) is the un-normalised input (ops.conv)
+            return ops.conv(x, w, k, stride=s, pad=p, bias=b, rowvec=rowvec, res=res, act=act, out=out,
+                            rows_per_rv=rows_per_rv, gn=gn)
         if cin % 64 == 0:
             if k == 1 and s == 1 and not ups:
                 B, H, W_, _ = x.shape
@@ -167,6 +171,11 @@ class GroupNorm(nn.GroupNorm, _Packed):
     def hip(self, x, x2=None, silu=False):
         g, b = self._pk()
         return ops.groupnorm(x, g, b, self.num_groups, self.eps, x2=x2, silu=silu)
+
+    def hip_table(self, x, x2=None):
+        """statistics only, as the affine table of the consumer convolution's prologue (ops.groupnorm_table)"""
+        g, b = self._pk()
+        return ops.groupnorm_table(x, g, b, self.num_groups, self.eps, x2=x2)
 
     def forward(self, x):
         return _io_wrap_nchw(self, x, self.hip)

@@ -142,14 +142,38 @@ def gemm(a, w, *, bias=None, rowvec=None, rows_per_rv=1, res=None, act=ACT_NONE,
     return out
 
 
+def conv_gn_fusable(B, H, W_, C1, C2, N, ksize=3, stride=1, pad=1):
+    """True when conv(..., gn=...) is served (PfdGemmDesc.gn_table: the 3x3 patch kernel) AND pays: at 16-wide
+    images GroupNorm is the single-launch small-slab kernel, cheaper than statistics + table."""
+    return (ksize == 3 and stride == 1 and pad == 1 and W_ in (32, 64) and H % (256 // W_) == 0 and
+            (B * H * W_) % 256 == 0 and N % 160 == 0 and C1 % 64 == 0 and C2 % 64 == 0)
+
+
 def conv(x, w, ksize, *, stride=1, pad=None, ups=False, bias=None, rowvec=None, res=None, act=ACT_NONE,
-         out=None, tile=0, out_hw=None, rows_per_rv=None):
+         out=None, tile=0, out_hw=None, rows_per_rv=None, gn=None):
     """Implicit-GEMM convolution of an NHWC image x[B,H,W,Cin] (Cin % 64 == 0) with packed
-    weights w[N, ksize*ksize*Cin]; returns [B,Ho,Wo,N].  rowvec: [B, N] per-sample vector."""
+    weights w[N, ksize*ksize*Cin]; returns [B,Ho,Wo,N].  rowvec: [B, N] per-sample vector.
+    gn = (table, x2, silu): GroupNorm(+SiLU) of the virtual concat [x | x2] applied while the input is staged
+    (table from groupnorm_table; see PfdGemmDesc.gn_table) -- x is then the UN-normalised tensor."""
     _chk16(x, "conv x")
     _chk16(w, "conv W")
     B, H, W_, Cin = x.shape
-    if x.stride(2) != x.stride(3) * Cin and x.stride(2) < Cin:
+    x2 = None
+    if gn is not None:
+        table, x2, gn_silu = gn
+        C1 = Cin
+        if x2 is not None:
+            _chk16(x2, "conv x2")
+            if x2.shape[:3] != x.shape[:3] or x2.device != x.device:
+                raise ValueError(f"conv: x2 {tuple(x2.shape)} does not match x {tuple(x.shape)}")
+            ld2 = x2.stride(2)
+            if x2.stride(1) != ld2 * W_ or (B > 1 and x2.stride(0) != ld2 * W_ * H):
+                raise ValueError("conv: x2 must be dense over (B, H, W)")
+            Cin = C1 + x2.shape[-1]
+        if table.dtype != torch.float32 or table.device != x.device or tuple(table.shape) != (B, 2, Cin) or \
+                not table.is_contiguous():
+            raise ValueError(f"conv: gn table {tuple(table.shape)} {table.dtype} is not a float32 [{B}, 2, {Cin}]")
+    if x.stride(2) < x.shape[-1]:
         raise ValueError("conv: bad pixel stride")
     lda = x.stride(2)
     if x.stride(1) != lda * W_ or (B > 1 and x.stride(0) != lda * W_ * H):
@@ -182,11 +206,15 @@ def conv(x, w, ksize, *, stride=1, pad=None, ups=False, bias=None, rowvec=None, 
     d.ksize, d.stride, d.pad, d.ups = ksize, stride, pad, 1 if ups else 0
     d.B, d.H, d.Wd, d.Cin, d.Ho, d.Wo = B, H, W_, Cin, Ho, Wo
     d.ws, d.ws_bytes = _workspace(x.device).data_ptr(), _WS_BYTES
+    if gn is not None:
+        d.gn_table, d.gn_c1, d.gn_act = table.data_ptr(), C1, ACT_SILU if gn_silu else ACT_NONE
+        if x2 is not None:
+            d.A2, d.lda2 = x2.data_ptr(), x2.stride(2)
     if _TRACE:
         _trace(d)
     lib = _lib()
     rc = lib.pfd_gemm_f16_ex(_byref(d), tile, _stream()) if tile else lib.pfd_gemm_f16(_byref(d), _stream())
-    _b.check(rc, f"pfd_gemm_f16(conv) M{M} N{N} K{K}")
+    _b.check(rc, f"pfd_gemm_f16(conv) M{M} N{N} K{K}" + (" with GroupNorm prologue" if gn is not None else ""))
     return out
 
 
@@ -264,6 +292,27 @@ def groupnorm(x, gamma, beta, groups, eps, *, x2=None, silu=False, out=None):
                                eps, ACT_SILU if silu else ACT_NONE, ws.data_ptr(), wsb, _stream())
     _b.check(rc, f"pfd_groupnorm_f16 B{B} HW{HW} C{C1}+{C2}")
     return out
+
+
+def groupnorm_table(x, gamma, beta, groups, eps, *, x2=None):
+    """GroupNorm statistics of NHWC x[B,H,W,C1] (| x2) as the per-(sample, channel) affine map the convolution's
+    GroupNorm prologue applies: float32 [B, 2, C1+C2] = (rstd * gamma | beta - mean * rstd * gamma)."""
+    _chk16(x, "groupnorm_table x")
+    B = x.shape[0]
+    C1 = x.shape[-1]
+    HW = x.numel() // (B * C1)
+    C2 = 0 if x2 is None else x2.shape[-1]
+    if x2 is not None:
+        _chk16(x2, "groupnorm_table x2")
+    table = torch.empty((B, 2, C1 + C2), dtype=torch.float32, device=x.device)
+    lib = _lib()
+    wsb = lib.pfd_groupnorm_ws_bytes(B, C1 + C2, HW)
+    ws = torch.empty(wsb, dtype=torch.uint8, device=x.device)
+    rc = lib.pfd_groupnorm_table_f16(x.data_ptr(), C1, x.stride(-2), _ptr(x2), C2, 0 if x2 is None else x2.stride(-2),
+                                     gamma.data_ptr(), beta.data_ptr(), table.data_ptr(), B, HW, groups, eps,
+                                     ws.data_ptr(), wsb, _stream())
+    _b.check(rc, f"pfd_groupnorm_table_f16 B{B} HW{HW} C{C1}+{C2}")
+    return table
 
 
 def layernorm(x, gamma, beta, eps=1e-5, out=None):

@@ -14,6 +14,7 @@ vector (`h + emb_out`, :272), the residual (`skip_connection(x) + h`, :274) and 
 upsampling (:114) fused into their prologue/epilogue.
 """
 import copy
+import os
 from functools import partial
 
 import torch
@@ -108,6 +109,12 @@ class Downsample(nn.Module):
 
 
 class ResBlock(TimestepBlock):
+    # GroupNorm -> SiLU inside the consumer convolution's input staging (PfdGemmDesc.gn_table) instead of a standalone
+    # launch.  Bit-identical, and measured SLOWER on MI355X (profiles/r02_gn_prologue_ab.log: the affine map + SiLU on
+    # the patch kernel's loader waves costs the convolution 20-26 us, the apply pass it removes 13-18 us; end to end
+    # 6.58 vs 6.68 images/s), so it is off unless PFD_GN_PROLOGUE=1 (tests switch it per call).
+    fuse_groupnorm = os.environ.get("PFD_GN_PROLOGUE", "0") == "1"
+
     def __init__(self, channels, emb_channels, dropout, out_channels=None, use_conv=False,
                  use_scale_shift_norm=False, dims=2, use_checkpoint=False, up=False, down=False):
         super().__init__()
@@ -144,7 +151,12 @@ class ResBlock(TimestepBlock):
         C1 = x.shape[-1]
         C2 = 0 if x2 is None else x2.shape[-1]
         assert C1 + C2 == self.channels
-        hn = self.in_layers[0].hip(x, x2, silu=True)                      # [B,H,W,C1+C2]
+        B, H, W_, _ = x.shape
+        # GroupNorm -> SiLU -> conv3x3 (:254-259, 268-270): where the patch kernel serves the convolution the
+        # normalise + activate pass runs inside its input staging (the normalised tensor is never written)
+        fuse = self.fuse_groupnorm
+        fuse_in = fuse and ops.conv_gn_fusable(B, H, W_, C1, C2, self.out_channels)
+        fuse_out = fuse and ops.conv_gn_fusable(B, H, W_, self.out_channels, 0, self.out_channels)
         rows_per_rv = None
         if emb is not None:
             table, cols, shared = emb
@@ -154,8 +166,12 @@ class ResBlock(TimestepBlock):
                 rows_per_rv = 1 << 30
         else:
             e = self.emb_layers[1].hip(semb)                               # [B, Cout]
-        h = self.in_layers[2].hip(hn, rowvec=e, rows_per_rv=rows_per_rv)   # conv + bias + emb
-        h = self.out_layers[0].hip(h, silu=True)
+        if fuse_in:
+            h = self.in_layers[2].hip(x, rowvec=e, rows_per_rv=rows_per_rv,
+                                      gn=(self.in_layers[0].hip_table(x, x2), x2, True))
+        else:
+            hn = self.in_layers[0].hip(x, x2, silu=True)                   # [B,H,W,C1+C2]
+            h = self.in_layers[2].hip(hn, rowvec=e, rows_per_rv=rows_per_rv)   # conv + bias + emb
         skip = self.skip_connection
         if isinstance(skip, nn.Identity):
             assert x2 is None
@@ -170,7 +186,9 @@ class ResBlock(TimestepBlock):
         else:
             assert x2 is None
             sk = skip.hip(x)
-        return self.out_layers[3].hip(h, res=sk)
+        if fuse_out:
+            return self.out_layers[3].hip(h, res=sk, gn=(self.out_layers[0].hip_table(h), None, True))
+        return self.out_layers[3].hip(self.out_layers[0].hip(h, silu=True), res=sk)
 
     def forward(self, x, emb):
         semb = ops.activation(emb.to(torch.float16).contiguous(), ops.ACT_SILU)

@@ -119,6 +119,43 @@ def test_conv_layers(cin, cout, k, s, ups, hw):
     close(ops.to_nchw(y, torch.float32), ref)
 
 
+@pytest.mark.parametrize("B,hw,c1,c2,cout,silu", [(2, 32, 128, 64, 320, True), (1, 64, 64, 0, 160, True),
+                                                  (3, 32, 320, 0, 320, False)])
+def test_conv_groupnorm_prologue(B, hw, c1, c2, cout, silu):
+    """GroupNorm32 -> SiLU -> conv3x3 (openaimodel.py:254-259) with the normalise / activate pass inside the patch
+    kernel's input staging: identical to the two-launch form, and equal to torch fp32 within fp16 noise."""
+    from lib.hip import layers as L
+    from lib.hip import ops
+    torch.manual_seed(4)
+    C = c1 + c2
+    gn = L.GroupNorm(32, C, eps=1e-5).half().cuda()
+    with torch.no_grad():
+        gn.weight.normal_(1.0, 0.2)
+        gn.bias.normal_(0.0, 0.2)
+    conv = L.Conv2d(C, cout, 3, padding=1).half().cuda()
+    x1 = _dev(B, hw, hw, c1) * 1.5 + 0.3
+    x2 = _dev(B, hw, hw, c2, seed=5) if c2 else None
+    res, e = _dev(B, hw, hw, cout, seed=6), _dev(B, cout, seed=7)
+    assert ops.conv_gn_fusable(B, hw, hw, c1, c2, cout)
+    table = gn.hip_table(x1, x2)
+    assert table.shape == (B, 2, C) and table.dtype == torch.float32
+    y = conv.hip(x1, rowvec=e, res=res, gn=(table, x2, silu))
+    two = conv.hip(gn.hip(x1, x2, silu=silu), rowvec=e, res=res)
+    assert torch.equal(y, two)
+    cat = (x1 if x2 is None else torch.cat([x1, x2], -1)).float().permute(0, 3, 1, 2)
+    hn = F.group_norm(cat, 32, gn.weight.float(), gn.bias.float(), 1e-5)
+    hn = F.silu(hn) if silu else hn
+    ref = F.conv2d(hn, conv.weight.float(), conv.bias.float(), padding=1) + e.float()[:, :, None, None]
+    close(y.float(), ref.permute(0, 2, 3, 1) + res.float())
+    # shapes the patch kernel does not take are refused, never served by another kernel without the prologue
+    x8 = _dev(1, 8, 8, 64)
+    c8 = L.Conv2d(64, 160, 3, padding=1).half().cuda()
+    g8 = L.GroupNorm(32, 64).half().cuda()
+    assert not ops.conv_gn_fusable(1, 8, 8, 64, 0, 160)
+    with pytest.raises(RuntimeError):
+        c8.hip(x8, gn=(g8.hip_table(x8), None, True))
+
+
 def test_groupnorm_concat_and_layernorm():
     from lib.hip import ops
     x1, x2 = _dev(2, 6, 5, 320), _dev(2, 6, 5, 640, seed=3)

@@ -228,6 +228,16 @@ def test_unet_c2_batch8_vs_oracle(net, param_shapes):
         check(f"C2 UNet eps sample {s} (apply_model)", eps[s:s + 1], ref)
         check(f"C2 UNet eps sample {s} (sampler path, zero-uncond shortcut)", eps2[s:s + 1], ref)
     assert float((eps2.float() - eps.float()).abs().max()) < 2e-2     # two routes to the same numbers
+    # the GroupNorm prologue of the patch convolution (optional path, 36 of the 44 ResBlock convolutions at this shape)
+    # against standalone GroupNorm launches: same statistics, same affine map -> the same bits
+    from lib.model_zoo.openaimodel import ResBlock
+    was = ResBlock.fuse_groupnorm
+    ResBlock.fuse_groupnorm = not was
+    try:
+        eps3 = net.apply_model({'type': 'image', 'x': x.cuda().half()}, t.cuda(), {'type': 'image', 'c': c.cuda().half()})
+    finally:
+        ResBlock.fuse_groupnorm = was
+    assert torch.equal(eps3, eps)
 
 
 def test_controlnet_c3_eps_vs_oracle(net, param_shapes):
