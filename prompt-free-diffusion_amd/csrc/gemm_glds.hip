@@ -28,6 +28,8 @@
 // Algorithmic bytes / flops per launch: see pfd_prof_begin below (operands + result once; 2MNK).
 #include <type_traits>
 
+#include <stdlib.h>
+
 #include "pfd_common.h"
 
 namespace {
@@ -472,9 +474,21 @@ __global__ __launch_bounds__(WAVES_M * 128) void gemm160_kernel(const G160Params
       if (kt_begin + s < kt_end) issue(s, kt_begin + s);
     int buf = 0;
     for (int kt = kt_begin; kt < kt_end; ++kt) {
-      if (NBUF > 2 && kt + DEPTH - 1 < kt_end) __builtin_amdgcn_s_waitcnt(WAIT_KEEP);
-      else __builtin_amdgcn_s_waitcnt(0);
-      __syncthreads();  // tile kt visible to all waves; everyone is done with the buffer of tile kt-1
+      // tile kt visible to all waves; everyone is done with the buffer of tile kt-1
+      if constexpr (NBUF > 2) {
+        // counted wait: only the OLDEST tile has to have landed.  The barrier must be the raw instruction:
+        // __syncthreads() carries a fence that hipcc lowers to s_waitcnt vmcnt(0) -- every LDS-DMA piece is a pending
+        // LDS write on the VM counter -- which drains the whole ring once per K step (that is how the round-1 ring
+        // "measured slower": it never had more than one tile in flight)
+        if (kt + DEPTH - 1 < kt_end) __builtin_amdgcn_s_waitcnt(WAIT_KEEP);
+        else __builtin_amdgcn_s_waitcnt(0x0F70);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+      } else {
+        __builtin_amdgcn_s_waitcnt(0);
+        __syncthreads();
+      }
       if (kt + DEPTH < kt_end) {
         int nb = buf + DEPTH;
         if (nb >= NBUF) nb -= NBUF;
@@ -1260,6 +1274,12 @@ int launch_patch(G160Params& p, hipStream_t s, bool ws = false) {
 
 }  // namespace
 
+// PFD_RING=0 in the environment keeps every problem on the 2-stage kernels (A/B runs)
+static bool ring_on() {
+  static const bool on = !(getenv("PFD_RING") && atoi(getenv("PFD_RING")) == 0);
+  return on;
+}
+
 // Called by pfd_gemm_f16_ex (gemm_conv.hip).  Returns 1 if the problem is not for this path.
 // variant: 0 = heuristic, 44 / 24 / 22 force <WAVES_M,WMB>; splits: 0 = heuristic.
 // N % 160 == 0 runs 160-wide tiles (every UNet / ControlNet width); otherwise N % 128 == 0 runs the same
@@ -1346,13 +1366,16 @@ int pfd_gemm160_try(const PfdGemmDesc* d, int variant, int splits, hipStream_t s
     // block's store pass with the other's K loop (GEGLU 32768x2560x320: 87 -> 79 us, qkv 8192x1920x640: 42 -> 35);
     // mid-K problems with <= 256 tiles of 128 rows take 64-row tiles (8192x640x2560: 54 -> 46 us)
     if (p.ksize == 0 && variant == 44 && p.M >= 8192 && nk_all <= 20) variant = 24;
+    // 128-row tiles that fill the chip at most once run the 3-stage ring (one 110 KB block per CU is no loss
+    // there): 8192x640x2560 46 -> 38 us, 8192x640x1280 25 -> 24 (profiles/r02_ring_replay.log)
+    if (ring_on() && bn == 160 && p.ksize == 0 && variant == 24 && t128 <= 256 && nk_all >= 16) variant = 25;
     if (p.ksize == 0 && variant == 24 && nk_all <= 40 && t128 <= 256 && tiles(64) >= 384) variant = 22;
     // implicit-GEMM convolutions (stride 2, fused upsample, widths the patch kernel does not take) run long K loops
     // of 53 KB stages: with the DMA pieces on four dedicated loader waves they gain 5-17 % (32768 x 640 x 5760
     // upsample conv: 225 -> 192 us = 1260 TF); the short-K linears do not (profiles/r02_wave_specialised_ab.log)
     if (variant == 44 && p.ksize > 0) variant = 48;
   }
-  const int bm = (variant == 44 || variant == 48) ? 256 : (variant == 24 || variant == 26) ? 128 : 64;
+  const int bm = (variant == 44 || variant == 48) ? 256 : (variant == 24 || variant == 25) ? 128 : 64;
   if (splits == 0) {
     splits = 1;
     const long tl = tiles(bm);
@@ -1360,12 +1383,12 @@ int pfd_gemm160_try(const PfdGemmDesc* d, int variant, int splits, hipStream_t s
     if (p.act != PFD_ACT_GEGLU && d->ws && (variant == 44 || variant == 48) && tl < 200 && nk >= 48 &&
         (size_t)2 * p.M * p.N * 4 <= d->ws_bytes) {
       splits = 2;  // 128 tiles of 256x160: two K halves fill the chip (758 vs 579 TF at 640->640 @32^2)
-    } else if (p.act != PFD_ACT_GEGLU && d->ws && variant == 24 && tl < 256) {
+    } else if (p.act != PFD_ACT_GEGLU && d->ws && (variant == 24 || variant == 25) && tl < 256) {
       splits = (int)((512 + tl - 1) / tl);
       if (splits > 8) splits = 8;
       while (splits > 1 && nk / splits < 16) --splits;  // the slab round trip must stay small vs the K loop
       while (splits > 1 && (size_t)splits * p.M * p.N * 4 > d->ws_bytes) --splits;
-    } else if (p.act != PFD_ACT_GEGLU && d->ws && variant == 22 && tl <= 128 && nk >= 16) {
+    } else if (p.act != PFD_ACT_GEGLU && d->ws && (variant == 22 || variant == 23) && tl <= 128 && nk >= 16) {
       splits = (int)(256 / tl);   // M <= 1024 rows (8^2 level, cond-half projections): 25 -> 21 us
       if (splits > 4) splits = 4;
       while (splits > 1 && (size_t)splits * p.M * p.N * 4 > d->ws_bytes) --splits;
@@ -1373,6 +1396,16 @@ int pfd_gemm160_try(const PfdGemmDesc* d, int variant, int splits, hipStream_t s
   }
   if (splits > 1 && (!d->ws || (size_t)splits * p.M * p.N * 4 > d->ws_bytes || p.act == PFD_ACT_GEGLU)) splits = 1;
   p.splits = splits;
+  if (auto_variant && bn == 160 && ring_on()) {
+    // Problems whose blocks fill the chip once (the 16^2 / 8^2 levels: <= 256 tiles, or split-K slices of them) are
+    // bound by the DMA round trip per K tile, not by MFMA or LDS capacity: they take the deep operand rings (3 K tiles
+    // in flight on 64-row tiles, 2 on 128-row tiles; counted vmcnt + raw barrier).  Cold replay of the sampler's launch
+    // list: 2048x1280x1280 23 -> 18 us, 4096x640x640 15 -> 12.5, 8^2 convs 512x1280x11520 38 -> 34, 512x1280x23040
+    // 60 -> 51, GEGLU 512x10240x1280 30 -> 24 (profiles/r02_ring_replay.log).
+    const int nk_split = nk_all / splits;
+    if (variant == 22 && tiles(64) * splits <= 256 && nk_split >= 8) variant = 23;
+    if (variant == 24 && tiles(128) < 256 && nk_split >= 6) variant = 25;
+  }
   const int conv = p.ksize > 0 ? 1 : 0;
   if (variant == 48) {   // 8 MFMA waves + 4 loader waves
     if (bn == 128) return launch160ws<4>(p, 12 + 4 * conv, s) < 0 ? PFD_ELAUNCH : 0;
@@ -1390,6 +1423,9 @@ int pfd_gemm160_try(const PfdGemmDesc* d, int variant, int splits, hipStream_t s
     case 44: return launch160<4, 4>(p, 12 + 4 * conv, s) < 0 ? PFD_ELAUNCH : 0;
     case 24: return launch160<2, 4>(p, 13 + 4 * conv, s) < 0 ? PFD_ELAUNCH : 0;
     case 22: return launch160<2, 2>(p, 14 + 4 * conv, s) < 0 ? PFD_ELAUNCH : 0;
+    // deep operand rings (counted vmcnt): K tiles in flight ahead of the MFMAs = 3 (64-row tile) / 2 (128-row tile)
+    case 23: return launch160<2, 2, 4>(p, 14 + 4 * conv, s) < 0 ? PFD_ELAUNCH : 0;
+    case 25: return launch160<2, 4, 3>(p, 13 + 4 * conv, s) < 0 ? PFD_ELAUNCH : 0;
     default: return PFD_EINVAL;
   }
 }

@@ -917,6 +917,15 @@ int main(int argc, char** argv) {
       GemmCase v{77, 960, 320, 0, false, false, false, false, 3400}; v.n_split = 640; run_gemm_case(v);
       GemmCase w{130, 480, 64, 0, true, false, false, false, 3200}; w.n_split = 320; run_gemm_case(w);
     }
+    // deep operand rings (counted vmcnt + raw barrier): K shorter than, equal to and longer than the ring, split-K, conv
+    run_gemm_case({130, 320, 128, 0, true, true, false, false, 3300});
+    run_gemm_case({300, 160, 256, PFD_ACT_GELU, true, true, true, false, 3500});
+    run_gemm_case({300, 320, 1024, 0, true, true, true, false, 3300});
+    run_gemm_case({77, 160, 1344, 0, true, false, false, false, 3500});
+    run_gemm_case({520, 320, 2048, 0, true, true, false, false, 3304});
+    run_gemm_case({130, 160, 1536, 0, true, false, false, false, 3503});
+    run_gemm_case({0, 320, 0, 0, true, true, false, false, 3302, 0, 3, 1, 1, 0, 2, 8, 8, 256});
+    run_gemm_case({0, 160, 0, PFD_ACT_SILU, true, false, true, false, 3500, 0, 3, 2, 1, 0, 2, 10, 8, 128});
     // wave-specialised forms: 256-row tile with loader waves (48), patch kernel with loader waves (98) / without (99)
     run_gemm_case({300, 320, 1024, 0, true, true, true, false, 5800});
     run_gemm_case({0, 320, 0, 0, true, true, false, false, 5800, 0, 3, 1, 1, 0, 2, 8, 8, 256});
