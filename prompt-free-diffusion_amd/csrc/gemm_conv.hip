@@ -15,6 +15,9 @@
 
 namespace {
 
+__device__ __attribute__((aligned(16))) half_t g_zero_halves[8];   // zero-initialised: source of absent epilogue operands
+__device__ __forceinline__ const half_t* pfd_zero_halves() { return g_zero_halves; }
+
 constexpr int BK = 64;
 constexpr int LDS_LD = BK + 8;  // halfs per LDS row
 
@@ -74,8 +77,9 @@ __global__ __launch_bounds__(256) void gemm_conv_kernel(const GemmParams p) {
   int a_b[C_::A_CH], a_y[C_::A_CH], a_x[C_::A_CH];        // conv: output coordinates
 #pragma unroll
   for (int i = 0; i < C_::A_CH; ++i) {
-    const int m = m0 + row0 + 32 * i;
-    a_ok[i] = m < p.M;
+    const int mr = m0 + row0 + 32 * i;
+    a_ok[i] = mr < p.M;
+    const int m = min(mr, p.M - 1);   // rows past M read row M - 1 and are masked to zero
     if (CONV) {
       const int hw = p.Ho * p.Wo;
       const int b = m / hw;
@@ -96,13 +100,20 @@ __global__ __launch_bounds__(256) void gemm_conv_kernel(const GemmParams p) {
   for (int i = 0; i < C_::B_CH; ++i) {
     const int n = n0 + row0 + 32 * i;
     b_ok[i] = n < p.N;
-    b_off[i] = (long)n * p.ldw + cc * 8;
+    b_off[i] = (long)min(n, p.N - 1) * p.ldw + cc * 8;
   }
 
   uint4 ra[C_::A_CH], rb[C_::B_CH];
   const int Hin = p.ups ? 2 * p.H : p.H;
   const int Win = p.ups ? 2 * p.Wd : p.Wd;
 
+  // Tile loads are UNCONDITIONAL: the address is clamped into the operand and the 16 bytes are AND-ed with an all-ones /
+  // all-zero mask.  `ok ? load : 0` is compiled as branch + load + s_waitcnt vmcnt(0) -- one load in flight per thread
+  // instead of A_CH + B_CH (tools/isa_audit.py) -- and a select after the load may be folded back into that branch.
+  auto masked = [](uint4 v, bool ok) {
+    const unsigned m = ok ? 0xFFFFFFFFu : 0u;
+    return make_uint4(v.x & m, v.y & m, v.z & m, v.w & m);
+  };
   auto load_tile = [&](int kt) {
     const int k0 = kt * BK;
     if (CONV) {
@@ -114,23 +125,21 @@ __global__ __launch_bounds__(256) void gemm_conv_kernel(const GemmParams p) {
       for (int i = 0; i < C_::A_CH; ++i) {
         int iy = a_y[i] + ky, ix = a_x[i] + kx;
         const bool ok = a_ok[i] && iy >= 0 && iy < Hin && ix >= 0 && ix < Win;
+        iy = min(max(iy, 0), Hin - 1);
+        ix = min(max(ix, 0), Win - 1);
         if (p.ups) {
           iy >>= 1;
           ix >>= 1;
         }
         const long off = (((long)a_b[i] * p.H + iy) * p.Wd + ix) * p.lda + ci0 + cc * 8;
-        ra[i] = ok ? *reinterpret_cast<const uint4*>(p.A + off) : make_uint4(0, 0, 0, 0);
+        ra[i] = masked(*reinterpret_cast<const uint4*>(p.A + off), ok);
       }
     } else {
 #pragma unroll
-      for (int i = 0; i < C_::A_CH; ++i)
-        ra[i] = a_ok[i] ? *reinterpret_cast<const uint4*>(p.A + a_off[i] + k0)
-                        : make_uint4(0, 0, 0, 0);
+      for (int i = 0; i < C_::A_CH; ++i) ra[i] = masked(*reinterpret_cast<const uint4*>(p.A + a_off[i] + k0), a_ok[i]);
     }
 #pragma unroll
-    for (int i = 0; i < C_::B_CH; ++i)
-      rb[i] = b_ok[i] ? *reinterpret_cast<const uint4*>(p.W + b_off[i] + k0)
-                      : make_uint4(0, 0, 0, 0);
+    for (int i = 0; i < C_::B_CH; ++i) rb[i] = masked(*reinterpret_cast<const uint4*>(p.W + b_off[i] + k0), b_ok[i]);
   };
   auto store_tile = [&](int buf) {
     half_t* As = lds + buf * C_::STAGE_HALFS;
@@ -189,17 +198,28 @@ __global__ __launch_bounds__(256) void gemm_conv_kernel(const GemmParams p) {
     for (int j = 0; j < TN; ++j) {
       const int nl = wn * 32 * TN + j * 32 + l31;
       const int n = n0 + nl;
-      float bcol = 0.f;
-      if (p.bias && !p.bias_per_row && n < p.N) bcol = (float)p.bias[n];
+      // all 1 + 16 + 16 scalar operand loads of this accumulator tile first, unconditional (clamped index; the zero page
+      // with stride 0 for an absent operand): written as `if (p.rowvec) v += rowvec[...]` per element they were 32
+      // serial L2 round trips per tile (tools/isa_audit.py)
+      const int nc = min(n, p.N - 1);
+      const half_t* zp = pfd_zero_halves();
+      const half_t* bcol_p = (p.bias && !p.bias_per_row) ? p.bias + nc : zp;
+      const half_t* brow_p = (p.bias && p.bias_per_row) ? p.bias : zp;
+      const int brow_s = (p.bias && p.bias_per_row) ? 1 : 0;
+      const half_t* rv_p = p.rowvec ? p.rowvec + nc : zp;
+      const long rv_s = p.rowvec ? p.ldrv : 0;
+      const half_t bcol_h = *bcol_p;
+      half_t brow_h[16], rv_h[16];
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int ml = wm * 32 * TM + i * 32 + mfma32_row(r, hi);
-        const int m = m0 + ml;
-        float v = acc[i][j][r] + bcol;
-        if (m < p.M && n < p.N) {
-          if (p.bias && p.bias_per_row) v += (float)p.bias[m];
-          if (p.rowvec) v += (float)p.rowvec[(long)(m / p.rows_per_rv) * p.ldrv + n];
-        }
+        const int m = min(m0 + wm * 32 * TM + i * 32 + mfma32_row(r, hi), p.M - 1);
+        brow_h[r] = brow_p[(long)m * brow_s];
+        rv_h[r] = rv_p[(long)(m / p.rows_per_rv) * rv_s];
+      }
+      const float bcol = (float)bcol_h;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        float v = acc[i][j][r] + bcol + (float)brow_h[r] + (float)rv_h[r];   // rows / columns past M, N are never stored
         if (p.act == PFD_ACT_GELU) v = pfd_gelu(v);
         else if (p.act == PFD_ACT_RELU) v = fmaxf(v, 0.f);
         else if (p.act == PFD_ACT_SILU) v = pfd_silu(v);
