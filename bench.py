@@ -108,6 +108,8 @@ def main():
     ap.add_argument("--config", default="c2", choices=["c2", "c3", "c5"],
                     help="BASELINE.json config: c2 = headline (default); c3 = + ControlNet + SeeCoder-PA; "
                          "c5 = 768x768, 30 (->31) steps, batch 2, non-zero unconditional context")
+    ap.add_argument("--per-sample-image", action="store_true",
+                    help="one reference image (one SeeCoder encode) per sample instead of one per batch (SURVEY 8(d))")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-prof", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="launch the DDIM loop eagerly instead of one hipGraph")
@@ -144,7 +146,8 @@ def main():
             net.ctx['image'].qtransformer.pe_layer = pe.half().to(f'cuda:{local}')
     pipe = PromptFreePipeline(net, rank=rank, world_size=world)
     pipe.enable_graph(not args.no_graph)
-    image = torch.rand((1, 3, args.height, args.width), generator=torch.Generator().manual_seed(1234))
+    image = torch.rand((args.batch if args.per_sample_image else 1, 3, args.height, args.width),
+                       generator=torch.Generator().manual_seed(1234))
     n_global = args.batch * world
     gen = torch.Generator().manual_seed(4321)
     control = torch.rand((1, 3, args.height, args.width), generator=gen) if args.config == "c3" else None
@@ -211,7 +214,7 @@ def main():
             "config": {"workload": f"[{args.config}] SD-v1.5 UNet + seecoder-v1-0"
                                    f"{' + ControlNet + PPE_MLP' if args.config == 'c3' else ''}, {args.height}x{args.width}, "
                                    f"{args.ddim_steps}-step DDIM ({ddim_real} real steps), CFG {args.scale}, fp16, "
-                                   f"batch={args.batch}/GPU, 1 SeeCoder encode + VAE decode per batch",
+                                   f"batch={args.batch}/GPU, {args.batch if args.per_sample_image else 1} SeeCoder encode(s) + VAE decode per batch",
                        "global_batch": n_global, "parallelism": f"dp{world}"},
         }
         if prof:

@@ -190,7 +190,15 @@ class PromptFreePipeline:
             mk.mark()
         xT = shard_xT(n_global, height, width, seed, r, P)
         n = xT.shape[0]
-        cond, zeros = self.encode_reference(image.to(dev), n)
+        if image.shape[0] > 1:
+            # one reference image PER SAMPLE (the "+737 GFLOP/img" variant): SeeCoder is run once per image
+            # (its decoder MHA attends across the batch axis, seecoder.py:70,83 -- a batch of images would mix them)
+            if image.shape[0] != n:
+                raise ValueError(f"{image.shape[0]} reference images for {n} local samples")
+            pairs = [self.encode_reference(image[i:i + 1].to(dev), 1) for i in range(n)]
+            cond, zeros = torch.cat([c for c, _ in pairs]), torch.cat([z for _, z in pairs])
+        else:
+            cond, zeros = self.encode_reference(image.to(dev), n)
         if uncond is None:
             uncond = zeros
         if mk:

@@ -351,6 +351,26 @@ def test_serving_queue_batches_requests_and_matches_direct_calls(net, golden):
     srv.close()
 
 
+def test_one_reference_image_per_sample(net, golden):
+    """SURVEY 8(d)'s variant: a batch whose samples each have their OWN reference image = one SeeCoder encode per sample
+    (never a batched encode: the decoder MHA quirk, seecoder.py:70,83) feeding one DDIM batch; sample i equals the
+    single-image call on image i with the same x_T stream"""
+    from lib.pipeline import PromptFreePipeline, shard_xT
+    img1 = T(golden["see.img"])
+    img2 = img1.flip(-1).contiguous()              # a different image of the same size (a batch tensor needs one size)
+    pipe = PromptFreePipeline(net)
+    both = torch.cat([img1, img2])
+    lat = pipe.generate(both, 2, 64, 64, steps=4, scale=2.0, seed=9, decode=False)[0]
+    assert lat.shape[0] == 2
+    first = pipe.generate(img1, 1, 64, 64, steps=4, scale=2.0, seed=9, decode=False)[0]     # x_T of sample 0 is the
+    assert torch.equal(shard_xT(2, 64, 64, 9, 0, 1)[:1], shard_xT(1, 64, 64, 9, 0, 1))     # same draw in both calls
+    check("per-sample reference image, sample 0 vs the single-image call", lat[:1], first.float().cpu(), 5e-3)
+    same = pipe.generate(img1, 2, 64, 64, steps=4, scale=2.0, seed=9, decode=False)[0]      # image 1 for both samples
+    assert float((lat[1:] - same[1:]).abs().max()) > 1e-3                                  # sample 1 really used image 2
+    with pytest.raises(ValueError):
+        pipe.generate(torch.cat([img1, img2, img1]), 2, 64, 64, steps=4)
+
+
 def test_config_c1_end_to_end_vs_oracle(net, param_shapes):
     """BASELINE config C1 (256x256, 10-step DDIM, batch 1 -- the reference's own CPU-runnable case), whole
     pipeline: SeeCoder context -> 10 CFG steps -> VAE decode, HIP path vs the CPU oracle run on this host on
