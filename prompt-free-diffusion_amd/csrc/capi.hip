@@ -57,7 +57,7 @@ const char* kBucketNames[kProfBuckets] = {
     "gemm_conv_kernel<2,1,true>",  "gemm_conv_kernel<2,2,true>",  "attention_kernel",
     "swin_attn_kernel",            "groupnorm(stats+finalize+apply)", "layernorm_kernel",
     "gemm160_kernel<4,4>(256x160)", "gemm160_kernel<2,4>(128x160)", "gemm160_kernel<2,2>(64x160)",
-    "other",                       "gemm160_kernel<4,4,conv>(256x160)", "gemm160_kernel<2,4,conv>(128x160)",
+    "elementwise / glue",          "gemm160_kernel<4,4,conv>(256x160)", "gemm160_kernel<2,4,conv>(128x160)",
     "gemm160_kernel<2,2,conv>(64x160)", "conv3x3_patch_kernel(256x160)"};
 
 void harvest(ProfSlot& s) {

@@ -250,6 +250,7 @@ extern "C" int pfd_nchw_to_nhwc_f16(const void* x, int32_t src_f32, void* y, int
                                     int32_t W, float mul, float add, int32_t rep, pfd_stream_t stream) {
   if (!x || !y || B <= 0 || C <= 0 || H <= 0 || W <= 0 || rep < 1) return PFD_EINVAL;
   const long n = (long)B * C * H * W;
+  PfdProfScope prof_scope(15, 0.0, 0.0, (hipStream_t)stream);
   hipLaunchKernelGGL(nchw_to_nhwc_kernel, dim3(grid_for(n, 256)), dim3(256), 0, (hipStream_t)stream, x, src_f32,
                      (half_t*)y, B, C, H, W, mul, add, rep);
   return pfd_check_launch("pfd_nchw_to_nhwc_f16");
@@ -260,6 +261,7 @@ extern "C" int pfd_nhwc_to_nchw(const void* x, void* y, int32_t dst_f32, int32_t
   if (!x || !y || B <= 0 || C <= 0 || H <= 0 || W <= 0) return PFD_EINVAL;
   const int HW = H * W;
   dim3 grid((HW + 63) / 64, (C + 63) / 64, B);
+  PfdProfScope prof_scope(15, 0.0, 0.0, (hipStream_t)stream);
   hipLaunchKernelGGL(nhwc_to_nchw_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const half_t*)x, y, dst_f32, B,
                      C, HW, mul, add, lo, hi);
   return pfd_check_launch("pfd_nhwc_to_nchw");
@@ -272,6 +274,7 @@ extern "C" int pfd_im2col_f16(const void* x, int64_t ldx, void* col, int32_t B, 
     return PFD_EINVAL;
   if (Kpad < ksize * ksize * Cin) return PFD_EINVAL;
   const long n = (long)B * Ho * Wo * Kpad;
+  PfdProfScope prof_scope(15, 0.0, 0.0, (hipStream_t)stream);
   hipLaunchKernelGGL(im2col_kernel, dim3(grid_for(n, 256)), dim3(256), 0, (hipStream_t)stream, (const half_t*)x,
                      (long)ldx, (half_t*)col, B, H, W, Cin, ksize, stride, pad, Ho, Wo, Kpad);
   return pfd_check_launch("pfd_im2col_f16");
@@ -281,6 +284,7 @@ extern "C" int pfd_timestep_embedding_f16(const int64_t* t, void* out, int32_t B
                                           pfd_stream_t stream) {
   if (!t || !out || B <= 0 || dim <= 1) return PFD_EINVAL;
   const int n = B * dim;
+  PfdProfScope prof_scope(15, 0.0, 0.0, (hipStream_t)stream);
   hipLaunchKernelGGL(timestep_embedding_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, t,
                      (half_t*)out, B, dim, max_period);
   return pfd_check_launch("pfd_timestep_embedding_f16");
@@ -292,6 +296,7 @@ extern "C" int pfd_cfg_ddim_step(const void* eps, int32_t nb, const float* x, co
   if (!eps || !x || !coef || !x_prev || !pred_x0) return PFD_EINVAL;
   if (nb < 1 || nb > 2 || B <= 0 || C <= 0 || h <= 0 || w <= 0 || (xin_next && (rep < 1 || rep > 2))) return PFD_EINVAL;
   const long n = (long)B * C * h * w;
+  PfdProfScope prof_scope(15, 0.0, 0.0, (hipStream_t)stream);
   hipLaunchKernelGGL(cfg_ddim_kernel, dim3(grid_for(n, 256)), dim3(256), 0, (hipStream_t)stream,
                      (const half_t*)eps, nb, x, noise, coef, x_prev, pred_x0, (half_t*)xin_next, rep, B, C, h, w);
   return pfd_check_launch("pfd_cfg_ddim_step");
@@ -302,6 +307,7 @@ extern "C" int pfd_add_f16(const void* a, const void* b, void* y, int64_t n, pfd
   if ((reinterpret_cast<uintptr_t>(a) & 15) || (reinterpret_cast<uintptr_t>(y) & 15) ||
       (b && (reinterpret_cast<uintptr_t>(b) & 15)))
     return PFD_EINVAL;
+  PfdProfScope prof_scope(15, 0.0, 0.0, (hipStream_t)stream);
   hipLaunchKernelGGL(add_kernel, dim3(grid_for(n / 8 + 1, 256)), dim3(256), 0, (hipStream_t)stream,
                      (const half_t*)a, (const half_t*)b, (half_t*)y, (long)n);
   return pfd_check_launch("pfd_add_f16");
@@ -313,6 +319,7 @@ extern "C" int pfd_axpby_f16(const void* a, float alpha, const void* b, float be
   if ((reinterpret_cast<uintptr_t>(a) & 15) || (reinterpret_cast<uintptr_t>(y) & 15) ||
       (b && (reinterpret_cast<uintptr_t>(b) & 15)))
     return PFD_EINVAL;
+  PfdProfScope prof_scope(15, 0.0, 0.0, (hipStream_t)stream);
   hipLaunchKernelGGL(axpby_kernel, dim3(grid_for(n / 8 + 1, 256)), dim3(256), 0, (hipStream_t)stream,
                      (const half_t*)a, alpha, (const half_t*)b, beta, (half_t*)y, (long)n);
   return pfd_check_launch("pfd_axpby_f16");
@@ -323,6 +330,7 @@ extern "C" int pfd_add_rowvec_f16(const void* x, int64_t ldx, const void* v, voi
   if (!x || !v || !y || R <= 0 || C <= 0) return PFD_EINVAL;
   if ((C & 7) || (ldx & 7) || (ldy & 7)) return PFD_EINVAL;
   const long n = (long)R * (C / 8);
+  PfdProfScope prof_scope(15, 0.0, 0.0, (hipStream_t)stream);
   hipLaunchKernelGGL(add_rowvec_kernel, dim3(grid_for(n, 256)), dim3(256), 0, (hipStream_t)stream,
                      (const half_t*)x, (long)ldx, (const half_t*)v, (half_t*)y, (long)ldy, R, C);
   return pfd_check_launch("pfd_add_rowvec_f16");
@@ -332,6 +340,7 @@ extern "C" int pfd_image_u8_f16(const void* x, void* y, int64_t n, float mul, fl
                                 pfd_stream_t stream) {
   if (!x || !y || n <= 0) return PFD_EINVAL;
   if ((reinterpret_cast<uintptr_t>(x) & 15) || (reinterpret_cast<uintptr_t>(y) & 7)) return PFD_EINVAL;
+  PfdProfScope prof_scope(15, 0.0, 0.0, (hipStream_t)stream);
   hipLaunchKernelGGL(image_u8_kernel, dim3(grid_for(n / 8 + 1, 256)), dim3(256), 0, (hipStream_t)stream,
                      (const half_t*)x, (uint8_t*)y, (long)n, mul, add, f16_image);
   return pfd_check_launch("pfd_image_u8_f16");
@@ -341,6 +350,7 @@ extern "C" int pfd_act_f16(const void* x, void* y, int64_t n, int32_t act, pfd_s
   if (!x || !y || n <= 0) return PFD_EINVAL;
   if (act < PFD_ACT_NONE || act > PFD_ACT_SILU) return PFD_EINVAL;
   if ((reinterpret_cast<uintptr_t>(x) & 15) || (reinterpret_cast<uintptr_t>(y) & 15)) return PFD_EINVAL;
+  PfdProfScope prof_scope(15, 0.0, 0.0, (hipStream_t)stream);
   hipLaunchKernelGGL(act_kernel, dim3(grid_for(n / 8 + 1, 256)), dim3(256), 0, (hipStream_t)stream,
                      (const half_t*)x, (half_t*)y, (long)n, act);
   return pfd_check_launch("pfd_act_f16");

@@ -633,6 +633,7 @@ extern "C" int pfd_layernorm_f16(const void* x, int64_t ldx, const void* gamma, 
     if ((C % 32) || B <= 0 || H <= 0 || W <= 0) return PFD_EINVAL;
     if ((long)B * ((H + 1) / 2) * ((W + 1) / 2) != M) return PFD_EINVAL;
   }
+  PfdProfScope prof_scope(11, 0.0, 4.0 * M * C, (hipStream_t)stream);   // read + write once
   if (!gather4 && C <= 1536 && M >= 8192) {  // below that one row per wave gives more blocks than CUs (2048 x 1280: 7.3 vs 11.5 us)
     constexpr int ROWS = 4;
     const dim3 grid((M + 4 * ROWS - 1) / (4 * ROWS));
@@ -673,6 +674,7 @@ extern "C" int pfd_softmax_rows_f16(const void* x, int64_t ldx, void* y, int64_t
   if (!x || !y || R <= 0 || N <= 0) return PFD_EINVAL;
   if (N & 7) return PFD_ESHAPE;
   if ((ldx & 7) || (ldy & 7)) return PFD_EINVAL;
+  PfdProfScope prof_scope(15, 0.0, 4.0 * R * N, (hipStream_t)stream);
   if (N > 256 * 8 * SM_MAXV)
     hipLaunchKernelGGL(softmax_rows_long_kernel, dim3(R), dim3(256), 0, (hipStream_t)stream, (const half_t*)x,
                        (long)ldx, (half_t*)y, (long)ldy, N, scale);

@@ -78,6 +78,20 @@ __device__ __forceinline__ int xcd_remap(int bid, int nblk) {
 bool pfd_prof_on();
 void pfd_prof_begin(int bucket, double flops, double bytes, hipStream_t stream);
 void pfd_prof_end(hipStream_t stream);
+// event pair around every launch of the enclosing scope (no-op unless pfd_prof_enable(1)); the destructor runs after the
+// `return pfd_check_launch(...)` expression, i.e. after the launches
+struct PfdProfScope {
+  hipStream_t s;
+  bool on;
+  PfdProfScope(int bucket, double flops, double bytes, hipStream_t st) : s(st), on(pfd_prof_on()) {
+    if (on) pfd_prof_begin(bucket, flops, bytes, s);
+  }
+  ~PfdProfScope() {
+    if (on) pfd_prof_end(s);
+  }
+  PfdProfScope(const PfdProfScope&) = delete;
+  PfdProfScope& operator=(const PfdProfScope&) = delete;
+};
 
 // host-side error plumbing (defined in capi.cpp)
 int pfd_check_launch(const char* what);

@@ -183,6 +183,7 @@ extern "C" int pfd_swin_window_attention_f16(const PfdSwinAttnDesc* d, pfd_strea
   p.nWy = p.Hp / WS; p.nWx = p.Wp / WS;
   p.scale = d->scale;
   dim3 grid(p.nWx * p.nWy, p.nH, p.B);
+  PfdProfScope prof_scope(9, 4.0 * p.B * p.nH * (double)(p.nWx * p.nWy) * 144 * 144 * 32, 0.0, (hipStream_t)stream);
   hipLaunchKernelGGL(swin_attn_kernel, grid, dim3(192), 0, (hipStream_t)stream, p);
   return pfd_check_launch("pfd_swin_window_attention_f16");
 }
