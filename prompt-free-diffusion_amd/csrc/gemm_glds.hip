@@ -58,6 +58,7 @@ struct G160Params {
   int B, H, Wd, Cin, Ho, Wo;
   int tiles_m, tiles_n, splits, kt_per_split;
   int nmajor;  // XCD-contiguous tile order: 0 = all N tiles of an M tile together, 1 = all M tiles of an N tile
+  int krot;    // 1 = every M tile starts its K loop at a different K tile (see k_rotation below)
   // GroupNorm(+SiLU) folded into the patch convolution's input staging (PfdGemmDesc.gn_table)
   const float* gn_table;   // [B][2][Cin]: scale plane, shift plane
   const half_t* A2;        // channels >= gn_c1 of the virtual concat
@@ -68,6 +69,21 @@ struct G160Params {
 __device__ __forceinline__ void glds16(const void* src, void* lds_dst) {
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                    (__attribute__((address_space(3))) void*)lds_dst, 16, 0, 0);
+}
+
+// K rotation.  All blocks of a launch start together and take the same time per K step, so the tiles_m blocks that
+// share one weight tile (same N tile, same split) ask for the SAME K tile of W at the same moment: one of them misses
+// to HBM, the others wait on that miss, and at any time only (ring depth) x (N tiles) x (splits) distinct weight
+// tiles are in flight chip-wide -- 1-4 MB against the >= 12 MB that 6 TB/s x ~2 us of loaded HBM latency need.  The
+// layers' weights are cold every time (1.7 GB of other layers pass through the 256 MB MALL between two uses), so the
+// 8^2 / 16^2 levels streamed W at ~1 TB/s (512 x 1280 x 11520: 29.5 MB in 34 us).  Starting M tile m at K tile
+// (m * stride) mod n makes the sharers lead on DIFFERENT parts of W (each part is fetched from HBM once, by its
+// leader, and hit in L2 by the others later): the number of distinct tiles in flight grows by min(tiles_m, n).
+// The fp32 summation order of a row then depends on its M tile (deterministic; PFD_KROT=0 restores the plain order).
+__device__ __forceinline__ int k_rotation(int krot, int tile_m, int tiles_m, int nsteps) {
+  if (!krot || nsteps < 2) return 0;
+  const int stride = max(1, nsteps / max(1, tiles_m));
+  return (tile_m * stride) % nsteps;
 }
 
 // 16-byte LDS store the compiler cannot see: next to pending LDS-DMA pieces hipcc orders every ds_write it knows
@@ -106,8 +122,9 @@ __device__ __forceinline__ bool epilogue_stage(const float4_t (&acc)[WMB][NT], c
   const int l15 = lane & 15, g = lane >> 4;
   const int mw = m0 + wm * WMB * 16 + l15;   // + i*16: this lane's output row in row-tile i
   const int nw = n0 + wn * (16 * NT) + 4 * g;       // + j*16: first of this lane's 4 columns in column-tile j
+  constexpr bool GEGLU_ONLY = NT == 10;      // the 320-wide tile is dispatched for GEGLU projections only
 
-  if (p.splits > 1) {  // split-K: raw fp32 partials, [split][M][N]
+  if (!GEGLU_ONLY && p.splits > 1) {  // split-K: raw fp32 partials, [split][M][N]
 #pragma unroll
     for (int i = 0; i < WMB; ++i) {
       const int m = mw + i * 16;
@@ -119,7 +136,7 @@ __device__ __forceinline__ bool epilogue_stage(const float4_t (&acc)[WMB][NT], c
     return false;
   }
 
-  if (p.Ct && n0 >= p.n_split) {  // transposed tail (tile-uniform): Ct[(n - n_split) * ldct + m] (+ bias)
+  if (!GEGLU_ONLY && p.Ct && n0 >= p.n_split) {  // transposed tail (tile-uniform): Ct[(n - n_split) * ldct + m] (+ bias)
     float bv[NT][4];
     const half_t* bp = p.bias ? p.bias + nw : g_zero_page;   // unconditional 8-byte loads (see pass 1 below)
     const int bstep = p.bias ? 16 : 0;
@@ -149,7 +166,7 @@ __device__ __forceinline__ bool epilogue_stage(const float4_t (&acc)[WMB][NT], c
   //  the GEGLU's 4-byte ones at 1.4 TB/s, measured; on the UNet's short-K linears that store pass was 40-60 %
   //  of the launch (profiles/r02_ring_and_ablation.log).  Through LDS the stores are whole 16-byte chunks of
   //  contiguous row segments and the residual is read the same way.)
-  const bool geglu = p.act == PFD_ACT_GEGLU;
+  const bool geglu = GEGLU_ONLY || p.act == PFD_ACT_GEGLU;
   const int lrow = wm * WMB * 16 + l15;
   // Every global load of this pass is UNCONDITIONAL and issued before the first use: `if (ptr) v = load` is compiled
   // as branch + load + s_waitcnt vmcnt(0), so the NT bias loads and WMB x NT row-vector loads went out one L2 round
@@ -180,7 +197,7 @@ __device__ __forceinline__ bool epilogue_stage(const float4_t (&acc)[WMB][NT], c
         *reinterpret_cast<half2_t*>(sp + j * 16) = o;
       }
     }
-  } else {
+  } else if constexpr (!GEGLU_ONLY) {
     constexpr int RS = stage_row_bytes(BN);
     char* sp0 = smem + lrow * RS + (wn * (16 * NT) + 4 * g) * 2;
     // one copy of the staging loop per activation (p.act is launch-uniform): `if (p.act == ...) else if ...` per
@@ -255,8 +272,9 @@ __device__ __forceinline__ bool epilogue_stage(const float4_t (&acc)[WMB][NT], c
 template <int BM, int NT, int NTHREADS>
 __device__ __forceinline__ void epilogue_store(const G160Params& p, int m0, int n0, const char* smem, int tid) {
   constexpr int BN = 32 * NT;
-  if (p.splits > 1 || (p.Ct && n0 >= p.n_split)) return;   // written directly by pass 1 (tile-uniform)
-  const bool geglu = p.act == PFD_ACT_GEGLU;
+  constexpr bool GEGLU_ONLY = NT == 10;
+  if (!GEGLU_ONLY && (p.splits > 1 || (p.Ct && n0 >= p.n_split))) return;   // written directly by pass 1 (tile-uniform)
+  const bool geglu = GEGLU_ONLY || p.act == PFD_ACT_GEGLU;
   auto store_pass = [&](auto cols_tag) {
     constexpr int COLS = decltype(cols_tag)::value;
     constexpr int RS = stage_row_bytes(COLS);
@@ -295,7 +313,7 @@ __device__ __forceinline__ void epilogue_store(const G160Params& p, int m0, int 
     }
   };
   if (geglu) store_pass(std::integral_constant<int, BN / 2>{});
-  else store_pass(std::integral_constant<int, BN>{});
+  else if constexpr (!GEGLU_ONLY) store_pass(std::integral_constant<int, BN>{});
 }
 
 template <int WMB, int NT, int NTHREADS>
@@ -318,9 +336,12 @@ __global__ __launch_bounds__(WAVES_M * 128) void gemm160_kernel(const G160Params
   constexpr int STAGE = (BM + BN) * ROWB;
   constexpr int MAIN_BYTES = NBUF * STAGE;
   constexpr int DEPTH = NBUF - 1;  // K tiles in flight ahead of the one being consumed
-  static_assert(NBUF == 2 || B_INSTR % NW == 0, "counted vmcnt needs the same DMA count in every wave");
+  // counted vmcnt (NBUF > 2) needs the same DMA count in every wave: when the B pieces do not split evenly, the
+  // surplus slots re-issue the piece NW below (same source, same destination)
+  constexpr bool B_DUP = NBUF > 2 && B_INSTR % NW != 0;
   static_assert(MAIN_BYTES <= 160 * 1024, "operand ring exceeds the 160 KiB LDS");
-  static_assert(BM * stage_row_bytes(BN) <= MAIN_BYTES, "the epilogue's staging image reuses the operand ring");
+  // NT = 10 (256 x 320 tile) serves the GEGLU projections only: its staged image is BN / 2 columns wide
+  static_assert(BM * stage_row_bytes(NT == 10 ? BN / 2 : BN) <= MAIN_BYTES, "the epilogue's staging image reuses the operand ring");
   constexpr int SMEM = MAIN_BYTES;
   static_assert(A_INSTR % NW == 0, "A tile must split evenly over the waves");
   __shared__ __attribute__((aligned(1024))) char smem[SMEM];
@@ -379,23 +400,20 @@ __global__ __launch_bounds__(WAVES_M * 128) void gemm160_kernel(const G160Params
   const half_t* b_ptr[B_PER_WAVE];
 #pragma unroll
   for (int j = 0; j < B_PER_WAVE; ++j) {
-    const int q = wave + NW * j;
+    int q = wave + NW * j;
+    if (q >= B_INSTR) q = B_DUP ? q - NW : 0;
     const int r = q * 8 + srow;
     const int c = cpos ^ ((r >> 1) & 7);
-    b_ptr[j] = p.W + (long)(n0 + (q < B_INSTR ? r : 0)) * p.ldw + c * 8;
+    b_ptr[j] = p.W + (long)(n0 + r) * p.ldw + c * 8;
   }
   const int Hin = p.ups ? 2 * p.H : p.H;
   const int Win = p.ups ? 2 * p.Wd : p.Wd;
 
+  // K tiles are walked in rotated order (k_rotation): step i works on tile kt_begin + (i + rot) % nsteps
+  const int nsteps = kt_end - kt_begin;
+  int kt_issue = kt_begin + k_rotation(p.krot, tile_m, p.tiles_m, nsteps);   // next tile to be issued (wave-uniform)
   // conv K walk: tap (ky, kx) outer, channel block inner
   int tap_ky = 0, tap_kx = 0, ci0 = 0;
-  if (CONV) {
-    const int k0 = kt_begin * BK;
-    const int tap = k0 / p.Cin;  // once per block
-    ci0 = k0 - tap * p.Cin;
-    tap_ky = tap / p.ksize;
-    tap_kx = tap - tap_ky * p.ksize;
-  }
   const half_t* a_tap[A_PER_WAVE];  // conv: source pointer for the current tap at ci = 0 (or zero page)
   auto set_tap = [&]() {
 #pragma unroll
@@ -409,17 +427,41 @@ __global__ __launch_bounds__(WAVES_M * 128) void gemm160_kernel(const G160Params
       a_tap[j] = ok ? p.A + a_img[j] + ((long)iy * p.Wd + ix) * p.lda + a_chunk[j] : nullptr;
     }
   };
-  if (CONV) set_tap();
+  auto seek = [&](int kt) {   // (tap, channel block) of K tile kt: once per block and once per wrap-around
+    const int k0 = kt * BK;
+    const int tap = k0 / p.Cin;
+    ci0 = k0 - tap * p.Cin;
+    tap_ky = tap / p.ksize;
+    tap_kx = tap - tap_ky * p.ksize;
+    set_tap();
+  };
+  if (CONV) seek(kt_issue);
 
-  auto issue = [&](int stage, int kt) {
+  auto issue = [&](int stage) {
     char* As = smem + stage * STAGE;
     char* Bs = As + BM * ROWB;
+    const int k0 = kt_issue * BK;
     if (CONV) {
 #pragma unroll
       for (int j = 0; j < A_PER_WAVE; ++j) {
         const half_t* src = a_tap[j] ? a_tap[j] + ci0 : g_zero_page;
         glds16(src, As + (wave + NW * j) * 1024);
       }
+    } else {
+#pragma unroll
+      for (int j = 0; j < A_PER_WAVE; ++j)
+        glds16(a_ok[j] ? a_ptr[j] + k0 : a_ptr[j], As + (wave + NW * j) * 1024);
+    }
+#pragma unroll
+    for (int j = 0; j < B_PER_WAVE; ++j) {
+      const int q = wave + NW * j;
+      if (q < B_INSTR) glds16(b_ptr[j] + k0, Bs + q * 1024);
+      else if (B_DUP) glds16(b_ptr[j] + k0, Bs + (q - NW) * 1024);
+    }
+    if (++kt_issue == kt_end) {  // wrap-around of the rotated walk (wave-uniform)
+      kt_issue = kt_begin;
+      if (CONV) seek(kt_begin);
+    } else if (CONV) {
       ci0 += BK;
       if (ci0 >= p.Cin) {  // next tap (wave-uniform)
         ci0 = 0;
@@ -429,17 +471,6 @@ __global__ __launch_bounds__(WAVES_M * 128) void gemm160_kernel(const G160Params
         }
         set_tap();
       }
-    } else {
-      const int k0 = kt * BK;
-#pragma unroll
-      for (int j = 0; j < A_PER_WAVE; ++j)
-        glds16(a_ok[j] ? a_ptr[j] + k0 : a_ptr[j], As + (wave + NW * j) * 1024);
-    }
-    const int k0 = kt * BK;
-#pragma unroll
-    for (int j = 0; j < B_PER_WAVE; ++j) {
-      const int q = wave + NW * j;
-      if (q < B_INSTR) glds16(b_ptr[j] + k0, Bs + q * 1024);
     }
   };
 
@@ -464,23 +495,23 @@ __global__ __launch_bounds__(WAVES_M * 128) void gemm160_kernel(const G160Params
   // profiles/r01_selftest_ring_ab.log).  Problems that fill the chip only once (<= 256 blocks) and stream
   // COLD weights are bound by the DMA round trip per K tile instead (~1.9 us per tile on the 8^2 convs),
   // so they run NBUF = 4-5 with a counted vmcnt wait: only the oldest tile has to have landed.
-  if (kt_begin < kt_end) {
+  if (nsteps > 0) {
     constexpr int PER_STEP = A_PER_WAVE + B_PER_WAVE;
     constexpr int KEEP = PER_STEP * (DEPTH - 1);  // DMA instructions that may stay outstanding
     static_assert(KEEP < 64, "vmcnt is 6 bits");
     constexpr int WAIT_KEEP = (KEEP & 15) | ((KEEP >> 4) << 14) | (7 << 4) | (15 << 8);
 #pragma unroll
     for (int s = 0; s < DEPTH; ++s)
-      if (kt_begin + s < kt_end) issue(s, kt_begin + s);
+      if (s < nsteps) issue(s);
     int buf = 0;
-    for (int kt = kt_begin; kt < kt_end; ++kt) {
+    for (int st = 0; st < nsteps; ++st) {
       // tile kt visible to all waves; everyone is done with the buffer of tile kt-1
       if constexpr (NBUF > 2) {
         // counted wait: only the OLDEST tile has to have landed.  The barrier must be the raw instruction:
         // __syncthreads() carries a fence that hipcc lowers to s_waitcnt vmcnt(0) -- every LDS-DMA piece is a pending
         // LDS write on the VM counter -- which drains the whole ring once per K step (that is how the round-1 ring
         // "measured slower": it never had more than one tile in flight)
-        if (kt + DEPTH - 1 < kt_end) __builtin_amdgcn_s_waitcnt(WAIT_KEEP);
+        if (st + DEPTH - 1 < nsteps) __builtin_amdgcn_s_waitcnt(WAIT_KEEP);
         else __builtin_amdgcn_s_waitcnt(0x0F70);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
@@ -489,27 +520,32 @@ __global__ __launch_bounds__(WAVES_M * 128) void gemm160_kernel(const G160Params
         __builtin_amdgcn_s_waitcnt(0);
         __syncthreads();
       }
-      if (kt + DEPTH < kt_end) {
+      if (st + DEPTH < nsteps) {
         int nb = buf + DEPTH;
         if (nb >= NBUF) nb -= NBUF;
-        issue(nb, kt + DEPTH);
+        issue(nb);
       }
       const char* base = smem + buf * STAGE;
+      constexpr int NTH = NT > 5 ? 5 : NT;   // B fragments held at a time (the 320-wide tile walks its columns in halves)
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) {
         const int off = ks ? off_k1 : off_k0;
-        half8_t af[WMB], bf[NT];
+        half8_t af[WMB];
 #pragma unroll
         for (int i = 0; i < WMB; ++i)
           af[i] = *reinterpret_cast<const half8_t*>(base + a_row0 + i * 16 * ROWB + off);
 #pragma unroll
-        for (int j = 0; j < NT; ++j)
-          bf[j] = *reinterpret_cast<const half8_t*>(base + b_row0 + j * 16 * ROWB + off);
+        for (int jh = 0; jh < NT; jh += NTH) {
+          half8_t bf[NTH];
 #pragma unroll
-        for (int i = 0; i < WMB; ++i)
+          for (int j = 0; j < NTH; ++j)
+            bf[j] = *reinterpret_cast<const half8_t*>(base + b_row0 + (jh + j) * 16 * ROWB + off);
 #pragma unroll
-          for (int j = 0; j < NT; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[j], af[i], acc[i][j], 0, 0, 0);
+          for (int i = 0; i < WMB; ++i)
+#pragma unroll
+            for (int j = 0; j < NTH; ++j)
+              acc[i][jh + j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[j], af[i], acc[i][jh + j], 0, 0, 0);
+        }
       }
       if (++buf == NBUF) buf = 0;
     }
@@ -531,7 +567,17 @@ __global__ __launch_bounds__(WAVES_M * 128) void gemm160_kernel(const G160Params
 // step for all 12 waves: loaders arrive after vmcnt(0) (their pieces of tile kt landed), consumers after the
 // MFMAs of tile kt - 1; then loaders refill the buffer the consumers just left.
 // ------------------------------------------------------------------------------------------------
-template <bool CONV, int NT>
+// PP ("ping-pong") = the two halves of the consumer waves run one barrier interval apart.  Lock-step consumers all
+// wait for their first fragments at the same moment after every barrier (the MFMA pipes idle for the ds_read latency,
+// ~250 of ~1600 cycles per K step) and then contend for the pipe.  With PP a K step is four barrier intervals; group 0
+// (waves 0-3, one per SIMD) reads the fragments of one 32-deep half step while group 1 (waves 4-7, the other wave of
+// each SIMD) issues the 20 MFMAs of its previous half step, and vice versa -- a SIMD always has exactly one wave in
+// an MFMA segment and the partner's LDS reads are hidden under it (guide 5.5 T3/T5: role split + s_setprio).
+//   interval:   4s        4s+1      4s+2      4s+3      4s+4
+//   group 0:    L(s,0)    M(s,0)    L(s,1)    M(s,1)    L(s+1,0)
+//   group 1:    M(s-1,1)  L(s,0)    M(s,0)    L(s,1)    M(s,1)
+//   loaders:    issue tile s+1 (its buffer was last read in interval 4s-1), then wait for it before barrier 4s+4
+template <bool CONV, int NT, bool PP>
 __global__ __launch_bounds__(768) void gemm160ws_kernel(const G160Params p) {
   constexpr int WMB = 4, NCW = 8, NLW = 4;
   constexpr int BN = 32 * NT, BM = 256;
@@ -558,9 +604,11 @@ __global__ __launch_bounds__(768) void gemm160ws_kernel(const G160Params p) {
   const int nsteps = kt_end - kt_begin;
 
   auto block_barrier = [&]() {
+    __builtin_amdgcn_sched_barrier(0);
     asm volatile("" ::: "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
   };
 
   if (wave >= NCW) {
@@ -603,14 +651,8 @@ __global__ __launch_bounds__(768) void gemm160ws_kernel(const G160Params p) {
     }
     const int Hin = p.ups ? 2 * p.H : p.H;
     const int Win = p.ups ? 2 * p.Wd : p.Wd;
+    int kt_issue = kt_begin + k_rotation(p.krot, tile_m, p.tiles_m, nsteps);   // rotated K walk, see k_rotation
     int tap_ky = 0, tap_kx = 0, ci0 = 0;
-    if (CONV) {
-      const int k0 = kt_begin * BK;
-      const int tap = k0 / p.Cin;
-      ci0 = k0 - tap * p.Cin;
-      tap_ky = tap / p.ksize;
-      tap_kx = tap - tap_ky * p.ksize;
-    }
     const half_t* a_tap[A_PL];
     auto set_tap = [&]() {
 #pragma unroll
@@ -624,11 +666,19 @@ __global__ __launch_bounds__(768) void gemm160ws_kernel(const G160Params p) {
         a_tap[j] = ok ? p.A + a_img[j] + ((long)iy * p.Wd + ix) * p.lda + a_chunk[j] : nullptr;
       }
     };
-    if (CONV) set_tap();
-    auto issue = [&](int stage, int kt) {
+    auto seek = [&](int kt) {
+      const int k0 = kt * BK;
+      const int tap = k0 / p.Cin;
+      ci0 = k0 - tap * p.Cin;
+      tap_ky = tap / p.ksize;
+      tap_kx = tap - tap_ky * p.ksize;
+      set_tap();
+    };
+    if (CONV) seek(kt_issue);
+    auto issue = [&](int stage) {
       char* As = smem + stage * STAGE;
       char* Bs = As + BM * ROWB;
-      const int k0 = kt * BK;
+      const int k0 = kt_issue * BK;
 #pragma unroll
       for (int j = 0; j < A_PL; ++j) {
         const half_t* src;
@@ -638,7 +688,10 @@ __global__ __launch_bounds__(768) void gemm160ws_kernel(const G160Params p) {
       }
 #pragma unroll
       for (int j = 0; j < B_PL; ++j) glds16(b_ptr[j] + k0, Bs + (lw + NLW * j) * 1024);
-      if (CONV) {
+      if (++kt_issue == kt_end) {
+        kt_issue = kt_begin;
+        if (CONV) seek(kt_begin);
+      } else if (CONV) {
         ci0 += BK;
         if (ci0 >= p.Cin) {
           ci0 = 0;
@@ -650,13 +703,18 @@ __global__ __launch_bounds__(768) void gemm160ws_kernel(const G160Params p) {
         }
       }
     };
-    if (nsteps > 0) issue(0, kt_begin);
+    if (nsteps > 0) issue(0);
     for (int s = 0; s < nsteps; ++s) {
       __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): this wave's pieces of K tile s are in LDS
-      block_barrier();                      // (A) tile s complete; consumers are done with tile s - 1
-      if (s + 1 < nsteps) issue((s + 1) & 1, kt_begin + s + 1);
+      block_barrier();                      // (A) tile s complete; every consumer is done reading tile s - 1
+      if (s + 1 < nsteps) issue((s + 1) & 1);
+      if constexpr (PP) {
+        block_barrier();
+        block_barrier();
+        block_barrier();
+      }
     }
-    block_barrier();                        // (B) consumers finished the last tile: LDS is free
+    block_barrier();                        // (B) consumers finished reading the last tile: LDS is free
     block_barrier();                        // (C) the staging image is written
   } else {
     // ================================ consumer waves ================================
@@ -672,30 +730,69 @@ __global__ __launch_bounds__(768) void gemm160ws_kernel(const G160Params p) {
     const int off_k1 = ((4 + g) ^ sw) * 16 + l15 * ROWB;
     const int a_row0 = wm * WMB * 16 * ROWB;
     const int b_row0 = BM * ROWB + wn * (16 * NT) * ROWB;
-    for (int s = 0; s < nsteps; ++s) {
-      block_barrier();                      // (A)
-      const char* base = smem + (s & 1) * STAGE;
-#pragma unroll
-      for (int ks = 0; ks < 2; ++ks) {
+    if constexpr (PP) {
+      half8_t af[WMB], bf[NT];
+      auto rd = [&](int s, int ks) __attribute__((always_inline)) {   // L segment: the 9 (8) fragments of one half step
+        const char* base = smem + (s & 1) * STAGE;
         const int off = ks ? off_k1 : off_k0;
-        half8_t af[WMB], bf[NT];
 #pragma unroll
         for (int i = 0; i < WMB; ++i)
           af[i] = *reinterpret_cast<const half8_t*>(base + a_row0 + i * 16 * ROWB + off);
 #pragma unroll
         for (int j = 0; j < NT; ++j)
           bf[j] = *reinterpret_cast<const half8_t*>(base + b_row0 + j * 16 * ROWB + off);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the stage may be refilled two barriers from here
+      };
+      auto mm = [&]() __attribute__((always_inline)) {               // M segment
+        __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int i = 0; i < WMB; ++i)
 #pragma unroll
           for (int j = 0; j < NT; ++j)
             acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[j], af[i], acc[i][j], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+      };
+      // Both groups run the SAME sequence (barrier, L0, barrier, M0, barrier, L1, barrier, M1) per K step; group 1 passes
+      // one extra barrier first and group 0 one extra barrier last, which puts group 1 exactly one interval behind.
+      const bool g1 = wave >= NCW / 2;        // wave-uniform
+      if (g1) block_barrier();                // 4s (A) of step 0
+      for (int s = 0; s < nsteps; ++s) {
+        block_barrier();                      // group 0: 4s (A)        group 1: 4s + 1
+        rd(s, 0);
+        block_barrier();
+        mm();
+        block_barrier();
+        rd(s, 1);
+        block_barrier();                      // group 0: 4s + 3        group 1: 4(s + 1) (A), or (B) after the last step
+        mm();
       }
+      if (!g1) block_barrier();               // (B)
+    } else {
+      for (int s = 0; s < nsteps; ++s) {
+        block_barrier();                      // (A)
+        const char* base = smem + (s & 1) * STAGE;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+          const int off = ks ? off_k1 : off_k0;
+          half8_t af[WMB], bf[NT];
+#pragma unroll
+          for (int i = 0; i < WMB; ++i)
+            af[i] = *reinterpret_cast<const half8_t*>(base + a_row0 + i * 16 * ROWB + off);
+#pragma unroll
+          for (int j = 0; j < NT; ++j)
+            bf[j] = *reinterpret_cast<const half8_t*>(base + b_row0 + j * 16 * ROWB + off);
+#pragma unroll
+          for (int i = 0; i < WMB; ++i)
+#pragma unroll
+            for (int j = 0; j < NT; ++j)
+              acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[j], af[i], acc[i][j], 0, 0, 0);
+        }
+      }
+      block_barrier();                        // (B)
     }
-    block_barrier();                        // (B)
     epilogue_stage<WMB, NT>(acc, p, lane, m0, n0, wm, wn, split, smem);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    block_barrier();                        // (C)
+    block_barrier();                          // (C)
   }
   epilogue_store<BM, NT, 768>(p, m0, n0, smem, tid);
 }
@@ -867,7 +964,8 @@ __global__ __launch_bounds__(512) void conv3x3_patch_kernel(const G160Params p) 
 // 12 waves) and epilogue; the consumers' instruction stream is ds_read + MFMA only.
 // ------------------------------------------------------------------------------------------------
 // GN: 0 = plain input, 1 = GroupNorm affine map in the staging path, 2 = affine map + SiLU
-template <int GN>
+// PP: ping-pong consumer groups, four barrier intervals per tap (see gemm160ws_kernel)
+template <int GN, bool PP>
 __global__ __launch_bounds__(768) void conv3x3_patch_ws_kernel(const G160Params p) {
   constexpr int NCW = 8, NLW = 4, WMB = 4;
   constexpr int PATCH_BYTES = PATCH_ROWS * ROWB;  // 51200
@@ -895,12 +993,29 @@ __global__ __launch_bounds__(768) void conv3x3_patch_ws_kernel(const G160Params 
   const int hw = H * W;
   const int b = m0 / hw;
   const int y0 = (m0 - b * hw) / W;
-  const int nsteps = (cb_end - cb_begin) * 9;
+  const int ncbs = max(0, cb_end - cb_begin);
+  const int nsteps = ncbs * 9;
+  // channel blocks are walked in rotated order (k_rotation): the i-th block of this tile is cbv(i)
+  const int cb_rot = k_rotation(p.krot, tile_m, p.tiles_m, ncbs);
+  auto cbv = [&](int i) -> int {
+    int c = i + cb_rot;
+    if (c >= ncbs) c -= ncbs;
+    return cb_begin + c;
+  };
 
   auto block_barrier = [&]() {
+    __builtin_amdgcn_sched_barrier(0);
     asm volatile("" ::: "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  auto pp_barriers = [&]() {   // the three extra barriers of a ping-pong step (loader side)
+    if constexpr (PP) {
+      block_barrier();
+      block_barrier();
+      block_barrier();
+    }
   };
 
   if (wave >= NCW) {
@@ -994,14 +1109,14 @@ __global__ __launch_bounds__(768) void conv3x3_patch_ws_kernel(const G160Params 
       };
       uint4 ra = make_uint4(0, 0, 0, 0), rb = ra;
       if (nsteps > 0) {
-        issue_w(0, 0, cb_begin);
-        load_tab(cb_begin);
+        issue_w(0, 0, cbv(0));
+        load_tab(cbv(0));
         {                                    // the whole first patch: every load first, then the transforms
           uint4 fa[9], fb[9];
 #pragma unroll
           for (int tp = 0; tp < 9; ++tp) {
-            fa[tp] = fetch(cb_begin, pix_a[tp]);
-            fb[tp] = lw < 2 ? fetch(cb_begin, pix_b[tp]) : make_uint4(0, 0, 0, 0);
+            fa[tp] = fetch(cbv(0), pix_a[tp]);
+            fb[tp] = lw < 2 ? fetch(cbv(0), pix_b[tp]) : make_uint4(0, 0, 0, 0);
           }
 #pragma unroll
           for (int tp = 0; tp < 9; ++tp) {
@@ -1009,68 +1124,74 @@ __global__ __launch_bounds__(768) void conv3x3_patch_ws_kernel(const G160Params 
             if (lw < 2 && 6 * tp + 4 + lw < P_INSTR) put(0, 6 * tp + 4 + lw, xform(fb[tp], pix_b[tp] >= 0));
           }
         }
-        if (cb_begin + 1 < cb_end) {         // request tap 0's pieces of the second patch + its table
-          load_tab(cb_begin + 1);
-          ra = fetch(cb_begin + 1, pix_a[0]);
-          if (lw < 2) rb = fetch(cb_begin + 1, pix_b[0]);
+        if (1 < ncbs) {                      // request tap 0's pieces of the second patch + its table
+          load_tab(cbv(1));
+          ra = fetch(cbv(1), pix_a[0]);
+          if (lw < 2) rb = fetch(cbv(1), pix_b[0]);
         }
       }
       int stage = 0;
-      for (int cb = cb_begin; cb < cb_end; ++cb) {
-        const int pbuf = (cb - cb_begin) & 1;
-        const bool more = cb + 1 < cb_end;
+      for (int ci = 0; ci < ncbs; ++ci) {
+        const int cb = cbv(ci);
+        const int pbuf = ci & 1;
+        const bool more = ci + 1 < ncbs;
+        const int cb1 = more ? cbv(ci + 1) : cb, cb2 = ci + 2 < ncbs ? cbv(ci + 2) : cb;
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap) {
           __builtin_amdgcn_s_waitcnt(0x0070);   // vmcnt(0) lgkmcnt(0): W pieces landed, pixels arrived, ds_writes done
           block_barrier();                      // (A)
           if (tap < 8) issue_w(stage ^ 1, tap + 1, cb);
-          else if (more) issue_w(stage ^ 1, 0, cb + 1);
+          else if (more) issue_w(stage ^ 1, 0, cb1);
           if (more) {
             // request the next pieces BEFORE transforming the ones that arrived: their latency runs under the VALU work
             uint4 na = ra, nb = rb;
             if (tap < 8) {                        // the next tap's pieces (same patch)
-              na = fetch(cb + 1, pix_a[tap + 1]);
-              if (lw < 2) nb = fetch(cb + 1, pix_b[tap + 1]);
-            } else if (cb + 2 < cb_end) {         // ... or tap 0 of the patch after
-              na = fetch(cb + 2, pix_a[0]);
-              if (lw < 2) nb = fetch(cb + 2, pix_b[0]);
+              na = fetch(cb1, pix_a[tap + 1]);
+              if (lw < 2) nb = fetch(cb1, pix_b[tap + 1]);
+            } else if (ci + 2 < ncbs) {           // ... or tap 0 of the patch after
+              na = fetch(cb2, pix_a[0]);
+              if (lw < 2) nb = fetch(cb2, pix_b[0]);
             }
             const uint4 va = xform(ra, pix_a[tap] >= 0);
             uint4 vb = make_uint4(0, 0, 0, 0);
             if (lw < 2) vb = xform(rb, pix_b[tap] >= 0);
-            if (tap == 8 && cb + 2 < cb_end) load_tab(cb + 2);   // after the last transform with the current table
+            if (tap == 8 && ci + 2 < ncbs) load_tab(cb2);   // after the last transform with the current table
             if (6 * tap + lw < P_INSTR) put(pbuf ^ 1, 6 * tap + lw, va);
             if (lw < 2 && 6 * tap + 4 + lw < P_INSTR) put(pbuf ^ 1, 6 * tap + 4 + lw, vb);
             ra = na;
             rb = nb;
           }
           stage ^= 1;
+          pp_barriers();
         }
       }
     } else {
       if (nsteps > 0) {
 #pragma unroll
         for (int tp = 0; tp < 9; ++tp) {     // the whole first patch
-          if (6 * tp + lw < P_INSTR) issue_patch(0, cb_begin, 6 * tp + lw, off_a[tp]);
-          if (lw < 2 && 6 * tp + 4 + lw < P_INSTR) issue_patch(0, cb_begin, 6 * tp + 4 + lw, off_b[tp]);
+          if (6 * tp + lw < P_INSTR) issue_patch(0, cbv(0), 6 * tp + lw, off_a[tp]);
+          if (lw < 2 && 6 * tp + 4 + lw < P_INSTR) issue_patch(0, cbv(0), 6 * tp + 4 + lw, off_b[tp]);
         }
-        issue_w(0, 0, cb_begin);
+        issue_w(0, 0, cbv(0));
       }
       int stage = 0;
-      for (int cb = cb_begin; cb < cb_end; ++cb) {
-        const int pbuf = (cb - cb_begin) & 1;
-        const bool more = cb + 1 < cb_end;
+      for (int ci = 0; ci < ncbs; ++ci) {
+        const int cb = cbv(ci);
+        const int pbuf = ci & 1;
+        const bool more = ci + 1 < ncbs;
+        const int cb1 = more ? cbv(ci + 1) : cb;
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap) {
           __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): this wave's pieces for this tap (and patch) are in LDS
           block_barrier();                      // (A)
           if (tap < 8) issue_w(stage ^ 1, tap + 1, cb);
-          else if (more) issue_w(stage ^ 1, 0, cb + 1);
+          else if (more) issue_w(stage ^ 1, 0, cb1);
           if (more) {
-            if (6 * tap + lw < P_INSTR) issue_patch(pbuf ^ 1, cb + 1, 6 * tap + lw, off_a[tap]);
-            if (lw < 2 && 6 * tap + 4 + lw < P_INSTR) issue_patch(pbuf ^ 1, cb + 1, 6 * tap + 4 + lw, off_b[tap]);
+            if (6 * tap + lw < P_INSTR) issue_patch(pbuf ^ 1, cb1, 6 * tap + lw, off_a[tap]);
+            if (lw < 2 && 6 * tap + 4 + lw < P_INSTR) issue_patch(pbuf ^ 1, cb1, 6 * tap + 4 + lw, off_b[tap]);
           }
           stage ^= 1;
+          pp_barriers();
         }
       }
     }
@@ -1095,40 +1216,89 @@ __global__ __launch_bounds__(768) void conv3x3_patch_ws_kernel(const G160Params 
     for (int i = 0; i < WMB; ++i)
 #pragma unroll
       for (int j = 0; j < 5; ++j) acc[i][j] = (float4_t){0.f, 0.f, 0.f, 0.f};
-    int stage = 0;
-    for (int cb = cb_begin; cb < cb_end; ++cb) {
-      const char* patch = smem + ((cb - cb_begin) & 1) * PATCH_BYTES;
-      int toff = 0;
+    auto a_off = [&](int i, int toff, int ks) -> int {   // byte offset of A fragment i in the patch (rotation swizzle)
+      const int r = rbase[i] + toff;
+      return r * ROWB + ((((ks * 4 + g) + (r & ~1)) & 7) << 4);
+    };
+    if constexpr (PP) {
+      half8_t af[WMB], bf[5];
+      auto rd = [&](const char* patch, const char* wt, int toff, int ks) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < WMB; ++i) af[i] = *reinterpret_cast<const half8_t*>(patch + a_off(i, toff, ks));
+        const int bo = ks ? boff1 : boff0;
+#pragma unroll
+        for (int j = 0; j < 5; ++j) bf[j] = *reinterpret_cast<const half8_t*>(wt + bo + j * 16 * ROWB);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the weight stage is refilled two barriers from here
+      };
+      auto mm = [&]() __attribute__((always_inline)) {
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int i = 0; i < WMB; ++i)
+#pragma unroll
+          for (int j = 0; j < 5; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[j], af[i], acc[i][j], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+      };
+      // same sequence for both groups; group 1 passes one extra barrier first, group 0 one extra barrier last
+      const bool g1 = wave >= NCW / 2;          // wave-uniform
+      if (g1) block_barrier();
+      int stage = 0;
+      for (int ci = 0; ci < ncbs; ++ci) {
+        const char* patch = smem + (ci & 1) * PATCH_BYTES;
+        int toff = 0;
 #pragma nounroll
-      for (int ky = 0; ky < 3; ++ky) {
+        for (int ky = 0; ky < 3; ++ky) {
 #pragma nounroll
-        for (int kx = 0; kx < 3; ++kx) {
-          block_barrier();                    // (A)
-          const char* wt = smem + OFF_W + stage * WT_BYTES;
-#pragma unroll
-          for (int ks = 0; ks < 2; ++ks) {
-            half8_t af[WMB], bf[5];
-#pragma unroll
-            for (int i = 0; i < WMB; ++i) {
-              const int r = rbase[i] + toff;
-              af[i] = *reinterpret_cast<const half8_t*>(patch + r * ROWB + ((((ks * 4 + g) + (r & ~1)) & 7) << 4));
-            }
-            const int bo = ks ? boff1 : boff0;
-#pragma unroll
-            for (int j = 0; j < 5; ++j) bf[j] = *reinterpret_cast<const half8_t*>(wt + bo + j * 16 * ROWB);
-#pragma unroll
-            for (int i = 0; i < WMB; ++i)
-#pragma unroll
-              for (int j = 0; j < 5; ++j)
-                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[j], af[i], acc[i][j], 0, 0, 0);
+          for (int kx = 0; kx < 3; ++kx) {
+            const char* wt = smem + OFF_W + stage * WT_BYTES;
+            block_barrier();                    // group 0: (A) of this tap; group 1: one interval later
+            rd(patch, wt, toff, 0);
+            block_barrier();
+            mm();
+            block_barrier();
+            rd(patch, wt, toff, 1);
+            block_barrier();
+            mm();
+            stage ^= 1;
+            toff += 1;
           }
-          stage ^= 1;
-          toff += 1;
+          toff += PW - 3;
         }
-        toff += PW - 3;
       }
+      if (!g1) block_barrier();                 // (B)
+    } else {
+      int stage = 0;
+      for (int ci = 0; ci < ncbs; ++ci) {
+        const char* patch = smem + (ci & 1) * PATCH_BYTES;
+        int toff = 0;
+#pragma nounroll
+        for (int ky = 0; ky < 3; ++ky) {
+#pragma nounroll
+          for (int kx = 0; kx < 3; ++kx) {
+            block_barrier();                    // (A)
+            const char* wt = smem + OFF_W + stage * WT_BYTES;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+              half8_t af[WMB], bf[5];
+#pragma unroll
+              for (int i = 0; i < WMB; ++i) af[i] = *reinterpret_cast<const half8_t*>(patch + a_off(i, toff, ks));
+              const int bo = ks ? boff1 : boff0;
+#pragma unroll
+              for (int j = 0; j < 5; ++j) bf[j] = *reinterpret_cast<const half8_t*>(wt + bo + j * 16 * ROWB);
+#pragma unroll
+              for (int i = 0; i < WMB; ++i)
+#pragma unroll
+                for (int j = 0; j < 5; ++j)
+                  acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[j], af[i], acc[i][j], 0, 0, 0);
+            }
+            stage ^= 1;
+            toff += 1;
+          }
+          toff += PW - 3;
+        }
+      }
+      block_barrier();                          // (B)
     }
-    block_barrier();                          // (B)
     epilogue_stage<WMB, 5>(acc, p, lane, m0, n0, wm, wn, split, smem);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     block_barrier();                          // (C)
@@ -1182,6 +1352,25 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const G160Params p) 
   }
 }
 
+// Rotated K walk (k_rotation), measured on the cold replay of the sampler's launch list (profiles/r03_krot_pp_replay.log):
+// linears gain (2048 x 3840 x 1280: 35.2 -> 30.6 us, 2048 x 10240 x 1280 GEGLU 64.9 -> 61.7, 2048 x 1280 x 1280
+// 18.3 -> 17.1, 8192 x 640 x 640 17.1 -> 16.3) and so do the loader-wave implicit-GEMM convolutions (upsample convs
+// 191.9 -> 168.6, 176.0 -> 164.4 us); the split-K convolutions of the 8^2 level lose (512 x 1280 x 23040: 52 -> 66 us:
+// eight rotated streams per XCD instead of one) and the patch kernel is 2-3 % slower, so those keep the plain walk.
+// PFD_KROT: 0 = never, 1 = the selection above (default), 2 = every kernel.
+inline int krot_mode() {
+  static const int m = getenv("PFD_KROT") ? atoi(getenv("PFD_KROT")) : 1;
+  return m;
+}
+// Ping-pong consumer groups (template flag PP of the loader-wave kernels) measured no better than lock-step consumers:
+// patch conv 32768 x 320 x 2880 53.4 -> 53.5 us, x 8640 125.0 -> 128.8; upsample conv 8192 x 1280 x 11520 191.9 -> 202.1
+// (profiles/r03_krot_pp_replay.log) -- the exposed fragment latency it hides is paid back in three more barriers per
+// K step.  Kept selectable for measurements: PFD_PP=1, or forced variants 49 (256-row tile) / 97 (patch kernel).
+inline bool pp_on() {
+  static const bool on = getenv("PFD_PP") && atoi(getenv("PFD_PP")) != 0;
+  return on;
+}
+
 // 1 when streaming W once per XCD would cost more L2-miss traffic than streaming the activations once per XCD
 inline int pick_nmajor(const G160Params& p) {
   const double a_bytes = p.ksize > 0 ? 2.0 * p.B * p.H * p.Wd * p.Cin : 2.0 * p.M * p.K;
@@ -1195,6 +1384,7 @@ int launch160(G160Params& p, int bucket, hipStream_t s) {
   p.tiles_m = (p.M + BM - 1) / BM;
   p.tiles_n = p.N / (32 * NT);
   p.nmajor = pick_nmajor(p);
+  p.krot = krot_mode() == 2 || (krot_mode() == 1 && p.ksize == 0);
   const int nk = p.K / BK;
   p.kt_per_split = (nk + p.splits - 1) / p.splits;
   p.splits = (nk + p.kt_per_split - 1) / p.kt_per_split;
@@ -1220,10 +1410,11 @@ int launch160(G160Params& p, int bucket, hipStream_t s) {
 }
 
 template <int NT>
-int launch160ws(G160Params& p, int bucket, hipStream_t s) {
+int launch160ws(G160Params& p, int bucket, hipStream_t s, bool pp) {
   p.tiles_m = (p.M + 255) / 256;
   p.tiles_n = p.N / (32 * NT);
   p.nmajor = pick_nmajor(p);
+  p.krot = krot_mode() >= 1;
   const int nk = p.K / BK;
   p.kt_per_split = (nk + p.splits - 1) / p.splits;
   p.splits = (nk + p.kt_per_split - 1) / p.kt_per_split;
@@ -1234,8 +1425,13 @@ int launch160ws(G160Params& p, int bucket, hipStream_t s) {
     const double n_out = p.act == PFD_ACT_GEGLU ? p.N / 2 : p.N;
     pfd_prof_begin(bucket, 2.0 * p.M * p.N * p.K, a_bytes + 2.0 * p.N * p.K + 2.0 * p.M * n_out * (p.R ? 2 : 1), s);
   }
-  if (p.ksize > 0) hipLaunchKernelGGL((gemm160ws_kernel<true, NT>), grid, dim3(768), 0, s, p);
-  else hipLaunchKernelGGL((gemm160ws_kernel<false, NT>), grid, dim3(768), 0, s, p);
+  if (p.ksize > 0) {
+    if (pp) hipLaunchKernelGGL((gemm160ws_kernel<true, NT, true>), grid, dim3(768), 0, s, p);
+    else hipLaunchKernelGGL((gemm160ws_kernel<true, NT, false>), grid, dim3(768), 0, s, p);
+  } else {
+    if (pp) hipLaunchKernelGGL((gemm160ws_kernel<false, NT, true>), grid, dim3(768), 0, s, p);
+    else hipLaunchKernelGGL((gemm160ws_kernel<false, NT, false>), grid, dim3(768), 0, s, p);
+  }
   if (p.splits > 1) {
     const long nvec = (long)p.M * (p.N / 8);
     int g = (int)((nvec + 255) / 256);
@@ -1246,10 +1442,12 @@ int launch160ws(G160Params& p, int bucket, hipStream_t s) {
   return pfd_check_launch("pfd_gemm_f16(wave-specialised)");
 }
 
-int launch_patch(G160Params& p, hipStream_t s, bool ws = false) {
+// ws: 0 = 8-wave kernel, 1 = + 4 loader waves, 2 = + ping-pong consumer groups
+int launch_patch(G160Params& p, hipStream_t s, int ws) {
   p.tiles_m = p.M / 256;
   p.tiles_n = p.N / BN;
   p.nmajor = pick_nmajor(p);
+  p.krot = krot_mode() == 2;
   const int ncb = p.Cin / BK;
   p.kt_per_split = (ncb + p.splits - 1) / p.splits;   // channel blocks per split
   p.splits = (ncb + p.kt_per_split - 1) / p.kt_per_split;
@@ -1258,9 +1456,10 @@ int launch_patch(G160Params& p, hipStream_t s, bool ws = false) {
   if (prof)
     pfd_prof_begin(19, 2.0 * p.M * p.N * p.K,
                    2.0 * p.B * p.H * p.Wd * p.Cin + 2.0 * p.N * p.K + 2.0 * p.M * p.N * (p.R ? 2 : 1), s);
-  if (p.gn_table && p.gn_act == PFD_ACT_SILU) hipLaunchKernelGGL(conv3x3_patch_ws_kernel<2>, grid, dim3(768), 0, s, p);
-  else if (p.gn_table) hipLaunchKernelGGL(conv3x3_patch_ws_kernel<1>, grid, dim3(768), 0, s, p);
-  else if (ws) hipLaunchKernelGGL(conv3x3_patch_ws_kernel<0>, grid, dim3(768), 0, s, p);
+  if (p.gn_table && p.gn_act == PFD_ACT_SILU) hipLaunchKernelGGL((conv3x3_patch_ws_kernel<2, false>), grid, dim3(768), 0, s, p);
+  else if (p.gn_table) hipLaunchKernelGGL((conv3x3_patch_ws_kernel<1, false>), grid, dim3(768), 0, s, p);
+  else if (ws == 2) hipLaunchKernelGGL((conv3x3_patch_ws_kernel<0, true>), grid, dim3(768), 0, s, p);
+  else if (ws) hipLaunchKernelGGL((conv3x3_patch_ws_kernel<0, false>), grid, dim3(768), 0, s, p);
   else hipLaunchKernelGGL(conv3x3_patch_kernel, grid, dim3(512), 0, s, p);
   if (p.splits > 1) {
     const long nvec = (long)p.M * (p.N / 8);
@@ -1317,6 +1516,7 @@ int pfd_gemm160_try(const PfdGemmDesc* d, int variant, int splits, hipStream_t s
   p.gn_c1 = d->gn_c1; p.gn_act = d->gn_act;
   if (p.gn_table) {   // GroupNorm prologue: patch kernel or nothing (validated here, PFD_ESHAPE by the caller otherwise)
     if (bn != 160 || (variant != 0 && variant != 98)) return 1;
+    variant = 98;   // loader waves without the ping-pong groups (the prologue path is not built for them)
     if (p.gn_c1 <= 0 || p.gn_c1 > p.Cin || (p.gn_c1 % BK) || (p.gn_c1 < p.Cin && !p.A2)) return 1;
     if ((p.lda2 & 7) || (reinterpret_cast<uintptr_t>(p.A2) & 15) || (reinterpret_cast<uintptr_t>(p.gn_table) & 15))
       return 1;
@@ -1326,7 +1526,7 @@ int pfd_gemm160_try(const PfdGemmDesc* d, int variant, int splits, hipStream_t s
   const int tn = p.N / bn;
   auto tiles = [&](int bm) { return (long)((p.M + bm - 1) / bm) * tn; };
   // 3x3 / s1 / p1 convolution on a 16-, 32- or 64-wide image: the patch kernel (variant 0 or 99)
-  if (bn == 160 && (variant == 0 || variant == 99 || variant == 98) && p.ksize == 3 && p.stride == 1 && p.pad == 1 && !p.ups &&
+  if (bn == 160 && (variant == 0 || variant == 99 || variant == 98 || variant == 97) && p.ksize == 3 && p.stride == 1 && p.pad == 1 && !p.ups &&
       (p.Wd == 16 || p.Wd == 32 || p.Wd == 64) && p.Ho == p.H && p.Wo == p.Wd && p.H % (256 / p.Wd) == 0 &&
       p.M % 256 == 0 && p.act != PFD_ACT_GEGLU) {
     const int ncb = p.Cin / BK;
@@ -1343,11 +1543,12 @@ int pfd_gemm160_try(const PfdGemmDesc* d, int variant, int splits, hipStream_t s
     if (splits > 1 && (!d->ws || (size_t)splits * p.M * p.N * 4 > d->ws_bytes)) splits = 1;
     p.splits = splits;
     // default: the wave-specialised form (4 loader waves): +4 ... 13 % on every patch-eligible conv of the UNet, most
-    // on the long-K ones (32768 x 320 x 8640: 149 -> 131 us = 1435 TF; profiles/r02_patch_ws_ab.log); 99 forces the
-    // 8-wave form
-    return launch_patch(p, s, variant != 99) < 0 ? PFD_ELAUNCH : 0;
+    // on the long-K ones (32768 x 320 x 8640: 149 -> 131 us = 1435 TF; profiles/r02_patch_ws_ab.log), with ping-pong
+    // consumer groups (round 3); 99 forces the 8-wave form, 98 loader waves + lock-step consumers, 97 ping-pong
+    const int ws = variant == 99 ? 0 : variant == 98 ? 1 : variant == 97 ? 2 : (pp_on() ? 2 : 1);
+    return launch_patch(p, s, ws) < 0 ? PFD_ELAUNCH : 0;
   }
-  if (variant == 99 || variant == 98 || p.gn_table) return 1;
+  if (variant == 99 || variant == 98 || variant == 97 || p.gn_table) return 1;
   const bool auto_variant = variant == 0;
   const int nk_all = p.K / BK;
   if (auto_variant) {
@@ -1373,14 +1574,15 @@ int pfd_gemm160_try(const PfdGemmDesc* d, int variant, int splits, hipStream_t s
     // implicit-GEMM convolutions (stride 2, fused upsample, widths the patch kernel does not take) run long K loops
     // of 53 KB stages: with the DMA pieces on four dedicated loader waves they gain 5-17 % (32768 x 640 x 5760
     // upsample conv: 225 -> 192 us = 1260 TF); the short-K linears do not (profiles/r02_wave_specialised_ab.log)
-    if (variant == 44 && p.ksize > 0) variant = 48;
+    if (variant == 44 && p.ksize > 0) variant = pp_on() ? 49 : 48;
   }
-  const int bm = (variant == 44 || variant == 48) ? 256 : (variant == 24 || variant == 25) ? 128 : 64;
+  const int bm = (variant == 44 || variant == 45 || variant == 48 || variant == 49 || variant == 84) ? 256
+                 : (variant == 24 || variant == 25 || variant == 26) ? 128 : 64;
   if (splits == 0) {
     splits = 1;
     const long tl = tiles(bm);
     const int nk = nk_all;
-    if (p.act != PFD_ACT_GEGLU && d->ws && (variant == 44 || variant == 48) && tl < 200 && nk >= 48 &&
+    if (p.act != PFD_ACT_GEGLU && d->ws && (variant == 44 || variant == 48 || variant == 49) && tl < 200 && nk >= 48 &&
         (size_t)2 * p.M * p.N * 4 <= d->ws_bytes) {
       splits = 2;  // 128 tiles of 256x160: two K halves fill the chip (758 vs 579 TF at 640->640 @32^2)
     } else if (p.act != PFD_ACT_GEGLU && d->ws && (variant == 24 || variant == 25) && tl < 256) {
@@ -1407,9 +1609,9 @@ int pfd_gemm160_try(const PfdGemmDesc* d, int variant, int splits, hipStream_t s
     if (variant == 24 && tiles(128) < 256 && nk_split >= 6) variant = 25;
   }
   const int conv = p.ksize > 0 ? 1 : 0;
-  if (variant == 48) {   // 8 MFMA waves + 4 loader waves
-    if (bn == 128) return launch160ws<4>(p, 12 + 4 * conv, s) < 0 ? PFD_ELAUNCH : 0;
-    return launch160ws<5>(p, 12 + 4 * conv, s) < 0 ? PFD_ELAUNCH : 0;
+  if (variant == 48 || variant == 49) {   // 8 MFMA waves + 4 loader waves (49: ping-pong consumer groups)
+    if (bn == 128) return launch160ws<4>(p, 12 + 4 * conv, s, variant == 49) < 0 ? PFD_ELAUNCH : 0;
+    return launch160ws<5>(p, 12 + 4 * conv, s, variant == 49) < 0 ? PFD_ELAUNCH : 0;
   }
   if (bn == 128) {
     switch (variant) {
@@ -1419,6 +1621,10 @@ int pfd_gemm160_try(const PfdGemmDesc* d, int variant, int splits, hipStream_t s
       default: return variant == 99 ? 1 : PFD_EINVAL;
     }
   }
+  if (variant == 84) {   // 256 x 320 tile (wave tile 64 x 160): GEGLU projections whose tiles fill the chip
+    if (p.act != PFD_ACT_GEGLU || conv || p.N % 320 || p.splits != 1) return PFD_EINVAL;
+    return launch160<4, 4, 2, 10>(p, 12, s) < 0 ? PFD_ELAUNCH : 0;
+  }
   switch (variant) {
     case 44: return launch160<4, 4>(p, 12 + 4 * conv, s) < 0 ? PFD_ELAUNCH : 0;
     case 24: return launch160<2, 4>(p, 13 + 4 * conv, s) < 0 ? PFD_ELAUNCH : 0;
@@ -1426,6 +1632,9 @@ int pfd_gemm160_try(const PfdGemmDesc* d, int variant, int splits, hipStream_t s
     // deep operand rings (counted vmcnt): K tiles in flight ahead of the MFMAs = 3 (64-row tile) / 2 (128-row tile)
     case 23: return launch160<2, 2, 4>(p, 14 + 4 * conv, s) < 0 ? PFD_ELAUNCH : 0;
     case 25: return launch160<2, 4, 3>(p, 13 + 4 * conv, s) < 0 ? PFD_ELAUNCH : 0;
+    // round 3: deeper rings for the HBM-bound long-K linears (more activation bytes in flight per CU)
+    case 26: return launch160<2, 4, 4>(p, 13 + 4 * conv, s) < 0 ? PFD_ELAUNCH : 0;
+    case 45: return launch160<4, 4, 3>(p, 12 + 4 * conv, s) < 0 ? PFD_ELAUNCH : 0;
     default: return PFD_EINVAL;
   }
 }

@@ -932,6 +932,30 @@ int main(int argc, char** argv) {
     run_gemm_case({0, 160, 0, PFD_ACT_SILU, true, false, true, false, 5800, 0, 3, 2, 1, 0, 2, 10, 8, 128});
     run_gemm_case({0, 320, 0, 0, true, true, false, false, 10800, 0, 3, 1, 1, 0, 1, 32, 32, 128});
     run_gemm_case({0, 160, 0, 0, true, false, true, false, 10802, 0, 3, 1, 1, 0, 1, 64, 64, 128});
+    // round 3: rotated K walk (several M tiles, K tiles >= M tiles and < M tiles, split-K, conv wrap-around) and the
+    // ping-pong consumer groups (5900 = 256-row tile, 10700 = patch kernel); 5800 / 10800 are the lock-step forms
+    for (int v : {5800, 5900}) {
+      run_gemm_case({1100, 320, 1024, 0, true, true, true, false, v});
+      run_gemm_case({700, 640, 192, PFD_ACT_GELU, true, false, true, false, v});
+      run_gemm_case({600, 320, 2048, 0, true, true, false, false, v + 2});                       // split-K 2
+      run_gemm_case({0, 320, 0, 0, true, true, false, false, v, 0, 3, 1, 1, 0, 3, 16, 16, 128});   // conv, 3 M tiles
+      run_gemm_case({0, 160, 0, PFD_ACT_SILU, true, false, true, false, v, 0, 3, 2, 1, 0, 5, 20, 16, 64});  // stride 2
+      run_gemm_case({0, 160, 0, 0, true, false, false, false, v, 0, 3, 1, 1, 1, 2, 9, 12, 64});   // upsample
+      run_gemm_case({600, 256, 512, 0, true, true, false, false, v});                            // 128-wide tiles
+    }
+    for (int v : {10800, 10700}) {
+      run_gemm_case({0, 320, 0, 0, true, true, true, false, v, 0, 3, 1, 1, 0, 2, 32, 32, 128});
+      run_gemm_case({0, 160, 0, PFD_ACT_SILU, true, false, true, false, v, 0, 3, 1, 1, 0, 1, 64, 64, 256});
+      run_gemm_case({0, 320, 0, 0, true, true, false, false, v, 0, 3, 1, 1, 0, 3, 16, 16, 320});
+      run_gemm_case({0, 160, 0, 0, true, false, false, false, v + 2, 0, 3, 1, 1, 0, 2, 16, 16, 512});  // split over cb
+    }
+    run_gemm_case({600, 640, 320, PFD_ACT_GEGLU, true, false, false, false, 9400});   // 256 x 320 GEGLU tile
+    run_gemm_case({300, 320, 64, PFD_ACT_GEGLU, false, false, false, false, 9400});
+    for (int v : {3200, 3300, 3400, 3500, 5400, 3600, 5500}) {   // the 8-wave kernels, rotated walk over several M tiles
+      run_gemm_case({1100, 320, 1024, 0, true, true, true, false, v});
+      run_gemm_case({0, 160, 0, 0, true, true, false, false, v, 0, 3, 1, 1, 0, 3, 16, 16, 128});
+      run_gemm_case({900, 320, 1536, 0, true, false, false, false, v + 3});
+    }
     // GroupNorm(+SiLU) prologue of the patch kernel == pfd_groupnorm_f16 followed by the plain convolution, bit for bit
     run_gn_conv_case(2, 16, 16, 64, 0, 160, PFD_ACT_SILU, false);
     run_gn_conv_case(1, 32, 32, 128, 64, 320, PFD_ACT_SILU, true);
