@@ -34,7 +34,7 @@ extern "C" {
 #define PFD_ESHAPE (-2)   /* shape outside what the kernels are built for           */
 #define PFD_ELAUNCH (-3)  /* hipGetLastError() != hipSuccess after the launch       */
 
-#define PFD_ABI_VERSION 6
+#define PFD_ABI_VERSION 7
 
 typedef void* pfd_stream_t; /* hipStream_t */
 
@@ -125,6 +125,25 @@ typedef struct PfdGemmDesc {
   int64_t lda2;
   int32_t gn_c1;
   int32_t gn_act;
+  /* LayerNorm folded into the contraction (ABI 7; BasicTransformerBlock, attention.py:294-306: every LayerNorm feeds
+   * a Linear with nothing in between -- norm1 -> to_q|to_k|to_v, norm2 -> to_q, norm3 -> GEGLU.proj).  With
+   * ln_stats != NULL the launch computes, for A = the UN-normalised tokens x and W = the gamma-scaled weight W o gamma,
+   *     LN(x) W^T + b  =  rstd_m * (x (W o gamma)^T)[m, n]  -  rstd_m * mean_m * s_n  +  b'_n
+   * with s_n = sum_k (W o gamma)[n, k] (ln_colsum, f32 [N], of the f16-rounded products) and
+   * b'_n = sum_k beta_k W[n, k] + b_n passed as `bias`; the affine map is applied to the fp32 accumulator in front
+   * of the rest of the epilogue (bias, activation / GEGLU, transposed tail, split-K reduce alike).
+   * ln_stats is the f32 [M][ln_parts][2] array of PARTIAL row sums (sum x, sum x^2) over the 160-column slices of A
+   * (ln_parts = K / 160 <= 8; mean and rstd are formed from their totals with ln_eps): it is what the PRODUCER of x
+   * writes when its own descriptor has ln_out != NULL (f32 [M][N / 160][2], N % 160 == 0, act != GEGLU, no Ct) --
+   * the out-projection / proj_in launch that stores x emits the statistics of the rows it holds, so no LayerNorm
+   * launch and no extra pass over x exist.  pfd_ln_rowstats_f16 writes the same array for tensors that no such
+   * launch produced.  Wide-tile linear path only (N % 160 == 0 or N % 128 == 0, ksize == 0); anything else is
+   * PFD_ESHAPE (callers run pfd_layernorm_f16 and a plain GEMM instead). */
+  const void* ln_stats;
+  const void* ln_colsum;
+  int32_t ln_parts;
+  float ln_eps;
+  void* ln_out;
 } PfdGemmDesc;
 int pfd_gemm_f16(const PfdGemmDesc* d, pfd_stream_t stream);
 /* Same, with the kernel variant forced (tests and tuning only); 0 = the library's heuristic.
@@ -221,6 +240,10 @@ int pfd_groupnorm_f16(const void* x1, int32_t C1, int64_t ldx1, const void* x2, 
 int pfd_layernorm_f16(const void* x, int64_t ldx, const void* gamma, const void* beta, void* y,
                       int64_t ldy, int32_t M, int32_t C, float eps, int32_t gather4, int32_t B,
                       int32_t H, int32_t W, pfd_stream_t stream);
+
+/* Partial row statistics of a [M, C] f16 token matrix in the layout PfdGemmDesc.ln_stats takes:
+ * out[m][p] = (sum, sum of squares) of x[m, 160 p .. 160 p + 159], f32 [M][C / 160][2].  C % 160 == 0, C <= 1280. */
+int pfd_ln_rowstats_f16(const void* x, int64_t ldx, int32_t M, int32_t C, void* out, pfd_stream_t stream);
 
 /* Row softmax with pre-scale: y[r,:] = softmax(scale * x[r,:]) (fp32 math), [R, N] f16.
  * Used by the VAE mid-block single-head attention (autokl_modules.py:186-197). */

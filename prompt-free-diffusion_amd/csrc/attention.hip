@@ -25,6 +25,8 @@
 //   * the accumulator is rescaled only when some row of the wave actually raised its running max
 //     (exact: alpha == 1 otherwise).
 // Per tile per wave: 2*DQK/16 + 4*DV/32 MFMAs (DQK = D rounded to 16, DV = D rounded to 32).
+#include <stdlib.h>
+
 #include "pfd_common.h"
 
 namespace {
@@ -32,6 +34,8 @@ namespace {
 #ifndef ATT_ABL
 #define ATT_ABL 0   // measurement-only ablation bits: 1 no exp, 2 no PV MFMAs, 4 no K/V loads + staging, 8 no QK MFMAs
 #endif
+
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 struct AttnParams {
   const half_t* Q;
@@ -298,14 +302,428 @@ __global__ __launch_bounds__(256, (D <= 40 ? 4 : 1)) void attention_kernel(const
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Round-3 form of the kernel above (same math, same LDS K image, same transposed formulation):
+//  * the ragged last KV tile is PEELED: the loop over full tiles has no key masking, no clamped row indices and no
+//    64-bit address arithmetic (per-thread source pointers advance by a constant per tile).  The ISA of the old loop
+//    spent ~60 of its ~200 VALU instructions per tile on that, and the softmax path is VALU bound at d = 40.
+//  * NWAVES = 8: 256 queries per block share one staged K / V^T tile (the global loads, ds_writes and the barrier of
+//    a tile are paid once per 256 queries instead of per 128; the "no loads / staging" ablation of the old kernel
+//    was -29 %).  Same 4 waves per SIMD (two 512-thread blocks per CU).
+//  * PV16 (d = 40): O^T = V^T . P^T on v_mfma_f32_16x16x32_f16, so the head dim pads 40 -> 48 instead of 64 (12
+//    MFMAs x 16 cycles per tile instead of 8 x 32).  The 32x32 S^T accumulator holds query l & 31 in lane l; a
+//    16x16x32 B operand wants the SAME 16 queries in all four 16-lane rows.  One v_permlane16_swap per packed
+//    register pair (16-key blocks bb = 0 / 1 of a 32-key half) does it: afterwards the first register holds queries
+//    0-15 in every row (row kg = 2 hi + bb), the second queries 16-31.  MFMA only needs A and B to agree on which key a
+//    (row, slot) pair means, so the V^T A operand is read in that order: keys 32 u + 16 bb + 4 hi + {0..3} and + 8.
+//    The V^T image is 64 halfs per row without padding; 8-byte slot s of row d is stored at s ^ sigma(d),
+//    sigma = d[1] | d[2] << 1 | d[3] << 3, which makes both ds_read_b64 of a fragment conflict free (rows of equal
+//    parity share a bank half; {sigma} and {sigma ^ 4} partition its 16 slots).
+// ------------------------------------------------------------------------------------------------
+template <int D, int NWAVES, bool PV16>
+__global__ __launch_bounds__(NWAVES * 64, (D <= 40 ? 4 : 1)) void attention2_kernel(const AttnParams p) {
+  static_assert(!PV16 || D == 40, "the 16x16x32 PV path is laid out for d = 40 (48 padded rows, row 40 = ones)");
+  constexpr int KV_TILE = 64, NU = 2;
+  constexpr int NTHR = NWAVES * 64;
+  constexpr int QB = NWAVES * 32;
+  constexpr int DQK = (D + 15) / 16 * 16;
+  constexpr int DV = PV16 ? 48 : (D + 31) / 32 * 32;
+  constexpr int VT_LD = PV16 ? KV_TILE : KV_TILE + 4;
+  constexpr int K_LD = DQK + 8;
+  constexpr int NS = DQK / 16;
+  constexpr int ND = DV / 32;        // 32-row O^T tiles (PV on 32x32x16)
+  constexpr int NDT = DV / 16;       // 16-row O^T tiles (PV on 16x16x32)
+  constexpr bool SUM_MFMA = DV > D;
+  constexpr int KCH = D / 8;
+  constexpr int K_CHUNKS = KV_TILE * KCH;
+  constexpr int V_CHUNKS = D * (KV_TILE / 8);
+  constexpr int K_PT = (K_CHUNKS + NTHR - 1) / NTHR;
+  constexpr int V_PT = (V_CHUNKS + NTHR - 1) / NTHR;
+  constexpr int K_TILE_HALFS = KV_TILE * K_LD;
+  constexpr int V_TILE_HALFS = DV * VT_LD;
+  __shared__ __attribute__((aligned(16))) half_t lds[2 * K_TILE_HALFS + 2 * V_TILE_HALFS];
+  half_t* const Ks = lds;
+  half_t* const Vts = lds + 2 * K_TILE_HALFS;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l31 = lane & 31, hi = lane >> 5;
+  const int nqb = (p.Nq + QB - 1) / QB;
+  const int lin = xcd_remap(blockIdx.x, gridDim.x);
+  const int bh = lin / nqb;
+  const int qb = lin - bh * nqb;
+  const int b = bh / p.H, h = bh - b * p.H;
+  const int q_row = qb * QB + wave * 32 + l31;
+
+  for (int i = tid; i < 2 * K_TILE_HALFS + 2 * V_TILE_HALFS; i += NTHR) lds[i] = (half_t)0.f;
+  __syncthreads();
+  if (SUM_MFMA) {   // row D of V^T = 1: O^T[D, q] accumulates sum_kv P (every slot of the row, so the swizzle is moot)
+    for (int i = tid; i < 2 * KV_TILE; i += NTHR)
+      Vts[(i / KV_TILE) * V_TILE_HALFS + D * VT_LD + (i % KV_TILE)] = (half_t)1.f;
+  }
+
+  half8_t qf[NS];
+  {
+    const half_t* qp = p.Q + (long)b * p.q_bs + (long)min(q_row, p.Nq - 1) * p.ldq + h * D;
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+      const int d = s * 16 + hi * 8;
+      Pack16 t;
+      t.u = *reinterpret_cast<const uint4*>(qp + min(d, D - 8));   // unconditional; padding slots zeroed below
+      if (d >= D) t.u = make_uint4(0, 0, 0, 0);
+      qf[s] = t.h;
+    }
+  }
+
+  float16_t o32[PV16 ? 1 : ND];          // PV on 32x32x16: O^T tile i, col = q = l31
+  float4_t o16[PV16 ? NDT : 1][2];       // PV on 16x16x32: [d tile][q tile], col = q % 16 = lane & 15, rows 4 (lane >> 4) + r
+#pragma unroll
+  for (int i = 0; i < (PV16 ? 1 : ND); ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o32[i][r] = 0.f;
+#pragma unroll
+  for (int i = 0; i < (PV16 ? NDT : 1); ++i)
+#pragma unroll
+    for (int q = 0; q < 2; ++q) o16[i][q] = (float4_t){0.f, 0.f, 0.f, 0.f};
+  float m_run = -INFINITY, l_run = 0.f;
+
+  const half_t* kbase = p.K + (long)b * p.k_bs + h * D;
+  const half_t* vbase = p.Vt + (long)h * D * p.ldvt + (long)b * p.vt_bs;
+  const float c = p.scale_log2;
+
+  // ---- staging: chunk = 16 bytes; thread t moves K chunks t + NTHR j and V^T chunks (t + NTHR / 2) % NTHR + NTHR j ----
+  // (inactive slots load a clamped, valid chunk and do not store it: no branch around a load.  Row / chunk indices are
+  //  recomputed where the ragged tile needs them: kept live they cost the d = 40 build its 128-register budget.)
+  auto k_chunk = [&](int j, int& row, int& cc) __attribute__((always_inline)) {
+    const int chc = min(tid + NTHR * j, K_CHUNKS - 1);
+    row = chc / KCH;
+    cc = chc - row * KCH;
+  };
+  auto v_chunk = [&](int j, int& d, int& cc) __attribute__((always_inline)) {
+    const int chc = min(((tid + NTHR / 2) & (NTHR - 1)) + NTHR * j, V_CHUNKS - 1);
+    d = chc / (KV_TILE / 8);
+    cc = chc % (KV_TILE / 8);
+  };
+  int k_lds[K_PT], v_lds0[V_PT];
+  bool k_on[K_PT], v_on[V_PT];
+  const half_t* kptr[K_PT];
+  const half_t* vptr[V_PT];
+#pragma unroll
+  for (int j = 0; j < K_PT; ++j) {
+    int row, cc;
+    k_chunk(j, row, cc);
+    k_on[j] = tid + NTHR * j < K_CHUNKS;
+    k_lds[j] = row * K_LD + cc * 8;
+    kptr[j] = kbase + (long)row * p.ldk + cc * 8;
+  }
+#pragma unroll
+  for (int j = 0; j < V_PT; ++j) {
+    int d, cc;
+    v_chunk(j, d, cc);
+    v_on[j] = ((tid + NTHR / 2) & (NTHR - 1)) + NTHR * j < V_CHUNKS;
+    if (PV16) {
+      const int dl_ = d & 15;
+      const int sg_ = ((dl_ >> 1) & 3) | (((dl_ >> 3) & 1) << 3);
+      v_lds0[j] = d * VT_LD + 4 * ((2 * cc) ^ sg_);   // second 8-byte half: slot (2 cc + 1) ^ sigma = this address ^ 4 halfs
+    } else {
+      v_lds0[j] = d * VT_LD + cc * 8;                 // second half: + 4 halfs
+    }
+    vptr[j] = vbase + (long)d * p.ldvt + cc * 8;
+  }
+  const int v_last = max(0, ((p.Nk + 7) & ~7) - 8);
+  // (first-class vector values, not the uint4 struct: a struct copy global -> private -> LDS is folded by the compiler's
+  //  memcpy forwarding into ONE copy at the store point, i.e. the prefetch load lands right in front of its ds_write)
+  u32x4 kregA[K_PT], vregA[V_PT];
+
+  auto load_full = [&](u32x4* kreg, u32x4* vreg) __attribute__((always_inline)) {   // the tile the pointers stand on
+#pragma unroll
+    for (int j = 0; j < K_PT; ++j) {
+      kreg[j] = *reinterpret_cast<const u32x4*>(kptr[j]);
+      kptr[j] += (long)KV_TILE * p.ldk;
+    }
+#pragma unroll
+    for (int j = 0; j < V_PT; ++j) {
+      vreg[j] = *reinterpret_cast<const u32x4*>(vptr[j]);
+      vptr[j] += KV_TILE;
+    }
+  };
+  auto load_ragged = [&](u32x4* kreg, u32x4* vreg, int kv0) __attribute__((always_inline)) {   // clamped to valid rows / chunks
+#pragma unroll
+    for (int j = 0; j < K_PT; ++j) {
+      int row, cc;
+      k_chunk(j, row, cc);
+      kreg[j] = *reinterpret_cast<const u32x4*>(kbase + (long)min(kv0 + row, p.Nk - 1) * p.ldk + cc * 8);
+    }
+#pragma unroll
+    for (int j = 0; j < V_PT; ++j) {
+      int d, cc;
+      v_chunk(j, d, cc);
+      vreg[j] = *reinterpret_cast<const u32x4*>(vbase + (long)d * p.ldvt + min(kv0 + cc * 8, v_last));
+    }
+  };
+  // RAG is a constant at every call site (the lambdas are not generic on purpose: a generic lambda is inlined too late
+  // for the staging arrays to be promoted to registers)
+  auto store_tile = [&](const u32x4* kreg, const u32x4* vreg, int stage, const bool RAG, int kv0) __attribute__((always_inline)) {
+    half_t* Kd = Ks + stage * K_TILE_HALFS;
+    half_t* Vd = Vts + stage * V_TILE_HALFS;
+#pragma unroll
+    for (int j = 0; j < K_PT; ++j)
+      if (k_on[j]) *reinterpret_cast<u32x4*>(Kd + k_lds[j]) = kreg[j];
+#pragma unroll
+    for (int j = 0; j < V_PT; ++j) {
+      unsigned w0 = vreg[j][0], w1 = vreg[j][1], w2 = vreg[j][2], w3 = vreg[j][3];
+      if (RAG) {   // keys past Nk: P is 0 there, but 0 x NaN garbage must not reach the accumulator
+        int d, cc;
+        v_chunk(j, d, cc);
+        const int valid = p.Nk - (kv0 + cc * 8);
+        w0 = valid >= 2 ? w0 : (valid == 1 ? (w0 & 0xFFFFu) : 0u);
+        w1 = valid >= 4 ? w1 : (valid == 3 ? (w1 & 0xFFFFu) : 0u);
+        w2 = valid >= 6 ? w2 : (valid == 5 ? (w2 & 0xFFFFu) : 0u);
+        w3 = valid >= 8 ? w3 : (valid == 7 ? (w3 & 0xFFFFu) : 0u);
+      }
+      if (v_on[j]) {
+        *reinterpret_cast<uint2*>(Vd + v_lds0[j]) = make_uint2(w0, w1);
+        *reinterpret_cast<uint2*>(Vd + (PV16 ? v_lds0[j] ^ 4 : v_lds0[j] + 4)) = make_uint2(w2, w3);
+      }
+    }
+  };
+
+  // V^T fragment addressing of the 16x16x32 path (halfs, relative to the tile): row dl, slots (4 bb + hi) and + 2
+  const int dl = lane & 15, kg = lane >> 4;
+  const int sg = ((dl >> 1) & 3) | (((dl >> 3) & 1) << 3);
+  const int x0 = (4 * (kg & 1) + (kg >> 1)) ^ (sg & 7), x1 = (4 * (kg & 1) + (kg >> 1) + 2) ^ (sg & 7);
+  const int u_flip = sg >> 3;
+  const int vrow16 = dl * VT_LD;
+
+  auto compute_tile = [&](int stage, const bool RAG, int kv0) __attribute__((always_inline)) {
+    const half_t* Kt = Ks + stage * K_TILE_HALFS;
+    const half_t* Vt = Vts + stage * V_TILE_HALFS;
+    float16_t st[NU];
+#pragma unroll
+    for (int u = 0; u < NU; ++u) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) st[u][r] = 0.f;
+      const half_t* kp = Kt + (u * 32 + l31) * K_LD + hi * 8;
+#pragma unroll
+      for (int s = 0; s < NS; ++s) {
+        const half8_t kf = *reinterpret_cast<const half8_t*>(kp + s * 16);
+        st[u] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[s], st[u], 0, 0, 0);
+      }
+    }
+    if (RAG) {
+#pragma unroll
+      for (int u = 0; u < NU; ++u)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          if (kv0 + u * 32 + mfma32_row(r, hi) >= p.Nk) st[u][r] = -INFINITY;
+    }
+    float mx = st[0][0];
+#pragma unroll
+    for (int u = 0; u < NU; ++u)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) mx = fmaxf(mx, st[u][r]);
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    const float m_new = fmaxf(m_run, mx);
+    if (__any(m_new > m_run)) {
+      const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c);   // 1 for rows whose max did not move; 0 at the start
+      l_run *= alpha;
+      if constexpr (PV16) {
+        const float a0 = __shfl(alpha, dl, 64), a1 = __shfl(alpha, dl + 16, 64);   // accumulator columns: q = dl + 16 qt
+#pragma unroll
+        for (int i = 0; i < NDT; ++i)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            o16[i][0][r] *= a0;
+            o16[i][1][r] *= a1;
+          }
+      } else {
+#pragma unroll
+        for (int i = 0; i < ND; ++i)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) o32[i][r] *= alpha;
+      }
+      m_run = m_new;
+    }
+    const float mc = m_run * c;
+    float rs = 0.f;
+    half8_t pf[NU][2];
+#pragma unroll
+    for (int u = 0; u < NU; ++u)
+#pragma unroll
+      for (int bb = 0; bb < 2; ++bb)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const float e = __builtin_amdgcn_exp2f(fmaf(st[u][bb * 8 + j], c, -mc));
+          if (!SUM_MFMA) rs += e;
+          pf[u][bb][j] = (half_t)e;
+        }
+    if (!SUM_MFMA) {
+      rs += __shfl_xor(rs, 32, 64);
+      l_run += rs;
+    }
+    if constexpr (PV16) {
+      union H8 {
+        half8_t h;
+        unsigned w[4];
+      };
+      half8_t pb[NU][2];   // [32-key half][q tile]
+#pragma unroll
+      for (int u = 0; u < NU; ++u) {
+        H8 a, bq, r0, r1;
+        a.h = pf[u][0];
+        bq.h = pf[u][1];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const auto sw = __builtin_amdgcn_permlane16_swap(a.w[k], bq.w[k], false, false);
+          r0.w[k] = sw[0];   // rows: (q 0-15, hi 0, bb 0) (q 0-15, hi 0, bb 1) (q 0-15, hi 1, bb 0) (q 0-15, hi 1, bb 1)
+          r1.w[k] = sw[1];   // the same for q 16-31
+        }
+        pb[u][0] = r0.h;
+        pb[u][1] = r1.h;
+      }
+#pragma unroll
+      for (int i = 0; i < NDT; ++i)
+#pragma unroll
+        for (int u = 0; u < NU; ++u) {
+          const half_t* vp = Vt + i * 16 * VT_LD + vrow16 + 32 * (u ^ u_flip);
+          const half4_t lo4 = *reinterpret_cast<const half4_t*>(vp + 4 * x0);
+          const half4_t hi4 = *reinterpret_cast<const half4_t*>(vp + 4 * x1);
+          half8_t vf;
+          vf[0] = lo4[0]; vf[1] = lo4[1]; vf[2] = lo4[2]; vf[3] = lo4[3];
+          vf[4] = hi4[0]; vf[5] = hi4[1]; vf[6] = hi4[2]; vf[7] = hi4[3];
+          o16[i][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf, pb[u][0], o16[i][0], 0, 0, 0);
+          o16[i][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf, pb[u][1], o16[i][1], 0, 0, 0);
+        }
+    } else {
+#pragma unroll
+      for (int i = 0; i < ND; ++i) {
+        const half_t* vp = Vt + (i * 32 + l31) * VT_LD + 4 * hi;
+#pragma unroll
+        for (int u = 0; u < NU; ++u)
+#pragma unroll
+          for (int bb = 0; bb < 2; ++bb) {
+            const half4_t lo4 = *reinterpret_cast<const half4_t*>(vp + u * 32 + bb * 16);
+            const half4_t hi4 = *reinterpret_cast<const half4_t*>(vp + u * 32 + bb * 16 + 8);
+            half8_t vf;
+            vf[0] = lo4[0]; vf[1] = lo4[1]; vf[2] = lo4[2]; vf[3] = lo4[3];
+            vf[4] = hi4[0]; vf[5] = hi4[1]; vf[6] = hi4[2]; vf[7] = hi4[3];
+            o32[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf[u][bb], o32[i], 0, 0, 0);
+          }
+      }
+    }
+  };
+
+  const int nfull = p.Nk / KV_TILE;
+  const bool rag = (p.Nk % KV_TILE) != 0;
+  // first tile
+  if (nfull > 0) {
+    load_full(kregA, vregA);
+    store_tile(kregA, vregA, 0, false, 0);
+  } else {
+    load_ragged(kregA, vregA, 0);
+    store_tile(kregA, vregA, 0, true, 0);
+  }
+  __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0) on every path into the loop (Q fragments included)
+  __syncthreads();
+  int t = 0;
+  for (; t + 1 < nfull; ++t) {          // full tile followed by a full tile: the hot loop
+    load_full(kregA, vregA);
+    compute_tile(t & 1, false, 0);
+    store_tile(kregA, vregA, (t & 1) ^ 1, false, 0);
+    __syncthreads();
+  }
+  if (nfull > 0) {                      // last full tile; its successor is the ragged tile or nothing
+    if (rag) load_ragged(kregA, vregA, (t + 1) * KV_TILE);
+    compute_tile(t & 1, false, 0);
+    if (rag) store_tile(kregA, vregA, (t & 1) ^ 1, true, (t + 1) * KV_TILE);
+    __syncthreads();
+    ++t;
+  }
+  if (rag) compute_tile(t & 1, true, t * KV_TILE);
+
+  // ---- epilogue: O[q, d] = O^T[d, q] / l ----
+  if constexpr (PV16) {
+    // row 40 of O^T (d tile 2, local row 8 = lane row 2, register 0) = sum_kv P of query (lane & 15) + 16 qt
+    const float l0 = __shfl(o16[2][0][0], 32 + dl, 64), l1 = __shfl(o16[2][1][0], 32 + dl, 64);
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt) {
+      const int q = qb * QB + wave * 32 + qt * 16 + dl;
+      const float inv = 1.0f / (qt ? l1 : l0);
+      if (q < p.Nq) {
+        half_t* op = p.O + (long)b * p.o_bs + (long)q * p.ldo + h * D;
+#pragma unroll
+        for (int i = 0; i < NDT; ++i) {
+          const int d0 = i * 16 + 4 * kg;
+          if (d0 < D) {
+            half4_t o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = (half_t)(o16[i][qt][e] * inv);
+            *reinterpret_cast<half4_t*>(op + d0) = o;
+          }
+        }
+      }
+    }
+  } else {
+    if (SUM_MFMA) {
+      constexpr int lr = D % 32;
+      constexpr int src_hi = (lr >> 2) & 1;
+      constexpr int reg = (lr & 3) + 4 * (lr >> 3);
+      const float v = o32[D / 32][reg];
+      l_run = __shfl(v, src_hi * 32 + l31, 64);
+    }
+    if (q_row < p.Nq) {
+      const float inv = 1.0f / l_run;
+      half_t* op = p.O + (long)b * p.o_bs + (long)q_row * p.ldo + h * D;
+#pragma unroll
+      for (int i = 0; i < ND; ++i)
+#pragma unroll
+        for (int rq = 0; rq < 4; ++rq) {
+          const int d0 = i * 32 + 8 * rq + 4 * hi;
+          if (d0 < D) {
+            half4_t o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = (half_t)(o32[i][rq * 4 + e] * inv);
+            *reinterpret_cast<half4_t*>(op + d0) = o;
+          }
+        }
+    }
+  }
+}
+
+// PFD_ATTN: 0 = round-2 kernel; 1 = peeled loop, 4 waves, PV on 32x32x16; 2 = + 8 waves per block (d = 40, big grids);
+// 3 = 4 waves + PV on 16x16x32 (d = 40); 4 (default) = 8 waves + PV on 16x16x32 where 8-wave blocks apply, mode 1 elsewhere.
+// PFD_ATTN_FORCE8=1 takes the 8-wave form for every d = 40 problem (tests).
+static int attn_mode() {
+  static const int m = getenv("PFD_ATTN") ? atoi(getenv("PFD_ATTN")) : 4;
+  return m;
+}
+static bool attn_force8() {
+  static const bool f = getenv("PFD_ATTN_FORCE8") && atoi(getenv("PFD_ATTN_FORCE8")) != 0;
+  return f;
+}
+
 template <int D>
 int launch(const AttnParams& p, hipStream_t s) {
-  dim3 grid(((p.Nq + 127) / 128) * p.H * p.B);
   const bool prof = pfd_prof_on();
   if (prof)
     pfd_prof_begin(8, 4.0 * p.B * p.H * (double)p.Nq * p.Nk * D,
                    2.0 * p.B * p.H * D * (2.0 * p.Nq + 2.0 * p.Nk), s);
-  hipLaunchKernelGGL((attention_kernel<D, 64>), grid, dim3(256), 0, s, p);
+  const int mode = attn_mode();
+  // 8-wave blocks pay when a block has many queries to amortise the staging over and the grid still fills the chip twice
+  const bool big = p.Nq >= 1024 && (long)p.B * p.H * ((p.Nq + 255) / 256) >= 512;
+  const bool w8 = (mode == 2 || mode == 4) && D == 40 && (big || attn_force8());
+  const int qb = w8 ? 256 : 128;
+  dim3 grid(((p.Nq + qb - 1) / qb) * p.H * p.B);
+  if (mode == 0) {
+    hipLaunchKernelGGL((attention_kernel<D, 64>), grid, dim3(256), 0, s, p);
+  } else if constexpr (D == 40) {
+    const bool pv16 = mode == 3 || (mode == 4 && w8);   // (the 4-wave PV16 build spills 24 bytes at 128 VGPRs)
+    if (w8 && pv16) hipLaunchKernelGGL((attention2_kernel<D, 8, true>), grid, dim3(512), 0, s, p);
+    else if (w8) hipLaunchKernelGGL((attention2_kernel<D, 8, false>), grid, dim3(512), 0, s, p);
+    else if (pv16) hipLaunchKernelGGL((attention2_kernel<D, 4, true>), grid, dim3(256), 0, s, p);
+    else hipLaunchKernelGGL((attention2_kernel<D, 4, false>), grid, dim3(256), 0, s, p);
+  } else {
+    hipLaunchKernelGGL((attention2_kernel<D, 4, false>), grid, dim3(256), 0, s, p);
+  }
   if (prof) pfd_prof_end(s);
   return pfd_check_launch("pfd_attention_f16");
 }

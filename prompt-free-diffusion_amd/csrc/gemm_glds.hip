@@ -32,6 +32,8 @@
 
 #include "pfd_common.h"
 
+int pfd_ln_rowstats_launch(const half_t* x, long ldx, int M, int C, float* out, hipStream_t s);   // norm.hip
+
 namespace {
 
 constexpr int BK = 64;
@@ -60,6 +62,12 @@ struct G160Params {
   int nmajor;  // XCD-contiguous tile order: 0 = all N tiles of an M tile together, 1 = all M tiles of an N tile
   int krot;    // 1 = every M tile starts its K loop at a different K tile (see k_rotation below)
   // GroupNorm(+SiLU) folded into the patch convolution's input staging (PfdGemmDesc.gn_table)
+  // LayerNorm folded into the contraction (PfdGemmDesc.ln_stats / ln_out)
+  const float2* ln_in;     // [M][ln_P]: partial (sum x, sum x^2) of the rows of A; nullptr = no fold
+  const float* ln_cs;      // [N]: column sums of the gamma-scaled weight
+  float2* ln_out;          // [M][tiles_n]: partial row sums of the OUTPUT of this launch; nullptr = none
+  int ln_P;
+  float ln_eps;
   const float* gn_table;   // [B][2][Cin]: scale plane, shift plane
   const half_t* A2;        // channels >= gn_c1 of the virtual concat
   long lda2;
@@ -115,14 +123,31 @@ __device__ __forceinline__ void lds_store16_opaque(void* lds_dst, uint4 v) {
 constexpr int stage_row_bytes(int cols) { return cols * 2 + 16; }
 
 // pass 1 (the waves that hold accumulators): returns true when the tile was staged in LDS and needs pass 2
+// lnstat: per-row {rstd, -rstd * mean} of this block's rows in LDS (LayerNorm folded into the GEMM), or nullptr
 template <int WMB, int NT>
-__device__ __forceinline__ bool epilogue_stage(const float4_t (&acc)[WMB][NT], const G160Params& p, int lane, int m0,
-                                               int n0, int wm, int wn, int split, char* smem) {
+__device__ __forceinline__ bool epilogue_stage(float4_t (&acc)[WMB][NT], const G160Params& p, int lane, int m0,
+                                               int n0, int wm, int wn, int split, char* smem,
+                                               const float2* lnstat = nullptr) {
   constexpr int BN = 32 * NT;
   const int l15 = lane & 15, g = lane >> 4;
   const int mw = m0 + wm * WMB * 16 + l15;   // + i*16: this lane's output row in row-tile i
   const int nw = n0 + wn * (16 * NT) + 4 * g;       // + j*16: first of this lane's 4 columns in column-tile j
   constexpr bool GEGLU_ONLY = NT == 10;      // the 320-wide tile is dispatched for GEGLU projections only
+  if (lnstat && p.splits == 1) {
+    // LN(x) W^T = rstd_m (x (W o gamma)^T)[m, n] - rstd_m mean_m s_n (+ b'_n, the `bias` of this launch): the affine map
+    // goes onto the accumulators, everything behind it (bias, activation / GEGLU, transposed tail) is unchanged
+    float4_t cs[NT];
+#pragma unroll
+    for (int j = 0; j < NT; ++j) cs[j] = *reinterpret_cast<const float4_t*>(p.ln_cs + nw + j * 16);
+#pragma unroll
+    for (int i = 0; i < WMB; ++i) {
+      const float2 ab = lnstat[wm * WMB * 16 + i * 16 + l15];
+#pragma unroll
+      for (int j = 0; j < NT; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[i][j][r] = fmaf(acc[i][j][r], ab.x, ab.y * cs[j][r]);
+    }
+  }
 
   if (!GEGLU_ONLY && p.splits > 1) {  // split-K: raw fp32 partials, [split][M][N]
 #pragma unroll
@@ -269,12 +294,60 @@ __device__ __forceinline__ bool epilogue_stage(const float4_t (&acc)[WMB][NT], c
 }
 
 // pass 2 (every thread of the block, after a barrier): + residual, 16-byte chunks of contiguous row segments
-template <int BM, int NT, int NTHREADS>
+// LNOUT: compile the statistics-emitting store pass (linear kernels only: convolutions never feed a LayerNorm, and the
+// loader-wave kernels have no registers to spare for it)
+template <int BM, int NT, int NTHREADS, bool LNOUT = false>
 __device__ __forceinline__ void epilogue_store(const G160Params& p, int m0, int n0, const char* smem, int tid) {
   constexpr int BN = 32 * NT;
   constexpr bool GEGLU_ONLY = NT == 10;
   if (!GEGLU_ONLY && (p.splits > 1 || (p.Ct && n0 >= p.n_split))) return;   // written directly by pass 1 (tile-uniform)
   const bool geglu = GEGLU_ONLY || p.act == PFD_ACT_GEGLU;
+  if constexpr (LNOUT && !GEGLU_ONLY && (BN / 8) % 4 == 0) {
+    if (p.ln_out) {
+      // This launch's output feeds a LayerNorm that is folded into ITS consumer GEMM: emit the partial row sums
+      // (sum, sum of squares of the f16 values stored, i.e. exactly what a LayerNorm kernel would read) of the BN
+      // columns this tile holds.  Four lanes per row, lane k takes chunks k, k + 4, ...: every store instruction still
+      // writes 64 contiguous bytes per row; two shuffles finish a row.
+      constexpr int RS = stage_row_bytes(BN);
+      constexpr int CPL = BN / 8 / 4;             // chunks per lane: 5 (4)
+      constexpr int ROWS_IT = NTHREADS / 4;
+      const int k = tid & 3;
+      const bool has_r = p.R != nullptr;
+      const int tile_n = n0 / BN, tiles_n = p.N / BN;
+      for (int row0 = 0; row0 < BM; row0 += ROWS_IT) {
+        const int row = row0 + (tid >> 2);
+        const int rowc = min(row, BM - 1);
+        const int m = m0 + row;
+        const bool ok = row < BM && m < p.M;
+        Pack16 r[CPL];
+        if (has_r) {
+#pragma unroll
+          for (int j = 0; j < CPL; ++j)
+            r[j].u = *reinterpret_cast<const uint4*>(p.R + (long)min(m0 + rowc, p.M - 1) * p.ldr + n0 + (k + 4 * j) * 8);
+        }
+        float sum = 0.f, sq = 0.f;
+#pragma unroll
+        for (int j = 0; j < CPL; ++j) {
+          Pack16 v;
+          v.u = *reinterpret_cast<const uint4*>(smem + rowc * RS + (k + 4 * j) * 16);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            if (has_r) v.e[e] = (half_t)((float)v.e[e] + (float)r[j].e[e]);
+            const float f = (float)v.e[e];
+            sum += f;
+            sq = fmaf(f, f, sq);
+          }
+          if (ok) *reinterpret_cast<uint4*>(p.C + (long)m * p.ldc + n0 + (k + 4 * j) * 8) = v.u;
+        }
+        sum += __shfl_xor(sum, 1, 64);
+        sq += __shfl_xor(sq, 1, 64);
+        sum += __shfl_xor(sum, 2, 64);
+        sq += __shfl_xor(sq, 2, 64);
+        if (ok && k == 0) p.ln_out[(long)m * tiles_n + tile_n] = make_float2(sum, sq);
+      }
+      return;
+    }
+  }
   auto store_pass = [&](auto cols_tag) {
     constexpr int COLS = decltype(cols_tag)::value;
     constexpr int RS = stage_row_bytes(COLS);
@@ -316,12 +389,13 @@ __device__ __forceinline__ void epilogue_store(const G160Params& p, int m0, int 
   else if constexpr (!GEGLU_ONLY) store_pass(std::integral_constant<int, BN>{});
 }
 
-template <int WMB, int NT, int NTHREADS>
-__device__ __forceinline__ void epilogue160(const float4_t (&acc)[WMB][NT], const G160Params& p, int lane, int m0,
-                                            int n0, int wm, int wn, int split, char* smem, int tid) {
-  epilogue_stage<WMB, NT>(acc, p, lane, m0, n0, wm, wn, split, smem);
+template <int WMB, int NT, int NTHREADS, bool LNOUT = false>
+__device__ __forceinline__ void epilogue160(float4_t (&acc)[WMB][NT], const G160Params& p, int lane, int m0,
+                                            int n0, int wm, int wn, int split, char* smem, int tid,
+                                            const float2* lnstat = nullptr) {
+  epilogue_stage<WMB, NT>(acc, p, lane, m0, n0, wm, wn, split, smem, lnstat);
   __syncthreads();
-  epilogue_store<(NTHREADS / 128) * WMB * 16, NT, NTHREADS>(p, m0, n0, smem, tid);
+  epilogue_store<(NTHREADS / 128) * WMB * 16, NT, NTHREADS, LNOUT>(p, m0, n0, smem, tid);
 }
 
 template <int WAVES_M, int WMB, bool CONV, int NBUF, int NT>
@@ -344,7 +418,11 @@ __global__ __launch_bounds__(WAVES_M * 128) void gemm160_kernel(const G160Params
   static_assert(BM * stage_row_bytes(NT == 10 ? BN / 2 : BN) <= MAIN_BYTES, "the epilogue's staging image reuses the operand ring");
   constexpr int SMEM = MAIN_BYTES;
   static_assert(A_INSTR % NW == 0, "A tile must split evenly over the waves");
-  __shared__ __attribute__((aligned(1024))) char smem[SMEM];
+  static_assert(WAVES_M * 128 >= BM, "one thread per row forms the LayerNorm statistics");
+  // + BM x {rstd, -rstd mean} behind the operand ring (LayerNorm folded into the GEMM): ONE __shared__ object, a
+  // second one would make hipcc drain the LDS-DMA queue in front of every fragment read (guide 5, trap (a))
+  __shared__ __attribute__((aligned(1024))) char smem[SMEM + (CONV ? 0 : BM * 8)];
+  float2* const lnstat = reinterpret_cast<float2*>(smem + SMEM);
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -503,6 +581,25 @@ __global__ __launch_bounds__(WAVES_M * 128) void gemm160_kernel(const G160Params
 #pragma unroll
     for (int s = 0; s < DEPTH; ++s)
       if (s < nsteps) issue(s);
+    if constexpr (!CONV) {
+      if (p.ln_in && tid < BM) {   // row statistics of this block's rows from the producer's partial sums
+        const int m = min(m0 + tid, p.M - 1);
+        const float2* src = p.ln_in + (long)m * p.ln_P;
+        float sum = 0.f, sq = 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {   // all loads in flight, unconditional (ln_P <= 8)
+          const float2 v = src[min(j, p.ln_P - 1)];
+          const float w = j < p.ln_P ? 1.f : 0.f;
+          sum = fmaf(v.x, w, sum);
+          sq = fmaf(v.y, w, sq);
+        }
+        const float inv_k = 1.0f / (float)p.K;
+        const float mean = sum * inv_k;
+        const float var = fmaxf(fmaf(-mean, mean, sq * inv_k), 0.f);
+        const float rstd = rsqrtf(var + p.ln_eps);
+        lnstat[tid] = make_float2(rstd, -rstd * mean);
+      }
+    }
     int buf = 0;
     for (int st = 0; st < nsteps; ++st) {
       // tile kt visible to all waves; everyone is done with the buffer of tile kt-1
@@ -552,7 +649,8 @@ __global__ __launch_bounds__(WAVES_M * 128) void gemm160_kernel(const G160Params
     __syncthreads();  // the epilogue reuses the ring as staging space
   }
 
-  epilogue160<WMB, NT, WAVES_M * 128>(acc, p, lane, m0, n0, wm, wn, split, smem, tid);
+  epilogue160<WMB, NT, WAVES_M * 128, !CONV>(acc, p, lane, m0, n0, wm, wn, split, smem, tid,
+                                             (!CONV && p.ln_in) ? lnstat : nullptr);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1338,6 +1436,27 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const G160Params p) 
         }
       }
     }
+    if (p.ln_in) {   // LayerNorm folded into this GEMM: the affine map of epilogue_stage, on the reduced accumulator
+      const float2* src = p.ln_in + (long)m * p.ln_P;
+      float sum = 0.f, sq = 0.f;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float2 t = src[min(j, p.ln_P - 1)];
+        const float w = j < p.ln_P ? 1.f : 0.f;
+        sum = fmaf(t.x, w, sum);
+        sq = fmaf(t.y, w, sq);
+      }
+      const float inv_k = 1.0f / (float)p.K;
+      const float mean = sum * inv_k;
+      const float rstd = rsqrtf(fmaxf(fmaf(-mean, mean, sq * inv_k), 0.f) + p.ln_eps);
+      const float4_t c0 = *reinterpret_cast<const float4_t*>(p.ln_cs + n);
+      const float4_t c1 = *reinterpret_cast<const float4_t*>(p.ln_cs + n + 4);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        v[e] = fmaf(v[e], rstd, -rstd * mean * c0[e]);
+        v[4 + e] = fmaf(v[4 + e], rstd, -rstd * mean * c1[e]);
+      }
+    }
     Pack16 o;
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
@@ -1368,6 +1487,12 @@ inline int krot_mode() {
 // K step.  Kept selectable for measurements: PFD_PP=1, or forced variants 49 (256-row tile) / 97 (patch kernel).
 inline bool pp_on() {
   static const bool on = getenv("PFD_PP") && atoi(getenv("PFD_PP")) != 0;
+  return on;
+}
+
+// PFD_R3TILES=0 keeps the round-2 tile choice (A/B runs of the round-3 rules in pfd_gemm160_try)
+inline bool r3tiles_on() {
+  static const bool on = !(getenv("PFD_R3TILES") && atoi(getenv("PFD_R3TILES")) == 0);
   return on;
 }
 
@@ -1404,6 +1529,8 @@ int launch160(G160Params& p, int bucket, hipStream_t s) {
     int g = (int)((nvec + 255) / 256);
     if (g > 2048) g = 2048;
     hipLaunchKernelGGL(splitk_reduce_kernel, dim3(g), dim3(256), 0, s, p);
+    // a split-K output that feeds a folded LayerNorm: its row statistics by the stand-alone kernel
+    if (p.ln_out) pfd_ln_rowstats_launch(p.C, p.ldc, p.M, p.N, reinterpret_cast<float*>(p.ln_out), s);
   }
   if (prof) pfd_prof_end(s);
   return pfd_check_launch("pfd_gemm_f16(wide)");
@@ -1437,6 +1564,8 @@ int launch160ws(G160Params& p, int bucket, hipStream_t s, bool pp) {
     int g = (int)((nvec + 255) / 256);
     if (g > 2048) g = 2048;
     hipLaunchKernelGGL(splitk_reduce_kernel, dim3(g), dim3(256), 0, s, p);
+    // a split-K output that feeds a folded LayerNorm: its row statistics by the stand-alone kernel
+    if (p.ln_out) pfd_ln_rowstats_launch(p.C, p.ldc, p.M, p.N, reinterpret_cast<float*>(p.ln_out), s);
   }
   if (prof) pfd_prof_end(s);
   return pfd_check_launch("pfd_gemm_f16(wave-specialised)");
@@ -1466,6 +1595,8 @@ int launch_patch(G160Params& p, hipStream_t s, int ws) {
     int g = (int)((nvec + 255) / 256);
     if (g > 2048) g = 2048;
     hipLaunchKernelGGL(splitk_reduce_kernel, dim3(g), dim3(256), 0, s, p);
+    // a split-K output that feeds a folded LayerNorm: its row statistics by the stand-alone kernel
+    if (p.ln_out) pfd_ln_rowstats_launch(p.C, p.ldc, p.M, p.N, reinterpret_cast<float*>(p.ln_out), s);
   }
   if (prof) pfd_prof_end(s);
   return pfd_check_launch("pfd_gemm_f16(conv3x3 patch)");
@@ -1514,6 +1645,17 @@ int pfd_gemm160_try(const PfdGemmDesc* d, int variant, int splits, hipStream_t s
   p.kt_per_split = 0;
   p.gn_table = (const float*)d->gn_table; p.A2 = (const half_t*)d->A2; p.lda2 = d->lda2;
   p.gn_c1 = d->gn_c1; p.gn_act = d->gn_act;
+  p.ln_in = (const float2*)d->ln_stats; p.ln_cs = (const float*)d->ln_colsum; p.ln_P = d->ln_parts; p.ln_eps = d->ln_eps;
+  p.ln_out = (float2*)d->ln_out;
+  if (p.ln_in) {   // LayerNorm fold: plain linear, statistics over K = ln_parts slices of 160 columns
+    if (d->ksize > 0 || !p.ln_cs || p.ln_P < 1 || p.ln_P > 8 || p.ln_P * 160 != d->K) return 1;
+    if ((reinterpret_cast<uintptr_t>(p.ln_in) & 7) || (reinterpret_cast<uintptr_t>(p.ln_cs) & 15)) return 1;
+    if (variant == 48 || variant == 49) return 1;   // the loader-wave kernels serve convolutions
+  }
+  if (p.ln_out) {  // statistics of the output rows for the consumer's fold
+    if (bn != 160 || d->ksize > 0 || d->act == PFD_ACT_GEGLU || d->Ct || (reinterpret_cast<uintptr_t>(p.ln_out) & 7)) return 1;
+    if (variant == 48 || variant == 49) return 1;
+  }
   if (p.gn_table) {   // GroupNorm prologue: patch kernel or nothing (validated here, PFD_ESHAPE by the caller otherwise)
     if (bn != 160 || (variant != 0 && variant != 98)) return 1;
     variant = 98;   // loader waves without the ping-pong groups (the prologue path is not built for them)
@@ -1528,7 +1670,11 @@ int pfd_gemm160_try(const PfdGemmDesc* d, int variant, int splits, hipStream_t s
   // 3x3 / s1 / p1 convolution on a 16-, 32- or 64-wide image: the patch kernel (variant 0 or 99)
   if (bn == 160 && (variant == 0 || variant == 99 || variant == 98 || variant == 97) && p.ksize == 3 && p.stride == 1 && p.pad == 1 && !p.ups &&
       (p.Wd == 16 || p.Wd == 32 || p.Wd == 64) && p.Ho == p.H && p.Wo == p.Wd && p.H % (256 / p.Wd) == 0 &&
-      p.M % 256 == 0 && p.act != PFD_ACT_GEGLU) {
+      p.M % 256 == 0 && p.act != PFD_ACT_GEGLU &&
+      // round 3: 64 ... 128 patch tiles with <= 5 channel blocks (the 320-channel convolutions of the batch-4 CFG prefix,
+      // 320 -> 640 at 32^2) leave half the CUs idle with no K range worth splitting: the 8-wave 128-row ring serves
+      // them better (16384 x 320 x 2880: 50 -> 43 us, 8192 x 640 x 2880: 50 -> 42; profiles/r03_tile_variants_replay.log)
+      !(variant == 0 && r3tiles_on() && !p.gn_table && tiles(256) >= 64 && tiles(256) <= 128 && p.Cin / BK <= 5)) {
     const int ncb = p.Cin / BK;
     if (splits == 0) {
       splits = 1;
@@ -1575,9 +1721,23 @@ int pfd_gemm160_try(const PfdGemmDesc* d, int variant, int splits, hipStream_t s
     // of 53 KB stages: with the DMA pieces on four dedicated loader waves they gain 5-17 % (32768 x 640 x 5760
     // upsample conv: 225 -> 192 us = 1260 TF); the short-K linears do not (profiles/r02_wave_specialised_ab.log)
     if (variant == 44 && p.ksize > 0) variant = pp_on() ? 49 : 48;
+    // round 3 (cold replay under every forced variant, profiles/r03_tile_variants_replay.log): the 128-row tile on EIGHT
+    // waves (4 x 2 wave layout, wave tile 32 x 80; variants 82 / 83) instead of four beats the 4-wave form wherever
+    // that was chosen (qkv 8192 x 1920 x 640: 32.5 -> 27.3 us, 32768 x 960 x 320: 34.3 -> 31.8, ff-out 8192 x 640 x 2560
+    // 39.4 -> 36.1, upsample conv 2048 x 1280 x 11520: 94 -> 73); GEGLU projections with >= 10 K tiles take the 256 x 320
+    // tile (84: 8192 x 5120 x 640 69 -> 60 us, 2048 x 10240 x 1280 63 -> 51); long-K problems on <= 2048 rows and the
+    // stride-2 convolutions take the 64-row tile on eight waves with the 4-stage ring and NO split-K (43: 2048 x 1280 x
+    // 5120 55 -> 48 us, 2048 x 640 x 5760 / s2 52 -> 37, 8192 x 320 x 2880 / s2 38.5 -> 30.7).
+    if (r3tiles_on() && bn == 160) {
+      if (p.act == PFD_ACT_GEGLU && p.ksize == 0 && p.N % 320 == 0 && p.M >= 2048 && nk_all >= 10) variant = 84;
+      else if (p.ksize == 0 && (variant == 24 || variant == 25) && p.M <= 2048 && nk_all >= 64) variant = 43;
+      else if (p.ksize > 0 && p.stride == 2 && p.M <= 8192 && (variant == 24 || variant == 25 || variant == 22)) variant = 43;
+      else if (variant == 24) variant = 82;
+      else if (variant == 25) variant = 83;
+    }
   }
-  const int bm = (variant == 44 || variant == 45 || variant == 48 || variant == 49 || variant == 84) ? 256
-                 : (variant == 24 || variant == 25 || variant == 26) ? 128 : 64;
+  const int bm = (variant == 44 || variant == 48 || variant == 49 || variant == 84) ? 256
+                 : (variant == 24 || variant == 25 || variant == 82 || variant == 83) ? 128 : 64;
   if (splits == 0) {
     splits = 1;
     const long tl = tiles(bm);
@@ -1585,12 +1745,12 @@ int pfd_gemm160_try(const PfdGemmDesc* d, int variant, int splits, hipStream_t s
     if (p.act != PFD_ACT_GEGLU && d->ws && (variant == 44 || variant == 48 || variant == 49) && tl < 200 && nk >= 48 &&
         (size_t)2 * p.M * p.N * 4 <= d->ws_bytes) {
       splits = 2;  // 128 tiles of 256x160: two K halves fill the chip (758 vs 579 TF at 640->640 @32^2)
-    } else if (p.act != PFD_ACT_GEGLU && d->ws && (variant == 24 || variant == 25) && tl < 256) {
+    } else if (p.act != PFD_ACT_GEGLU && d->ws && (variant == 24 || variant == 25 || variant == 82 || variant == 83) && tl < 256) {
       splits = (int)((512 + tl - 1) / tl);
       if (splits > 8) splits = 8;
       while (splits > 1 && nk / splits < 16) --splits;  // the slab round trip must stay small vs the K loop
       while (splits > 1 && (size_t)splits * p.M * p.N * 4 > d->ws_bytes) --splits;
-    } else if (p.act != PFD_ACT_GEGLU && d->ws && (variant == 22 || variant == 23) && tl <= 128 && nk >= 16) {
+    } else if (p.act != PFD_ACT_GEGLU && d->ws && (variant == 22 || variant == 23 || variant == 41 || variant == 43) && tl <= 128 && nk >= 16) {
       splits = (int)(256 / tl);   // M <= 1024 rows (8^2 level, cond-half projections): 25 -> 21 us
       if (splits > 4) splits = 4;
       while (splits > 1 && (size_t)splits * p.M * p.N * 4 > d->ws_bytes) --splits;
@@ -1607,6 +1767,7 @@ int pfd_gemm160_try(const PfdGemmDesc* d, int variant, int splits, hipStream_t s
     const int nk_split = nk_all / splits;
     if (variant == 22 && tiles(64) * splits <= 256 && nk_split >= 8) variant = 23;
     if (variant == 24 && tiles(128) < 256 && nk_split >= 6) variant = 25;
+    if (variant == 82 && (p.ksize == 0 || (p.stride == 1 && !p.ups)) && tiles(128) <= 256 && nk_split >= 6) variant = 83;
   }
   const int conv = p.ksize > 0 ? 1 : 0;
   if (variant == 48 || variant == 49) {   // 8 MFMA waves + 4 loader waves (49: ping-pong consumer groups)
@@ -1632,9 +1793,13 @@ int pfd_gemm160_try(const PfdGemmDesc* d, int variant, int splits, hipStream_t s
     // deep operand rings (counted vmcnt): K tiles in flight ahead of the MFMAs = 3 (64-row tile) / 2 (128-row tile)
     case 23: return launch160<2, 2, 4>(p, 14 + 4 * conv, s) < 0 ? PFD_ELAUNCH : 0;
     case 25: return launch160<2, 4, 3>(p, 13 + 4 * conv, s) < 0 ? PFD_ELAUNCH : 0;
-    // round 3: deeper rings for the HBM-bound long-K linears (more activation bytes in flight per CU)
-    case 26: return launch160<2, 4, 4>(p, 13 + 4 * conv, s) < 0 ? PFD_ELAUNCH : 0;
-    case 45: return launch160<4, 4, 3>(p, 12 + 4 * conv, s) < 0 ? PFD_ELAUNCH : 0;
+    // round 3 experiments: the same tiles on 8 waves (4 x 2 wave layout, wave tile 16 x 80 / 32 x 80): twice the waves
+    // issuing LDS-DMA pieces per CU and two waves per SIMD on the problems whose one 4-wave block per CU is bound by the
+    // piece issue rate (64-row tiles: 41 two stages, 43 four-stage ring; 128-row tiles: 82 two stages, 83 three)
+    case 41: return launch160<4, 1, 2>(p, 14 + 4 * conv, s) < 0 ? PFD_ELAUNCH : 0;
+    case 43: return launch160<4, 1, 4>(p, 14 + 4 * conv, s) < 0 ? PFD_ELAUNCH : 0;
+    case 82: return launch160<4, 2, 2>(p, 13 + 4 * conv, s) < 0 ? PFD_ELAUNCH : 0;
+    case 83: return launch160<4, 2, 3>(p, 13 + 4 * conv, s) < 0 ? PFD_ELAUNCH : 0;
     default: return PFD_EINVAL;
   }
 }

@@ -669,6 +669,55 @@ extern "C" int pfd_layernorm_f16(const void* x, int64_t ldx, const void* gamma, 
   return pfd_check_launch("pfd_layernorm_f16");
 }
 
+// Partial row sums for the LayerNorm folded into the consumer GEMM (PfdGemmDesc.ln_stats).  Fallback producer only
+// (tensors that were not written by a wide-tile GEMM epilogue: the `x + bias` rows of the zero-context shortcut, split-K
+// outputs).  SAME summation order as the statistics-emitting store pass of the GEMM epilogue (gemm_glds.hip,
+// epilogue_store): four lanes per (row, 160-column slice), lane k adds chunks k, k + 4, ..., k + 16 element by element,
+// then xor-1 and xor-2 exchanges -- so a row's statistics do not depend on which of the two wrote them (the
+// zero-context shortcut stays bit-identical to the full computation).
+__global__ __launch_bounds__(256) void ln_rowstats_kernel(const half_t* __restrict__ x, long ldx, int M, int P,
+                                                          float2* __restrict__ out) {
+  const long grp = ((long)blockIdx.x * 256 + threadIdx.x) >> 2;
+  const int k = threadIdx.x & 3;
+  const long ngrp = (long)M * P;
+  const long g = min(grp, ngrp - 1);
+  const int m = (int)(g / P), p = (int)(g - (long)m * P);
+  const half_t* src = x + (long)m * ldx + p * 160;
+  Pack16 v[5];
+#pragma unroll
+  for (int j = 0; j < 5; ++j) v[j].u = *reinterpret_cast<const uint4*>(src + (k + 4 * j) * 8);   // all loads first
+  float s = 0.f, q = 0.f;
+#pragma unroll
+  for (int j = 0; j < 5; ++j)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const float f = (float)v[j].e[e];
+      s += f;
+      q = fmaf(f, f, q);
+    }
+  s += __shfl_xor(s, 1, 64);
+  q += __shfl_xor(q, 1, 64);
+  s += __shfl_xor(s, 2, 64);
+  q += __shfl_xor(q, 2, 64);
+  if (k == 0 && grp < ngrp) out[grp] = make_float2(s, q);
+}
+
+int pfd_ln_rowstats_launch(const half_t* x, long ldx, int M, int C, float* out, hipStream_t s) {
+  const int P = C / 160;
+  const long ngrp = (long)M * P;
+  PfdProfScope prof_scope(11, 0.0, 2.0 * M * C, s);
+  hipLaunchKernelGGL(ln_rowstats_kernel, dim3((unsigned)((ngrp + 63) / 64)), dim3(256), 0, s, x, ldx, M, P,
+                     reinterpret_cast<float2*>(out));
+  return pfd_check_launch("pfd_ln_rowstats_f16");
+}
+
+extern "C" int pfd_ln_rowstats_f16(const void* x, int64_t ldx, int32_t M, int32_t C, void* out, pfd_stream_t stream) {
+  if (!x || !out || M <= 0 || C <= 0) return PFD_EINVAL;
+  if ((C % 160) || C > 1280) return PFD_ESHAPE;
+  if ((ldx & 7) || (reinterpret_cast<uintptr_t>(x) & 15) || (reinterpret_cast<uintptr_t>(out) & 7)) return PFD_EINVAL;
+  return pfd_ln_rowstats_launch((const half_t*)x, (long)ldx, M, C, (float*)out, (hipStream_t)stream);
+}
+
 extern "C" int pfd_softmax_rows_f16(const void* x, int64_t ldx, void* y, int64_t ldy, int32_t R, int32_t N,
                                     float scale, pfd_stream_t stream) {
   if (!x || !y || R <= 0 || N <= 0) return PFD_EINVAL;

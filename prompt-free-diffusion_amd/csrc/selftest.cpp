@@ -217,6 +217,119 @@ static void run_gemm_case(const GemmCase& c) {
   report(name, gotc, ref, 4e-3, 3e-3);
 }
 
+// ------------------------------------------------------------------ LayerNorm folded into the GEMM (ABI 7)
+// x = producer GEMM output (+ residual) with ln_out; y = LN(x; gamma, beta) W^T + b computed by the consumer GEMM over
+// the un-normalised x with the gamma-scaled weight, the column sums and b' -- against an fp64 LayerNorm -> Linear
+// over the same f16 x.  Also: producer partial sums == pfd_ln_rowstats_f16 of the stored x.
+static void run_ln_fold_case(int M, int C, int N, int act, int tile_prod, int tile_cons, int n_split) {
+  const int Kp = 192;                       // producer contraction length
+  const int P = C / 160;
+  auto A0 = rand_h((size_t)M * Kp), W0 = rand_h((size_t)C * Kp, 0.12f), b0 = rand_h(C, 0.5f), R0 = rand_h((size_t)M * C, 2.0f);
+  for (int m = 0; m < M; ++m)               // a per-row offset so that mean^2 >> var on some rows (cancellation check)
+    for (int c = 0; c < C; ++c) R0[(size_t)m * C + c] = (h16)((float)R0[(size_t)m * C + c] + (m % 7 == 0 ? 6.0f : 0.3f));
+  auto gam = rand_f(C, 0.5f), bet = rand_f(C, 0.3f);
+  for (auto& g : gam) g += 1.0f;
+  auto W1 = rand_h((size_t)N * C, 0.08f), b1 = rand_h(N, 0.5f);
+  const float eps = 1e-5f;
+  // packed operands of the fold: W' = f16(W o gamma), s_n = sum_k W'[n][k], b'_n = sum_k beta_k W[n][k] + b_n
+  std::vector<h16> Wg((size_t)N * C), bp(N);
+  std::vector<float> cs(N);
+  for (int n = 0; n < N; ++n) {
+    double sacc = 0, bacc = (double)b1[n];
+    for (int k = 0; k < C; ++k) {
+      const h16 w = (h16)((float)W1[(size_t)n * C + k] * gam[k]);
+      Wg[(size_t)n * C + k] = w;
+      sacc += (double)w;
+      bacc += (double)bet[k] * (double)W1[(size_t)n * C + k];
+    }
+    cs[n] = (float)sacc;
+    bp[n] = (h16)bacc;
+  }
+  Dev<h16> dA0(A0), dW0(W0), db0(b0), dR0(R0), dX((size_t)M * C), dWg(Wg), dbp(bp);
+  Dev<float> dcs(cs), dst((size_t)M * P * 2), dst2((size_t)M * P * 2), dWS((size_t)8 * M * std::max(N, C) + 64);
+  const int Nout = act == PFD_ACT_GEGLU ? N / 2 : (n_split > 0 ? n_split : N);
+  Dev<h16> dY((size_t)M * Nout);
+  const long ldct = (M + 7) / 8 * 8;
+  Dev<h16> dCt(n_split > 0 ? (size_t)(N - n_split) * ldct : 8);
+  char name[200];
+  snprintf(name, sizeof(name), "ln-fold M%d C%d N%d act%d prod%d cons%d split%d", M, C, N, act, tile_prod, tile_cons, n_split);
+  PfdGemmDesc d;
+  memset(&d, 0, sizeof(d));
+  d.A = dA0.p; d.W = dW0.p; d.bias = db0.p; d.R = dR0.p; d.C = dX.p;
+  d.lda = Kp; d.ldw = Kp; d.ldr = C; d.ldc = C; d.M = M; d.N = C; d.K = Kp; d.rows_per_rv = 1;
+  d.ws = dWS.p; d.ws_bytes = dWS.n * sizeof(float);
+  d.ln_out = dst.p;
+  int rc = pfd_gemm_f16_ex(&d, tile_prod, nullptr);
+  if (rc == 0) rc = pfd_ln_rowstats_f16(dX.p, C, M, C, dst2.p, nullptr);
+  PfdGemmDesc e;
+  memset(&e, 0, sizeof(e));
+  e.A = dX.p; e.W = dWg.p; e.bias = dbp.p; e.C = dY.p;
+  e.lda = C; e.ldw = C; e.ldc = Nout; e.M = M; e.N = N; e.K = C; e.rows_per_rv = 1; e.act = act;
+  e.ws = dWS.p; e.ws_bytes = dWS.n * sizeof(float);
+  e.ln_stats = dst.p; e.ln_colsum = dcs.p; e.ln_parts = P; e.ln_eps = eps;
+  if (n_split > 0) { e.Ct = dCt.p; e.ldct = ldct; e.n_split = n_split; }
+  if (rc == 0) rc = pfd_gemm_f16_ex(&e, tile_cons, nullptr);
+  if (rc != 0) { ++g_total; ++g_fail; printf("FAIL %-58s rc=%d (%s)\n", name, rc, pfd_last_error()); return; }
+  auto X = dX.get();
+  auto st = dst.get(), st2 = dst2.get();
+  {  // statistics: producer epilogue vs stand-alone kernel vs fp64 over the stored x
+    std::vector<double> ref(st.size());
+    for (int m = 0; m < M; ++m)
+      for (int p = 0; p < P; ++p) {
+        double a = 0, q = 0;
+        for (int c = 0; c < 160; ++c) { const double v = (double)X[(size_t)m * C + p * 160 + c]; a += v; q += v * v; }
+        ref[((size_t)m * P + p) * 2] = a; ref[((size_t)m * P + p) * 2 + 1] = q;
+      }
+    report((std::string(name) + " [stats: epilogue]").c_str(), st, ref, 2e-2, 2e-5);
+    report((std::string(name) + " [stats: kernel]").c_str(), st2, ref, 2e-2, 2e-5);
+  }
+  std::vector<double> pre((size_t)M * N);
+  std::vector<double> xn(C);
+  for (int m = 0; m < M; ++m) {
+    double mu = 0, var = 0;
+    for (int c = 0; c < C; ++c) mu += (double)X[(size_t)m * C + c];
+    mu /= C;
+    for (int c = 0; c < C; ++c) { const double dlt = (double)X[(size_t)m * C + c] - mu; var += dlt * dlt; }
+    const double rstd = 1.0 / sqrt(var / C + eps);
+    for (int c = 0; c < C; ++c) xn[c] = ((double)X[(size_t)m * C + c] - mu) * rstd * gam[c] + bet[c];
+    for (int n = 0; n < N; ++n) {
+      double a = (double)b1[n];
+      for (int c = 0; c < C; ++c) a += xn[c] * (double)W1[(size_t)n * C + c];
+      pre[(size_t)m * N + n] = a;
+    }
+  }
+  auto got = dY.get();
+  std::vector<double> ref((size_t)M * Nout);
+  for (int m = 0; m < M; ++m)
+    for (int n = 0; n < Nout; ++n) {
+      if (act == PFD_ACT_GEGLU) {
+        const int blk = n / 2, j = n % 2;
+        ref[(size_t)m * Nout + n] = pre[(size_t)m * N + blk * 4 + j] * act_ref(pre[(size_t)m * N + blk * 4 + 2 + j], PFD_ACT_GELU);
+      } else {
+        ref[(size_t)m * Nout + n] = act_ref(pre[(size_t)m * N + n], act);
+      }
+    }
+  report(name, got, ref, 1e-2, 6e-3);
+  if (n_split > 0) {
+    auto gt = dCt.get();
+    std::vector<double> rt(gt.size(), 0.0);
+    for (int n = n_split; n < N; ++n)
+      for (int m = 0; m < M; ++m) rt[(size_t)(n - n_split) * ldct + m] = pre[(size_t)m * N + n];
+    report((std::string(name) + " [Ct]").c_str(), gt, rt, 1e-2, 6e-3);
+  }
+}
+
+static void run_ln_fold_suite() {
+  run_ln_fold_case(300, 320, 960, 0, 0, 0, 640);            // fused q | k | v^T of a 320-wide block (transposed tail)
+  run_ln_fold_case(700, 320, 320, 0, 3400, 3400, 0);        // 128-row tiles, 4 waves
+  run_ln_fold_case(520, 640, 640, 0, 9200, 9200, 0);        // 128-row tiles, 8 waves
+  run_ln_fold_case(300, 640, 1280, PFD_ACT_GEGLU, 5400, 5400, 0);   // GEGLU, 256-row tiles
+  run_ln_fold_case(600, 320, 640, PFD_ACT_GEGLU, 3200, 9400, 0);    // 256 x 320 GEGLU tile; 64-row producer
+  run_ln_fold_case(130, 1280, 320, 0, 3204, 3204, 0);       // split-K on both sides (stats by the stand-alone kernel)
+  run_ln_fold_case(200, 1280, 1280, PFD_ACT_GELU, 5300, 3300, 0);   // 8-wave 64-row ring producer, 4-wave ring consumer
+  run_ln_fold_case(77, 960, 160, 0, 9300, 3500, 0);         // ragged M, 6 partials
+}
+
 // ------------------------------------------------------------------ attention
 static void run_attn_case(int B, int H, int Nq, int Nk, int D, bool fused_layout) {
   const int C = H * D;
@@ -835,6 +948,43 @@ int main(int argc, char** argv) {
     bench_gn_conv("1920->640 @32^2 (skip concat)", 16, 32, 1280, 640, 640);
     return 0;
   }
+  if (argc > 1 && !strcmp(argv[1], "--gemm-new")) {   // quick correctness pass over the round-3 tile variants only
+    for (int v : {5100, 5300, 9200, 9300}) {
+      run_gemm_case({1100, 320, 1024, 0, true, true, true, false, v});
+      run_gemm_case({300, 320, 192, PFD_ACT_SILU, true, true, true, false, v});
+      run_gemm_case({77, 160, 64, 0, true, false, false, false, v, 8});
+      run_gemm_case({0, 160, 0, 0, true, true, false, false, v, 0, 3, 1, 1, 0, 3, 16, 16, 128});
+      run_gemm_case({900, 320, 1536, 0, true, false, false, false, v + 3});
+      run_gemm_case({200, 320, 128, PFD_ACT_GEGLU, true, false, false, false, v});
+    }
+    { GemmCase t{520, 480, 128, 0, false, false, false, false, 5100}; t.n_split = 320; run_gemm_case(t); }
+    { GemmCase t{520, 480, 128, 0, false, false, false, false, 9200}; t.n_split = 320; run_gemm_case(t); }
+    run_gemm_case({600, 640, 320, PFD_ACT_GEGLU, true, false, false, false, 9400});
+    run_gemm_case({300, 320, 64, PFD_ACT_GEGLU, false, false, false, false, 9400});
+    printf("SELFTEST %d/%d passed, %d failed\n", g_total - g_fail, g_total, g_fail);
+    return g_fail;
+  }
+  if (argc > 1 && !strcmp(argv[1], "--ln")) {
+    run_ln_fold_suite();
+    printf("SELFTEST %d/%d passed, %d failed\n", g_total - g_fail, g_total, g_fail);
+    return g_fail;
+  }
+  if (argc > 1 && !strcmp(argv[1], "--attn")) {   // attention correctness cases only (seconds; run once per PFD_ATTN mode)
+    run_attn_case(2, 2, 128, 128, 40, true);
+    run_attn_case(1, 2, 300, 148, 40, false);
+    run_attn_case(2, 2, 512, 256, 40, true);
+    run_attn_case(1, 1, 256, 40, 40, false);
+    run_attn_case(1, 2, 520, 1000, 40, false);
+    run_attn_case(1, 2, 77, 64, 40, true);
+    run_attn_case(1, 2, 200, 148, 40, false);
+    run_attn_case(2, 2, 64, 64, 80, true);
+    run_attn_case(1, 2, 144, 256, 96, false);
+    run_attn_case(1, 3, 148, 148, 96, false);
+    run_attn_case(2, 2, 64, 148, 160, false);
+    run_attn_case(1, 1, 256, 320, 160, true);
+    printf("SELFTEST %d/%d passed, %d failed\n", g_total - g_fail, g_total, g_fail);
+    return g_fail;
+  }
   if (argc > 1 && !strcmp(argv[1], "--bench-attn")) {
     bench_attn("self-attn 64^2 d40", 8, 8, 4096, 4096, 40);
     bench_attn("self-attn 32^2 d80", 8, 8, 1024, 1024, 80);
@@ -951,7 +1101,7 @@ int main(int argc, char** argv) {
     }
     run_gemm_case({600, 640, 320, PFD_ACT_GEGLU, true, false, false, false, 9400});   // 256 x 320 GEGLU tile
     run_gemm_case({300, 320, 64, PFD_ACT_GEGLU, false, false, false, false, 9400});
-    for (int v : {3200, 3300, 3400, 3500, 5400, 3600, 5500}) {   // the 8-wave kernels, rotated walk over several M tiles
+    for (int v : {3200, 3300, 3400, 3500, 5400, 5100, 5300, 9200, 9300}) {   // rotated walk over several M tiles; 8-wave small tiles
       run_gemm_case({1100, 320, 1024, 0, true, true, true, false, v});
       run_gemm_case({0, 160, 0, 0, true, true, false, false, v, 0, 3, 1, 1, 0, 3, 16, 16, 128});
       run_gemm_case({900, 320, 1536, 0, true, false, false, false, v + 3});
@@ -966,7 +1116,13 @@ int main(int argc, char** argv) {
     run_gemm_case({0, 320, 0, 0, true, false, false, false, 0, 8, 3, 2, 0, 0, 1, 9, 9, 64});               // pad 0, ld+8
     run_gemm_case({0, 160, 0, 0, true, false, false, false, 0, 0, 1, 1, 0, 0, 2, 6, 6, 128});              // 1x1 as conv
 
+    run_ln_fold_suite();
     run_attn_case(2, 2, 128, 128, 40, true);
+    run_attn_case(1, 2, 300, 148, 40, false);    // ragged queries and keys (2 full tiles + 20 keys)
+    run_attn_case(2, 2, 512, 256, 40, true);     // full tiles only
+    run_attn_case(1, 1, 256, 40, 40, false);     // a single ragged tile
+    run_attn_case(1, 2, 520, 1000, 40, false);   // 15 full tiles + 40 keys
+    run_attn_case(1, 2, 77, 64, 40, true);       // exactly one full tile
     run_attn_case(1, 2, 200, 148, 40, false);
     run_attn_case(2, 2, 64, 64, 80, true);
     run_attn_case(1, 2, 144, 256, 96, false);

@@ -14,7 +14,7 @@ import os
 _LIB = None
 _LIB_PATH = os.path.normpath(os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "..", "libpfd_hip.so"))
 
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 ACT_NONE, ACT_GELU, ACT_RELU, ACT_SILU, ACT_GEGLU = 0, 1, 2, 3, 4
 
@@ -32,6 +32,7 @@ class PfdGemmDesc(C.Structure):
         ("ws", _vp), ("ws_bytes", _sz),
         ("Ct", _vp), ("ldct", _i64), ("n_split", _i32), ("reserved0", _i32),
         ("gn_table", _vp), ("A2", _vp), ("lda2", _i64), ("gn_c1", _i32), ("gn_act", _i32),
+        ("ln_stats", _vp), ("ln_colsum", _vp), ("ln_parts", _i32), ("ln_eps", _f32), ("ln_out", _vp),
     ]
 
 
@@ -68,6 +69,7 @@ SIGNATURES = {
     "pfd_groupnorm_f16": (_i32, [_vp, _i32, _i64, _vp, _i32, _i64, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _f32,
                                  _i32, _vp, _sz, _vp]),
     "pfd_layernorm_f16": (_i32, [_vp, _i64, _vp, _vp, _vp, _i64, _i32, _i32, _f32, _i32, _i32, _i32, _i32, _vp]),
+    "pfd_ln_rowstats_f16": (_i32, [_vp, _i64, _i32, _i32, _vp, _vp]),
     "pfd_softmax_rows_f16": (_i32, [_vp, _i64, _vp, _i64, _i32, _i32, _f32, _vp]),
     "pfd_nchw_to_nhwc_f16": (_i32, [_vp, _i32, _vp, _i32, _i32, _i32, _i32, _f32, _f32, _i32, _vp]),
     "pfd_nhwc_to_nchw": (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _f32, _f32, _f32, _f32, _vp]),

@@ -79,6 +79,21 @@ def pack_vec(b):
     return None if b is None else _dev16(b).contiguous()
 
 
+def fold_layernorm(w, b, gamma, beta):
+    """Operands of a Linear whose input LayerNorm is folded into the GEMM (PfdGemmDesc.ln_stats): w [N, K] fp16 in
+    KERNEL row order (after any GEGLU interleave), b [N] fp16 or None in the same order, gamma / beta the LayerNorm
+    affine [K].  -> (W o gamma as fp16, its fp32 row sums s_n, b' = beta . W^T + b as fp16).  Runs once per weight
+    version (load time), like every other packing step."""
+    w32 = w.float()
+    g32, be32 = gamma.detach().float(), beta.detach().float()
+    wg = (w32 * g32[None, :]).to(torch.float16).contiguous()
+    cs = wg.float().sum(1).contiguous()
+    bp = w32 @ be32
+    if b is not None:
+        bp = bp + b.float()
+    return wg, cs, bp.to(torch.float16).contiguous()
+
+
 class _Packed:
     """mixin: self._packed(name, builder, *params) -> cached kernel-layout tensors"""
 
@@ -106,7 +121,8 @@ class Conv2d(nn.Conv2d, _Packed):
         return self._packed("w", lambda: (pack_conv_weight(self.weight), pack_vec(self.bias)), self.weight, self.bias)
 
     def hip(self, x, *, ups=False, rowvec=None, res=None, act=ACT_NONE, out=None, out_hw=None, rows_per_rv=None,
-            gn=None):
+            gn=None, ln_out=None):
+        """ln_out (1x1 convolutions only): also return the partial row sums of the output, see ops.gemm"""
         w, b = self._pk()
         k, s, p = self.kernel_size[0], self.stride[0], self.padding[0]
         cin = self.in_channels
@@ -120,8 +136,12 @@ class Conv2d(nn.Conv2d, _Packed):
                 r2 = None if res is None else res.reshape(-1, res.shape[-1])
                 y = ops.gemm(x.reshape(-1, cin), w, bias=b, rowvec=rowvec,
                              rows_per_rv=H * W_ if rows_per_rv is None else rows_per_rv, res=r2, act=act,
-                             out=o2)
+                             out=o2, ln_out=ln_out)
+                if ln_out is not None and ln_out is not False:
+                    return y[0].view(B, H, W_, self.out_channels), y[1]
                 return y.view(B, H, W_, self.out_channels)
+            if ln_out is not None and ln_out is not False:
+                raise ValueError("ln_out is for 1x1 convolutions (token-wise linears)")
             return ops.conv(x, w, k, stride=s, pad=p, ups=ups, bias=b, rowvec=rowvec, res=res, act=act, out=out,
                             out_hw=out_hw, rows_per_rv=rows_per_rv)
         if ups:
@@ -139,8 +159,20 @@ class Linear(nn.Linear, _Packed):
     def _pk(self):
         return self._packed("w", lambda: (pack_matrix(self.weight), pack_vec(self.bias)), self.weight, self.bias)
 
-    def hip(self, x, *, act=ACT_NONE, res=None, rowvec=None, rows_per_rv=1, out=None):
-        """x: [..., K] fp16 token-major -> [..., N]"""
+    def _pk_ln(self, norm):
+        """(W o gamma, column sums, b') for `norm` folded into this Linear (fold_layernorm)"""
+        return self._packed(("ln", id(norm)), lambda: fold_layernorm(*self._pk(), norm.weight, norm.bias),
+                            self.weight, self.bias, norm.weight, norm.bias)
+
+    def hip(self, x, *, act=ACT_NONE, res=None, rowvec=None, rows_per_rv=1, out=None, ln=None, ln_out=None):
+        """x: [..., K] fp16 token-major -> [..., N].
+        ln = (LayerNorm module, partial row sums of x): the LayerNorm in front of this Linear is folded into the GEMM
+        (x is the UN-normalised tensor).  ln_out: see ops.gemm (returns (y, stats))."""
+        if ln is not None:
+            norm, st = ln
+            w, cs, b = self._pk_ln(norm)
+            return ops.gemm(x, w, bias=b, act=act, res=res, rowvec=rowvec, rows_per_rv=rows_per_rv, out=out,
+                            ln=(st, cs, norm.eps), ln_out=ln_out)
         w, b = self._pk()
         K = self.in_features
         x2 = x.reshape(-1, K) if x.dim() != 2 else x
@@ -149,7 +181,9 @@ class Linear(nn.Linear, _Packed):
             xp[:, :K] = x2
             x2 = xp
         r2 = None if res is None else (res.reshape(-1, res.shape[-1]) if res.dim() != 2 else res)
-        y = ops.gemm(x2, w, bias=b, act=act, res=r2, rowvec=rowvec, rows_per_rv=rows_per_rv, out=out)
+        y = ops.gemm(x2, w, bias=b, act=act, res=r2, rowvec=rowvec, rows_per_rv=rows_per_rv, out=out, ln_out=ln_out)
+        if ln_out is not None and ln_out is not False:
+            return y
         return y if x.dim() == 2 else y.view(*x.shape[:-1], y.shape[-1])
 
     def hip_t(self, x2d, out=None):

@@ -60,6 +60,8 @@ def _workspace(device):
 
 
 _TRACE = os.environ.get("PFD_TRACE_GEMM")
+# PFD_LN_FOLD=0: every LayerNorm is its own launch again (A/B runs)
+LN_FOLD = os.environ.get("PFD_LN_FOLD", "1") != "0"
 
 
 def _trace(d):
@@ -99,10 +101,31 @@ def _rows(t):
 # ----------------------------------------------------------------------------------------------
 # GEMM / convolution
 # ----------------------------------------------------------------------------------------------
+def ln_fold_ok(C):
+    """widths whose LayerNorm can be folded into the consumer GEMM (PfdGemmDesc.ln_stats: 160-column slices, <= 8)"""
+    return LN_FOLD and C % 160 == 0 and C // 160 <= 8
+
+
+def ln_rowstats(x, out=None):
+    """partial row sums [M, C/160, 2] (fp32) of a token matrix, in the layout gemm(ln=...) takes -- for tensors that
+    were not written by a gemm(ln_out=...) launch"""
+    _chk16(x, "ln_rowstats x")
+    M, Cc, ld = _rows(x)
+    if out is None:
+        out = torch.empty((M, Cc // 160, 2), dtype=torch.float32, device=x.device)
+    elif out.dtype != torch.float32 or not out.is_contiguous() or out.numel() != M * (Cc // 160) * 2:
+        raise ValueError("ln_rowstats: out must be a contiguous float32 [M, C/160, 2]")
+    _b.check(_lib().pfd_ln_rowstats_f16(x.data_ptr(), ld, M, Cc, out.data_ptr(), _stream()), "pfd_ln_rowstats_f16")
+    return out
+
+
 def gemm(a, w, *, bias=None, rowvec=None, rows_per_rv=1, res=None, act=ACT_NONE, out=None,
-         bias_per_row=False, n=None, k=None, tile=0, out_t=None, n_split=None):
+         bias_per_row=False, n=None, k=None, tile=0, out_t=None, n_split=None, ln=None, ln_out=None):
     """out[M, N] = epi(a[M, K] @ w[N, K]^T); see pfd_gemm_f16 in include/pfd_hip.h.
-    out_t / n_split: columns >= n_split go, transposed, to out_t[N - n_split, M] (wide-tile path only)."""
+    out_t / n_split: columns >= n_split go, transposed, to out_t[N - n_split, M] (wide-tile path only).
+    ln = (stats, colsum, eps): LayerNorm of `a` folded into the contraction (w is the gamma-scaled weight, bias is b';
+    PfdGemmDesc.ln_stats).  ln_out: True (allocate) or a float32 [M, N/160, 2] tensor -> the partial row sums of the
+    OUTPUT are written there and (out, stats) is returned."""
     _chk16(a, "gemm A")
     _chk16(w, "gemm W")
     M, Ka, lda = _rows(a)
@@ -134,12 +157,29 @@ def gemm(a, w, *, bias=None, rowvec=None, rows_per_rv=1, res=None, act=ACT_NONE,
     d.rows_per_rv, d.act, d.bias_per_row = rows_per_rv, act, 1 if bias_per_row else 0
     d.ksize = 0
     d.ws, d.ws_bytes = _workspace(a.device).data_ptr(), _WS_BYTES
+    if ln is not None:
+        st, cs, eps = ln
+        if st.dtype != torch.float32 or not st.is_contiguous() or st.dim() != 3 or st.shape[0] != M or \
+                st.shape[1] * 160 != K or st.shape[2] != 2 or st.device != a.device:
+            raise ValueError(f"gemm: ln stats {tuple(st.shape)} {st.dtype} do not describe a [{M}, {K}] operand")
+        if cs.dtype != torch.float32 or cs.numel() != N or not cs.is_contiguous() or cs.device != a.device:
+            raise ValueError("gemm: ln column sums must be a contiguous float32 [N]")
+        d.ln_stats, d.ln_colsum, d.ln_parts, d.ln_eps = st.data_ptr(), cs.data_ptr(), st.shape[1], float(eps)
+    stats = None
+    if ln_out is not None and ln_out is not False:
+        if ln_out is True:
+            stats = torch.empty((M, N // 160, 2), dtype=torch.float32, device=a.device)
+        else:
+            stats = ln_out
+            if stats.dtype != torch.float32 or not stats.is_contiguous() or stats.numel() != M * (N // 160) * 2:
+                raise ValueError("gemm: ln_out must be a contiguous float32 [M, N/160, 2]")
+        d.ln_out = stats.data_ptr()
     if _TRACE:
         _trace(d)
     lib = _lib()
     rc = lib.pfd_gemm_f16_ex(_byref(d), tile, _stream()) if tile else lib.pfd_gemm_f16(_byref(d), _stream())
     _b.check(rc, f"pfd_gemm_f16 M{M} N{N} K{K}")
-    return out
+    return out if stats is None else (out, stats)
 
 
 def conv_gn_fusable(B, H, W_, C1, C2, N, ksize=3, stride=1, pad=1):

@@ -125,7 +125,16 @@ class GEGLU(nn.Module, L._Packed):
             return wi.contiguous(), bi.contiguous()
         return self._packed("geglu", build, self.proj.weight, self.proj.bias)
 
-    def hip(self, x2d):
+    def _pk_ln(self, norm):
+        return self._packed(("geglu_ln", id(norm)), lambda: L.fold_layernorm(*self._pk(), norm.weight, norm.bias),
+                            self.proj.weight, self.proj.bias, norm.weight, norm.bias)
+
+    def hip(self, x2d, ln=None):
+        """ln = (LayerNorm module, partial row sums of x2d): norm3 folded into the projection (x2d un-normalised)"""
+        if ln is not None:
+            norm, st = ln
+            w, cs, b = self._pk_ln(norm)
+            return ops.gemm(x2d, w, bias=b, act=ops.ACT_GEGLU, ln=(st, cs, norm.eps))
         w, b = self._pk()
         return ops.gemm(x2d, w, bias=b, act=ops.ACT_GEGLU)
 
@@ -143,8 +152,11 @@ class FeedForward(nn.Module):
         project_in = GEGLU(dim, inner_dim) if glu else nn.Sequential(L.Linear(dim, inner_dim), nn.GELU())
         self.net = nn.Sequential(project_in, nn.Dropout(dropout), L.Linear(inner_dim, dim_out))
 
-    def hip(self, x2d, res=None):
-        h = self.net[0].hip(x2d) if self.glu else self.net[0][0].hip(x2d, act=ops.ACT_GELU)
+    def hip(self, x2d, res=None, ln=None):
+        if self.glu:
+            h = self.net[0].hip(x2d, ln=ln)
+        else:
+            h = self.net[0][0].hip(x2d, act=ops.ACT_GELU, ln=ln)
         return self.net[2].hip(h, res=res)
 
     def forward(self, x):
@@ -177,16 +189,38 @@ class CrossAttention(nn.Module, L._Packed):
                                       L._dev16(self.to_v.weight)], 0).contiguous(),
             self.to_q.weight, self.to_k.weight, self.to_v.weight)
 
-    def hip(self, x, B, N, context=None, res=None):
-        """x: [B*N, query_dim] tokens (already normalised); context: None (self-attention) or a
-        ContextKV; res: residual added by the out-projection epilogue.  -> [B*N, query_dim]"""
+    def _pk_qkv_ln(self, norm):
+        return self._packed(("qkv_ln", id(norm)), lambda: L.fold_layernorm(self._pk_qkv(), None, norm.weight, norm.bias),
+                            self.to_q.weight, self.to_k.weight, self.to_v.weight, norm.weight, norm.bias)
+
+    def ln_foldable(self, x, N, context):
+        """can the LayerNorm in front of this attention be folded into its first projection?"""
+        Cd = self.inner_dim
+        if not ops.ln_fold_ok(x.shape[1]):
+            return False
+        if context is None:
+            return N % 8 == 0 and Cd % 160 == 0 and x.shape[1] % 64 == 0
+        return True
+
+    def hip(self, x, B, N, context=None, res=None, ln=None, stats_out=False):
+        """x: [B*N, query_dim] tokens (already normalised, or UN-normalised with ln = (LayerNorm, partial row sums of
+        x): the norm is then folded into the q | k | v / q projection); context: None (self-attention) or a ContextKV;
+        res: residual added by the out-projection epilogue.  -> [B*N, query_dim]; with stats_out also the partial
+        row sums of the result (for the next folded LayerNorm)."""
         Cd, H, D = self.inner_dim, self.heads, self.dim_head
+        if ln is not None and not self.ln_foldable(x, N, context):
+            raise ValueError("CrossAttention.hip: ln= passed for a shape the fold does not serve (see ln_foldable)")
         if context is None:
             if N % 8 == 0 and Cd % 160 == 0 and x.shape[1] % 64 == 0:
                 # one launch over the shared activation: q | k token-major, v transposed (ABI 3)
                 Np = N
                 vt = torch.empty((Cd, B * N), dtype=torch.float16, device=x.device)
-                qk = ops.gemm(x, self._pk_qkv(), out_t=vt, n_split=2 * Cd)
+                if ln is not None:
+                    norm, st = ln
+                    wq, cs, bq = self._pk_qkv_ln(norm)
+                    qk = ops.gemm(x, wq, bias=bq, out_t=vt, n_split=2 * Cd, ln=(st, cs, norm.eps))
+                else:
+                    qk = ops.gemm(x, self._pk_qkv(), out_t=vt, n_split=2 * Cd)
             elif N % 8 == 0:
                 Np = N
                 qk = ops.gemm(x, self._pk_qk())             # [M, 2*inner]: q | k
@@ -210,16 +244,21 @@ class CrossAttention(nn.Module, L._Packed):
                 out = torch.empty_like(res)
                 w_o, b_o = self.to_out[0]._pk()
                 ops.add_rowvec(res[:z * N], b_o, out=out[:z * N])
-                q = self.to_q.hip(x[z * N:])
+                q = self.to_q.hip(x[z * N:], ln=None if ln is None else (ln[0], ln[1][z * N:]))
                 o = ops.attention(q, k[z * context.Nkp:], vt[:, z * context.Nkp:], Bc, H, N, context.Nk, D,
                                   self.scale, ldq=Cd, ldk=Cd, ldvt=B * context.Nkp, q_bs=N * Cd,
                                   k_bs=context.Nkp * Cd, vt_bs=context.Nkp)
+                if stats_out:
+                    st_o = torch.empty((B * N, out.shape[1] // 160, 2), dtype=torch.float32, device=out.device)
+                    ops.ln_rowstats(out[:z * N], out=st_o[:z * N])     # the `x + bias` rows: stand-alone statistics
+                    self.to_out[0].hip(o, res=res[z * N:], out=out[z * N:], ln_out=st_o[z * N:])
+                    return out, st_o
                 self.to_out[0].hip(o, res=res[z * N:], out=out[z * N:])
                 return out
-            q = self.to_q.hip(x)
+            q = self.to_q.hip(x, ln=ln)
             o = ops.attention(q, k, vt, B, H, N, context.Nk, D, self.scale, ldq=Cd, ldk=Cd,
                               ldvt=B * context.Nkp, q_bs=N * Cd, k_bs=context.Nkp * Cd, vt_bs=context.Nkp)
-        return self.to_out[0].hip(o, res=res)
+        return self.to_out[0].hip(o, res=res, ln_out=True if stats_out else None)
 
     def forward(self, x, context=None, mask=None):
         assert mask is None, "mask is not supported on the HIP path"
@@ -244,13 +283,31 @@ class BasicTransformerBlock(nn.Module):
         self.norm3 = L.LayerNorm(dim)
         self.checkpoint = checkpoint  # inference only: never used
 
-    def hip_self(self, x, B, N, context):
-        """x + attn1(LN(x)): the part of the block that does not see the context (unless disable_self_attn)"""
-        return self.attn1.hip(self.norm1.hip(x), B, N, context if self.disable_self_attn else None, res=x)
+    def _fold(self, x, N):
+        """LayerNorm fold (every LayerNorm of the block feeds a Linear with nothing in between, attention.py:302-306):
+        the norm's affine map goes into the consumer GEMM's epilogue, its row statistics come from the epilogue of the
+        launch that produced x (ops.gemm(ln_out=...)) -- no LayerNorm launch, no extra pass over the tokens."""
+        ctx1 = None if not self.disable_self_attn else 1
+        return ops.ln_fold_ok(x.shape[1]) and self.attn1.ln_foldable(x, N, ctx1) and \
+            self.attn1.to_out[0].out_features % 160 == 0 and self.attn2.to_out[0].out_features % 160 == 0
 
-    def hip_rest(self, x, B, N, context):
-        """cross-attention and feed-forward residual branches"""
+    def hip_self(self, x, B, N, context, xs=None):
+        """x + attn1(LN(x)): the part of the block that does not see the context (unless disable_self_attn).
+        xs: partial row sums of x (ops.gemm(ln_out=...)) or None.  Returns y, or (y, partial row sums of y) when the
+        block folds its LayerNorms."""
+        c1 = context if self.disable_self_attn else None
+        if self._fold(x, N) and (c1 is None or getattr(c1, 'zero_lead', 0) == 0):
+            if xs is None:
+                xs = ops.ln_rowstats(x)
+            return self.attn1.hip(x, B, N, c1, res=x, ln=(self.norm1, xs), stats_out=True)
+        return self.attn1.hip(self.norm1.hip(x), B, N, c1, res=x)
+
+    def hip_rest(self, x, B, N, context, xs=None):
+        """cross-attention and feed-forward residual branches; xs: partial row sums of x when the block folds"""
         z = getattr(context, 'zero_lead', 0) if context is not None else 0
+        if xs is not None and context is not None and not isinstance(context, ContextMix):
+            x, xs = self.attn2.hip(x, B, N, context, res=x, ln=(self.norm2, xs), stats_out=True)
+            return self.ff.hip(x, res=x, ln=(self.norm3, xs))
         if 0 < z < B:   # LayerNorm only feeds to_q: skip it for the zero-context samples too
             xn = torch.empty_like(x)
             self.norm2.hip(x[z * N:], out=xn[z * N:])
@@ -259,8 +316,11 @@ class BasicTransformerBlock(nn.Module):
             x = self.attn2.hip(self.norm2.hip(x), B, N, context, res=x)
         return self.ff.hip(self.norm3.hip(x), res=x)
 
-    def hip(self, x, B, N, context):
-        return self.hip_rest(self.hip_self(x, B, N, context), B, N, context)
+    def hip(self, x, B, N, context, xs=None):
+        y = self.hip_self(x, B, N, context, xs)
+        if isinstance(y, tuple):
+            return self.hip_rest(y[0], B, N, context, y[1])
+        return self.hip_rest(y, B, N, context)
 
     def forward(self, x, context=None):
         B, N, _ = x.shape
@@ -303,17 +363,30 @@ class SpatialTransformer(nn.Module):
         is doubled right before the context enters.  Returns the full (doubled) batch."""
         B, H, W_, Cc = x.shape
         N = H * W_
-        h = self.proj_in.hip(self.norm.hip(x)).view(B * N, -1)
         blocks = list(self.transformer_blocks)
+        hs = None
+        inner = self.proj_in.out_features if self.use_linear else self.proj_in.out_channels
+        if ops.ln_fold_ok(inner) and inner % 160 == 0:
+            # proj_in stores the tokens the first LayerNorm reads: it emits their partial row sums with them
+            h, hs = self.proj_in.hip(self.norm.hip(x), ln_out=True)
+            h = h.view(B * N, -1)
+        else:
+            h = self.proj_in.hip(self.norm.hip(x)).view(B * N, -1)
         if cfg_pair:
             if blocks[0].disable_self_attn:
                 raise ValueError("cfg_pair needs a context-free self-attention in the first block")
-            h = blocks[0].hip_self(h, B, N, context)
+            h = blocks[0].hip_self(h, B, N, context, hs)
+            hs = None
+            if isinstance(h, tuple):
+                h, hs = h
+                hs = torch.cat([hs, hs])
             h, x, B = torch.cat([h, h]), torch.cat([x, x]), 2 * B      # the only two copies (21 MB each at 64^2)
-            h = blocks[0].hip_rest(h, B, N, context)
+            h = blocks[0].hip_rest(h, B, N, context, hs)
+            hs = None
             blocks = blocks[1:]
         for blk in blocks:
-            h = blk.hip(h, B, N, context)
+            h = blk.hip(h, B, N, context, hs)
+            hs = None
         return self.proj_out.hip(h.view(B, H, W_, -1), res=x)
 
     def forward(self, x, context=None):
