@@ -32,7 +32,7 @@
 
 #include "pfd_common.h"
 
-int pfd_ln_rowstats_launch(const half_t* x, long ldx, int M, int C, float* out, hipStream_t s);   // norm.hip
+int pfd_ln_rowstats_launch(const half_t* x, long ldx, int M, int C, float* out, hipStream_t s, bool prof);   // norm.hip
 
 namespace {
 
@@ -1476,9 +1476,12 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const G160Params p) 
 // 18.3 -> 17.1, 8192 x 640 x 640 17.1 -> 16.3) and so do the loader-wave implicit-GEMM convolutions (upsample convs
 // 191.9 -> 168.6, 176.0 -> 164.4 us); the split-K convolutions of the 8^2 level lose (512 x 1280 x 23040: 52 -> 66 us:
 // eight rotated streams per XCD instead of one) and the patch kernel is 2-3 % slower, so those keep the plain walk.
-// PFD_KROT: 0 = never, 1 = the selection above (default), 2 = every kernel.
+// End to end the selection is worth nothing measurable (bench.py, same box: 559.0 ms per batch without, 559.2 / 560.8 with),
+// and a rotated walk makes a row's fp32 summation order depend on WHERE in the batch the row sits -- the zero-context
+// shortcut (same rows, half the batch) then stops being bit-identical to the full computation.  So the default is OFF;
+// PFD_KROT: 0 = never (default), 1 = the selection above, 2 = every kernel.
 inline int krot_mode() {
-  static const int m = getenv("PFD_KROT") ? atoi(getenv("PFD_KROT")) : 1;
+  static const int m = getenv("PFD_KROT") ? atoi(getenv("PFD_KROT")) : 0;
   return m;
 }
 // Ping-pong consumer groups (template flag PP of the loader-wave kernels) measured no better than lock-step consumers:
@@ -1530,7 +1533,7 @@ int launch160(G160Params& p, int bucket, hipStream_t s) {
     if (g > 2048) g = 2048;
     hipLaunchKernelGGL(splitk_reduce_kernel, dim3(g), dim3(256), 0, s, p);
     // a split-K output that feeds a folded LayerNorm: its row statistics by the stand-alone kernel
-    if (p.ln_out) pfd_ln_rowstats_launch(p.C, p.ldc, p.M, p.N, reinterpret_cast<float*>(p.ln_out), s);
+    if (p.ln_out) pfd_ln_rowstats_launch(p.C, p.ldc, p.M, p.N, reinterpret_cast<float*>(p.ln_out), s, false);   // inside this launch's event pair
   }
   if (prof) pfd_prof_end(s);
   return pfd_check_launch("pfd_gemm_f16(wide)");
@@ -1565,7 +1568,7 @@ int launch160ws(G160Params& p, int bucket, hipStream_t s, bool pp) {
     if (g > 2048) g = 2048;
     hipLaunchKernelGGL(splitk_reduce_kernel, dim3(g), dim3(256), 0, s, p);
     // a split-K output that feeds a folded LayerNorm: its row statistics by the stand-alone kernel
-    if (p.ln_out) pfd_ln_rowstats_launch(p.C, p.ldc, p.M, p.N, reinterpret_cast<float*>(p.ln_out), s);
+    if (p.ln_out) pfd_ln_rowstats_launch(p.C, p.ldc, p.M, p.N, reinterpret_cast<float*>(p.ln_out), s, false);   // inside this launch's event pair
   }
   if (prof) pfd_prof_end(s);
   return pfd_check_launch("pfd_gemm_f16(wave-specialised)");
@@ -1596,7 +1599,7 @@ int launch_patch(G160Params& p, hipStream_t s, int ws) {
     if (g > 2048) g = 2048;
     hipLaunchKernelGGL(splitk_reduce_kernel, dim3(g), dim3(256), 0, s, p);
     // a split-K output that feeds a folded LayerNorm: its row statistics by the stand-alone kernel
-    if (p.ln_out) pfd_ln_rowstats_launch(p.C, p.ldc, p.M, p.N, reinterpret_cast<float*>(p.ln_out), s);
+    if (p.ln_out) pfd_ln_rowstats_launch(p.C, p.ldc, p.M, p.N, reinterpret_cast<float*>(p.ln_out), s, false);   // inside this launch's event pair
   }
   if (prof) pfd_prof_end(s);
   return pfd_check_launch("pfd_gemm_f16(conv3x3 patch)");
@@ -1670,11 +1673,10 @@ int pfd_gemm160_try(const PfdGemmDesc* d, int variant, int splits, hipStream_t s
   // 3x3 / s1 / p1 convolution on a 16-, 32- or 64-wide image: the patch kernel (variant 0 or 99)
   if (bn == 160 && (variant == 0 || variant == 99 || variant == 98 || variant == 97) && p.ksize == 3 && p.stride == 1 && p.pad == 1 && !p.ups &&
       (p.Wd == 16 || p.Wd == 32 || p.Wd == 64) && p.Ho == p.H && p.Wo == p.Wd && p.H % (256 / p.Wd) == 0 &&
-      p.M % 256 == 0 && p.act != PFD_ACT_GEGLU &&
-      // round 3: 64 ... 128 patch tiles with <= 5 channel blocks (the 320-channel convolutions of the batch-4 CFG prefix,
-      // 320 -> 640 at 32^2) leave half the CUs idle with no K range worth splitting: the 8-wave 128-row ring serves
-      // them better (16384 x 320 x 2880: 50 -> 43 us, 8192 x 640 x 2880: 50 -> 42; profiles/r03_tile_variants_replay.log)
-      !(variant == 0 && r3tiles_on() && !p.gn_table && tiles(256) >= 64 && tiles(256) <= 128 && p.Cin / BK <= 5)) {
+      p.M % 256 == 0 && p.act != PFD_ACT_GEGLU) {
+    // (The 8-wave 128-row ring beats the patch kernel on its smallest problems -- 16384 x 320 x 2880: 50 -> 43 us,
+    //  profiles/r03_tile_variants_replay.log -- but the GroupNorm-prologue form lives in the patch kernel only and the two
+    //  must stay bit-identical, for 1 ms per batch: not taken.)
     const int ncb = p.Cin / BK;
     if (splits == 0) {
       splits = 1;

@@ -702,12 +702,14 @@ __global__ __launch_bounds__(256) void ln_rowstats_kernel(const half_t* __restri
   if (k == 0 && grp < ngrp) out[grp] = make_float2(s, q);
 }
 
-int pfd_ln_rowstats_launch(const half_t* x, long ldx, int M, int C, float* out, hipStream_t s) {
+int pfd_ln_rowstats_launch(const half_t* x, long ldx, int M, int C, float* out, hipStream_t s, bool prof) {
   const int P = C / 160;
   const long ngrp = (long)M * P;
-  PfdProfScope prof_scope(11, 0.0, 2.0 * M * C, s);
+  const bool on = prof && pfd_prof_on();   // (event pairs do not nest: the GEMM launchers call this inside their own)
+  if (on) pfd_prof_begin(11, 0.0, 2.0 * M * C, s);
   hipLaunchKernelGGL(ln_rowstats_kernel, dim3((unsigned)((ngrp + 63) / 64)), dim3(256), 0, s, x, ldx, M, P,
                      reinterpret_cast<float2*>(out));
+  if (on) pfd_prof_end(s);
   return pfd_check_launch("pfd_ln_rowstats_f16");
 }
 
@@ -715,7 +717,7 @@ extern "C" int pfd_ln_rowstats_f16(const void* x, int64_t ldx, int32_t M, int32_
   if (!x || !out || M <= 0 || C <= 0) return PFD_EINVAL;
   if ((C % 160) || C > 1280) return PFD_ESHAPE;
   if ((ldx & 7) || (reinterpret_cast<uintptr_t>(x) & 15) || (reinterpret_cast<uintptr_t>(out) & 7)) return PFD_EINVAL;
-  return pfd_ln_rowstats_launch((const half_t*)x, (long)ldx, M, C, (float*)out, (hipStream_t)stream);
+  return pfd_ln_rowstats_launch((const half_t*)x, (long)ldx, M, C, (float*)out, (hipStream_t)stream, true);
 }
 
 extern "C" int pfd_softmax_rows_f16(const void* x, int64_t ldx, void* y, int64_t ldy, int32_t R, int32_t N,
