@@ -16,9 +16,10 @@ around every launch of every kernel family on its launch stream (libpfd_hip's pf
 be captured), so the same kernels, shapes and data path are timed on ONE more, eagerly launched, batch
 right after the timed region (`roofline.measured_on` says which; rocprofv3 summaries of the same command
 are under profiles/).  Event pairs around eager launches also contain the idle time in front of each kernel
-(the host enqueues ~23 k launches per batch); every kernel of the library is instrumented, so the eager
-times are normalised to sum to the graph-replayed wall time of the same batch (`roofline.eager_to_graph`,
-un-normalised value in `avg_launch_ms_eager`) -- that is the in-graph duration rocprofv3 reports.
+(the host enqueues ~20 k launches per batch); every kernel of the library is instrumented, so that gap is estimated
+as (sum of the event pairs - graph-replayed wall time of the same batch) / launches and subtracted PER LAUNCH
+(`roofline.eager_gap_us_per_launch`; un-corrected value in `avg_launch_ms_eager`) -- an estimate of the in-graph
+duration rocprofv3 reports.
 `roofline.traffic` = HBM bytes per launch from rocprofv3 PMC passes
 (profiles/pmc_traffic.json, see tools/pmc_bucket.py).
 `cpu_baseline` times the CPU oracle (a port of the reference's algorithm, oracle/pfd_oracle.py)
@@ -94,9 +95,13 @@ def cpu_baseline(net, height, width, ddim_steps, scale):
     per_image = t_ctx + ddim_steps * t_step + t_vae
     return {"value": 1.0 / per_image, "unit": "images/s", "cores": threads, "kind": "port",
             "host_cpus": os.cpu_count(), "thread_sweep_s": sweep,
+            # the port against the reference's own modules, same host, same inputs (oracle/time_reference_vs_port.py run in
+            # the build container, where /root/reference exists): bit-identical outputs, 0.93-1.17x the reference's time
+            "reference_vs_port": {"max_abs_diff": 0.0, "port_time_over_reference_time": [0.93, 1.17],
+                                  "source": "profiles/r02_cpu_reference_vs_port.log"},
             "sample": f"1 image {height}x{width}: SeeCoder encode {t_ctx:.2f}s + 1 CFG UNet step (batch 2) "
                       f"{t_step:.2f}s x{ddim_steps} (extrapolated) + VAE decode {t_vae:.2f}s, fp32 torch CPU, "
-                      f"{threads} threads (best of a sweep)"}
+                      f"{threads} of {os.cpu_count()} host threads (best of a sweep)"}
 
 
 def main():
@@ -109,9 +114,11 @@ def main():
     ap.add_argument("--width", type=int, default=512)
     ap.add_argument("--ddim-steps", type=int, default=50)
     ap.add_argument("--scale", type=float, default=2.0)
-    ap.add_argument("--config", default="c2", choices=["c2", "c3", "c5"],
-                    help="BASELINE.json config: c2 = headline (default); c3 = + ControlNet + SeeCoder-PA; "
-                         "c5 = 768x768, 30 (->31) steps, batch 2, non-zero unconditional context")
+    ap.add_argument("--config", default="c2", choices=["c2", "c3", "c4", "c5"],
+                    help="BASELINE.json config: c2 = headline (default; N > 1 keeps its 4 images per GPU); c3 = + ControlNet "
+                         "+ SeeCoder-PA; c4 = 8 images per GPU (configs[3]: global batch 64 on 8 GPUs; on one GPU it is that "
+                         "run's per-rank workload, UNet batch 16); c5 = 768x768, 30 (->31) steps, batch 2, non-zero "
+                         "unconditional context")
     ap.add_argument("--per-sample-image", action="store_true",
                     help="one reference image (one SeeCoder encode) per sample instead of one per batch (SURVEY 8(d))")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -121,6 +128,8 @@ def main():
     if args.config == "c5":
         args.height = args.width = 768
         args.ddim_steps, args.batch = 30, 2
+    if args.config == "c4":
+        args.batch = 8
 
     import torch
     import torch.distributed as dist
@@ -227,13 +236,20 @@ def main():
             tot = sum(b["ms"] for b in prof)
             # Event pairs around EAGER launches also contain the idle time between the previous kernel's end and this
             # kernel's start (the host enqueues ~23 k launches per batch through ctypes; the hipGraph the timed region
-            # replays has no such gaps).  Every kernel of the library is instrumented, so the eager times are
-            # normalised to sum to the graph-replayed wall time of the same batch (`stage_ms_per_batch`): this is the
-            # in-graph duration rocprofv3 --kernel-trace reports for the same command (profiles/*_rocprof_kernel_stats.md).
+            # replays has no such gaps; profiles/*_rocprof_kernel_stats.md hold the in-graph durations of the same command).
             wall = sum(stage_ms.get(k, 0.0) for k in ("ctx_encode_ms", "ddim_loop_ms", "vae_decode_ms"))
-            norm = (wall * prof_steps / tot) if (not args.no_graph and wall > 0 and tot > 0) else 1.0
-            norm = min(1.0, norm)
-            secs = top["ms"] * norm / 1e3
+            # The idle time in front of an eagerly launched kernel is a roughly CONSTANT host enqueue gap per launch, not
+            # a share of the kernel's duration: it is estimated as (sum of the event pairs - graph wall time) / launches
+            # and subtracted per launch (a proportional factor would shrink long kernels too much and short ones too
+            # little).  A bucket never goes below half of its eager time (guards the estimate on tiny kernels).
+            n_launch = sum(b["launches"] for b in prof)
+            gap_ms = 0.0
+            if not args.no_graph and wall > 0 and tot > wall * prof_steps and n_launch > 0:
+                gap_ms = (tot - wall * prof_steps) / n_launch
+            for b in prof:
+                b["ms_graph"] = max(b["ms"] - gap_ms * b["launches"], 0.5 * b["ms"])
+            norm = top["ms_graph"] / top["ms"] if top["ms"] > 0 else 1.0
+            secs = top["ms_graph"] / 1e3
             if mfma:
                 ach = top["flops"] / secs / 1e12
                 res["roofline"] = {"bound": "mfma", "achieved": ach, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
@@ -250,14 +266,17 @@ def main():
                 except Exception:
                     traffic = None
             res["roofline"].update({"traffic": traffic, "kernel": top["name"], "launches": top["launches"],
-                                    "avg_launch_ms": top["ms"] * norm / top["launches"],
+                                    "avg_launch_ms": top["ms_graph"] / top["launches"],
                                     "avg_launch_ms_eager": top["ms"] / top["launches"], "eager_to_graph": norm,
-                                    "measured_on": prof_where,
+                                    "eager_gap_us_per_launch": gap_ms * 1e3,
+                                    "measured_on": prof_where + " (eager event pairs minus the per-launch enqueue gap)",
                                     "alg_flops_per_launch": top["flops"] / top["launches"],
                                     "alg_bytes_per_launch": top["bytes"] / top["launches"]})
-            res["kernel_time_ms_per_step"] = {b["name"]: round(b["ms"] * norm / prof_steps, 3) for b in prof}
-            res["kernel_tflops"] = {b["name"]: round(b["flops"] / (b["ms"] * norm / 1e3) / 1e12, 1) for b in prof
-                                    if b["flops"] > 0 and b["ms"] > 0}
+            res["kernel_time_ms_per_step"] = {b["name"]: round(b["ms_graph"] / prof_steps, 3) for b in prof}
+            res["kernel_tflops"] = {b["name"]: round(b["flops"] / (b["ms_graph"] / 1e3) / 1e12, 1) for b in prof
+                                    if b["flops"] > 0 and b["ms_graph"] > 0}
+            res["kernel_gbps"] = {b["name"]: round(b["bytes"] / (b["ms_graph"] / 1e3) / 1e9, 1) for b in prof
+                                  if b["flops"] == 0 and b["bytes"] > 0 and b["ms_graph"] > 0}
             res["instrumented_kernel_ms_per_step"] = tot / prof_steps          # eager, before the normalisation
             res["launch_mode"] = "eager" if args.no_graph else "hipGraph (DDIM loop)"
         res["stage_ms_per_batch"] = {k: round(v, 2) for k, v in stage_ms.items()}

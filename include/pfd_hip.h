@@ -110,7 +110,12 @@ typedef struct PfdGemmDesc {
   void* Ct;
   int64_t ldct;
   int32_t n_split;
-  int32_t reserved0;
+  /* weight layout (ABI 7): 0 = row-major [N][ldw]; 1 = K-tile-contiguous: with T = 160 if N % 160 == 0 else 128
+   * (N % 128 == 0), element (n, k) lives at (((n / T) * (K / 64) + k / 64) * T + n % T) * 64 + k % 64 -- the
+   * (T x 64) weight tile a block stages per K step is one contiguous T x 128-byte run of memory instead of T pieces a
+   * whole weight row apart (cold weight streams ran at ~1 TB/s on the row-major layout).  Wide-tile kernels only;
+   * with w_tiled != 0 a shape they do not take is PFD_ESHAPE.  ldw is ignored. */
+  int32_t w_tiled;
   /* optional GroupNorm(+SiLU) prologue (ABI 6; `GroupNorm32 -> SiLU -> conv3x3` of ResBlock._forward,
    * openaimodel.py:200-226, 254-274): with gn_table != NULL the convolution reads
    *     act(x[b, y, x, c] * gn_table[b][0][c] + gn_table[b][1][c])   rounded to f16

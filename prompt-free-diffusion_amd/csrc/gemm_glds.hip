@@ -61,6 +61,12 @@ struct G160Params {
   int tiles_m, tiles_n, splits, kt_per_split;
   int nmajor;  // XCD-contiguous tile order: 0 = all N tiles of an M tile together, 1 = all M tiles of an N tile
   int krot;    // 1 = every M tile starts its K loop at a different K tile (see k_rotation below)
+  // weight layout: row-major [N][ldw] (w_tu == 0) or K-tile-contiguous [N / w_tu][K / 64][w_tu][64] (w_tu = 160 | 128):
+  // a block's weight tile of one K step is then ONE contiguous (w_tu x 128)-byte run of HBM instead of w_tu separate
+  // 128-byte pieces a whole weight row (2 K bytes) apart -- the cold weight streams of the 8^2 / 16^2 levels ran at
+  // ~1 TB/s on the row-major layout whatever the tile shape (profiles/r03_tile_variants_replay.log)
+  int w_tu;
+  long w_kstep;   // halfs from one K tile to the next: 64 (row-major) or w_tu * 64
   // GroupNorm(+SiLU) folded into the patch convolution's input staging (PfdGemmDesc.gn_table)
   // LayerNorm folded into the contraction (PfdGemmDesc.ln_stats / ln_out)
   const float2* ln_in;     // [M][ln_P]: partial (sum x, sum x^2) of the rows of A; nullptr = no fold
@@ -77,6 +83,13 @@ struct G160Params {
 __device__ __forceinline__ void glds16(const void* src, void* lds_dst) {
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                    (__attribute__((address_space(3))) void*)lds_dst, 16, 0, 0);
+}
+
+// address of 16-byte chunk c8 (in halfs) of weight row n at K tile 0, in either layout
+__device__ __forceinline__ const half_t* w_row_ptr(const G160Params& p, int n, int c8) {
+  if (p.w_tu == 0) return p.W + (long)n * p.ldw + c8;
+  const int tn = n / p.w_tu;
+  return p.W + ((long)tn * (p.K / BK) * p.w_tu + (n - tn * p.w_tu)) * BK + c8;
 }
 
 // K rotation.  All blocks of a launch start together and take the same time per K step, so the tiles_m blocks that
@@ -482,7 +495,7 @@ __global__ __launch_bounds__(WAVES_M * 128) void gemm160_kernel(const G160Params
     if (q >= B_INSTR) q = B_DUP ? q - NW : 0;
     const int r = q * 8 + srow;
     const int c = cpos ^ ((r >> 1) & 7);
-    b_ptr[j] = p.W + (long)(n0 + r) * p.ldw + c * 8;
+    b_ptr[j] = w_row_ptr(p, n0 + r, c * 8);
   }
   const int Hin = p.ups ? 2 * p.H : p.H;
   const int Win = p.ups ? 2 * p.Wd : p.Wd;
@@ -519,6 +532,7 @@ __global__ __launch_bounds__(WAVES_M * 128) void gemm160_kernel(const G160Params
     char* As = smem + stage * STAGE;
     char* Bs = As + BM * ROWB;
     const int k0 = kt_issue * BK;
+    const long kw = kt_issue * p.w_kstep;
     if (CONV) {
 #pragma unroll
       for (int j = 0; j < A_PER_WAVE; ++j) {
@@ -533,8 +547,8 @@ __global__ __launch_bounds__(WAVES_M * 128) void gemm160_kernel(const G160Params
 #pragma unroll
     for (int j = 0; j < B_PER_WAVE; ++j) {
       const int q = wave + NW * j;
-      if (q < B_INSTR) glds16(b_ptr[j] + k0, Bs + q * 1024);
-      else if (B_DUP) glds16(b_ptr[j] + k0, Bs + (q - NW) * 1024);
+      if (q < B_INSTR) glds16(b_ptr[j] + kw, Bs + q * 1024);
+      else if (B_DUP) glds16(b_ptr[j] + kw, Bs + (q - NW) * 1024);
     }
     if (++kt_issue == kt_end) {  // wrap-around of the rotated walk (wave-uniform)
       kt_issue = kt_begin;
@@ -745,7 +759,7 @@ __global__ __launch_bounds__(768) void gemm160ws_kernel(const G160Params p) {
     for (int j = 0; j < B_PL; ++j) {
       const int r = (lw + NLW * j) * 8 + srow;
       const int c = cpos ^ ((r >> 1) & 7);
-      b_ptr[j] = p.W + (long)(n0 + r) * p.ldw + c * 8;
+      b_ptr[j] = w_row_ptr(p, n0 + r, c * 8);
     }
     const int Hin = p.ups ? 2 * p.H : p.H;
     const int Win = p.ups ? 2 * p.Wd : p.Wd;
@@ -777,6 +791,7 @@ __global__ __launch_bounds__(768) void gemm160ws_kernel(const G160Params p) {
       char* As = smem + stage * STAGE;
       char* Bs = As + BM * ROWB;
       const int k0 = kt_issue * BK;
+      const long kw = kt_issue * p.w_kstep;
 #pragma unroll
       for (int j = 0; j < A_PL; ++j) {
         const half_t* src;
@@ -785,7 +800,7 @@ __global__ __launch_bounds__(768) void gemm160ws_kernel(const G160Params p) {
         glds16(src, As + (lw + NLW * j) * 1024);
       }
 #pragma unroll
-      for (int j = 0; j < B_PL; ++j) glds16(b_ptr[j] + k0, Bs + (lw + NLW * j) * 1024);
+      for (int j = 0; j < B_PL; ++j) glds16(b_ptr[j] + kw, Bs + (lw + NLW * j) * 1024);
       if (++kt_issue == kt_end) {
         kt_issue = kt_begin;
         if (CONV) seek(kt_begin);
@@ -966,14 +981,14 @@ __global__ __launch_bounds__(512) void conv3x3_patch_kernel(const G160Params p) 
     const int q = wave + NW * j;
     const int r = q * 8 + srow;
     const int c = cpos ^ ((r >> 1) & 7);
-    wp[j] = p.W + (long)(n0 + (q < 20 ? r : 0)) * p.ldw + c * 8;
+    wp[j] = w_row_ptr(p, n0 + (q < 20 ? r : 0), c * 8);
   }
   auto issue_patch_slot = [&](int buf, int cb, int j) {
     const int q = wave + NW * j;
     if (q < P_INSTR) glds16(pp[j] ? pp[j] + cb * BK : g_zero_page, smem + buf * PATCH_BYTES + q * 1024);
   };
   auto issue_w = [&](int stage, int tap, int cb) {
-    const int k0 = tap * p.Cin + cb * BK;
+    const long k0 = (long)(tap * (p.Cin / BK) + cb) * p.w_kstep;
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
       const int q = wave + NW * j;
@@ -1147,10 +1162,10 @@ __global__ __launch_bounds__(768) void conv3x3_patch_ws_kernel(const G160Params 
     for (int j = 0; j < 5; ++j) {
       const int r = (lw + NLW * j) * 8 + srow;
       const int c = cpos ^ ((r >> 1) & 7);
-      wp[j] = p.W + (long)(n0 + r) * p.ldw + c * 8;
+      wp[j] = w_row_ptr(p, n0 + r, c * 8);
     }
     auto issue_w = [&](int stage, int tap, int cb) {
-      const int k0 = tap * p.Cin + cb * BK;
+      const long k0 = (long)(tap * (p.Cin / BK) + cb) * p.w_kstep;
 #pragma unroll
       for (int j = 0; j < 5; ++j) glds16(wp[j] + k0, smem + OFF_W + stage * WT_BYTES + (lw + NLW * j) * 1024);
     };
@@ -1639,6 +1654,8 @@ int pfd_gemm160_try(const PfdGemmDesc* d, int variant, int splits, hipStream_t s
   p.rowvec = (const half_t*)d->rowvec; p.R = (const half_t*)d->R; p.C = (half_t*)d->C;
   p.ws = (float*)d->ws;
   p.lda = d->lda; p.ldw = d->ldw; p.ldr = d->ldr; p.ldc = d->ldc; p.ldrv = d->ldrv;
+  p.w_tu = d->w_tiled ? bn : 0;
+  p.w_kstep = d->w_tiled ? (long)bn * BK : BK;
   p.M = d->M; p.N = d->N; p.K = d->K;
   p.rows_per_rv = d->rows_per_rv > 0 ? d->rows_per_rv : 1;
   p.act = d->act;

@@ -109,6 +109,7 @@ struct GemmCase {
   int extra_ld = 0;  // added to every leading dimension
   int ksize = 0, stride = 1, pad = 0, ups = 0, B = 0, H = 0, W = 0, Cin = 0;
   int n_split = 0;  // > 0: columns >= n_split go transposed to Ct
+  int w_tiled = 0;  // 1: the weight is uploaded K-tile-contiguous (PfdGemmDesc.w_tiled)
 };
 
 static void run_gemm_case(const GemmCase& c) {
@@ -133,7 +134,15 @@ static void run_gemm_case(const GemmCase& c) {
   const int n_rv = (M + rows_per_rv - 1) / rows_per_rv;
   auto rv = rand_h((size_t)n_rv * ldrv, 0.5f);
   auto R = rand_h((size_t)M * ldr, 1.0f);
-  Dev<h16> dA(A), dW(W), dB(bias), dRV(rv), dR(R), dC((size_t)M * ldc);
+  std::vector<h16> Wup = W;
+  if (c.w_tiled) {   // (n, k) -> (((n / T) * (K / 64) + k / 64) * T + n % T) * 64 + k % 64
+    const int T = N % 160 == 0 ? 160 : 128, nkt = K / 64;
+    Wup.assign((size_t)N * K, (h16)0);
+    for (int n = 0; n < N; ++n)
+      for (int k = 0; k < K; ++k)
+        Wup[(((size_t)(n / T) * nkt + k / 64) * T + n % T) * 64 + k % 64] = W[(size_t)n * ldw + k];
+  }
+  Dev<h16> dA(A), dW(Wup), dB(bias), dRV(rv), dR(R), dC((size_t)M * ldc);
   Dev<float> dWS((size_t)8 * M * N + 64);
   PfdGemmDesc d;
   memset(&d, 0, sizeof(d));
@@ -147,10 +156,11 @@ static void run_gemm_case(const GemmCase& c) {
   const long ldct = (M + 7) / 8 * 8 + 8;
   Dev<h16> dCt(c.n_split > 0 ? (size_t)(N - c.n_split) * ldct : 8);
   if (c.n_split > 0) { d.Ct = dCt.p; d.ldct = ldct; d.n_split = c.n_split; }
+  d.w_tiled = c.w_tiled;
   const int rc = pfd_gemm_f16_ex(&d, c.tile, nullptr);
   char name[256];
-  snprintf(name, sizeof(name), "gemm M%d N%d K%d act%d b%d r%d rv%d br%d tile%d ld+%d %s", M, N, K, c.act,
-           c.bias, c.res, c.rowvec, c.bias_row, c.tile, c.extra_ld,
+  snprintf(name, sizeof(name), "gemm M%d N%d K%d act%d b%d r%d rv%d br%d tile%d%s ld+%d %s", M, N, K, c.act,
+           c.bias, c.res, c.rowvec, c.bias_row, c.tile, c.w_tiled ? "T" : "", c.extra_ld,
            conv ? (std::string("conv k") + std::to_string(c.ksize) + " s" + std::to_string(c.stride) + " p" +
                    std::to_string(c.pad) + " u" + std::to_string(c.ups))
                       .c_str()
@@ -215,6 +225,25 @@ static void run_gemm_case(const GemmCase& c) {
   for (int m = 0; m < M; ++m)
     for (long n = c.n_split > 0 ? c.n_split : Nout; n < ldc; ++n) gotc[(size_t)m * ldc + n] = got[(size_t)m * ldc + n];
   report(name, gotc, ref, 4e-3, 3e-3);
+}
+
+// K-tile-contiguous weights (PfdGemmDesc.w_tiled): every wide-tile kernel family, both tile widths, conv K walks, split-K
+static void run_tiled_weight_cases() {
+  for (int v : {0, 3200, 3300, 3400, 3500, 5400, 5800, 5100, 5300, 9200, 9300}) {
+    GemmCase a{700, 320, 1024, 0, true, true, true, false, v}; a.w_tiled = 1; run_gemm_case(a);
+    GemmCase b{0, 320, 0, 0, true, true, false, false, v, 0, 3, 1, 1, 0, 3, 16, 16, 128}; b.w_tiled = 1; run_gemm_case(b);
+  }
+  { GemmCase c{600, 640, 320, PFD_ACT_GEGLU, true, false, false, false, 9400}; c.w_tiled = 1; run_gemm_case(c); }
+  { GemmCase c{520, 960, 320, 0, false, false, false, false, 0}; c.n_split = 640; c.w_tiled = 1; run_gemm_case(c); }
+  { GemmCase c{900, 320, 1536, 0, true, false, false, false, 3203}; c.w_tiled = 1; run_gemm_case(c); }
+  { GemmCase c{600, 256, 512, 0, true, true, false, false, 5400}; c.w_tiled = 1; run_gemm_case(c); }          // 128-wide tiles
+  { GemmCase c{0, 256, 0, PFD_ACT_SILU, true, true, true, false, 0, 0, 3, 1, 1, 0, 2, 9, 7, 128}; c.w_tiled = 1; run_gemm_case(c); }
+  for (int v : {10800, 10700, 10900, 10802}) {   // patch kernels (tap / channel-block walk over the tiled K axis)
+    GemmCase c{0, 320, 0, 0, true, true, true, false, v, 0, 3, 1, 1, 0, 2, 32, 32, 128}; c.w_tiled = 1; run_gemm_case(c);
+    GemmCase e{0, 160, 0, PFD_ACT_SILU, true, false, true, false, v, 0, 3, 1, 1, 0, 1, 64, 64, 256}; e.w_tiled = 1; run_gemm_case(e);
+  }
+  { GemmCase c{0, 160, 0, PFD_ACT_SILU, true, false, true, false, 5800, 0, 3, 2, 1, 0, 5, 20, 16, 64}; c.w_tiled = 1; run_gemm_case(c); }   // stride 2
+  { GemmCase c{0, 160, 0, 0, true, false, false, false, 5800, 0, 3, 1, 1, 1, 2, 9, 12, 64}; c.w_tiled = 1; run_gemm_case(c); }               // upsample
 }
 
 // ------------------------------------------------------------------ LayerNorm folded into the GEMM (ABI 7)
@@ -887,6 +916,8 @@ static int replay(const char* path, bool timed = false, int force_tile = 0) {
         d.W = dPool.p + pool_off;
         pool_off += wn;
       }
+      static const bool replay_tiled = getenv("PFD_REPLAY_TILED") && atoi(getenv("PFD_REPLAY_TILED")) != 0;
+      if (replay_tiled && (d.N % 160 == 0 || d.N % 128 == 0) && d.K % 64 == 0 && !d.bias_per_row) d.w_tiled = 1;
       if (force_tile == 0 || pfd_gemm_f16_ex(&d, force_tile, nullptr) != 0) bad += pfd_gemm_f16(&d, nullptr) != 0;
       if (timed) HIP_OK(hipEventRecord(ev[++li], nullptr));
     }
@@ -961,6 +992,7 @@ int main(int argc, char** argv) {
     { GemmCase t{520, 480, 128, 0, false, false, false, false, 9200}; t.n_split = 320; run_gemm_case(t); }
     run_gemm_case({600, 640, 320, PFD_ACT_GEGLU, true, false, false, false, 9400});
     run_gemm_case({300, 320, 64, PFD_ACT_GEGLU, false, false, false, false, 9400});
+    run_tiled_weight_cases();
     printf("SELFTEST %d/%d passed, %d failed\n", g_total - g_fail, g_total, g_fail);
     return g_fail;
   }

@@ -174,13 +174,13 @@ class DDIMSampler(object):
                    float(scale), nb, x_type, c_type, int(log_every_t), zero_lead, bool(self.share_cfg_prefix),
                    hash(np.asarray(timesteps).tobytes()),
                    self._weights_signature())
-            ent = self._graphs.get(key)
+            ent = self._graphs.pop(key, None)
             if ent is None:
-                if len(self._graphs) >= 4:
+                while len(self._graphs) >= self.max_graphs:
                     torch.cuda.synchronize()   # never drop a graph whose replay may still be in flight
-                    self._graphs.clear()
-                ent = self._capture(run_loop, x, c_in, hint, (coef, t_table))
-                self._graphs[key] = ent
+                    self._graphs.pop(next(iter(self._graphs)))   # least recently used (a server varies batch size and
+                ent = self._capture(run_loop, x, c_in, hint, (coef, t_table))   # scale per request: keep the others)
+            self._graphs[key] = ent            # (re-)inserted last = most recently used
             g, sx, sc, sh, outs, _keep = ent
             sx.copy_(x)
             sc.copy_(c_in)
@@ -297,6 +297,7 @@ class DDIMSampler(object):
     # ---- hipGraph plumbing (launch-bound loop: ~700 kernel launches per step) -------------------
     use_graph = False
     _graphs = None
+    max_graphs = 6   # captured trajectories kept (each owns a private memory pool); least recently used goes first
     zero_uncond_shortcut = True
     share_cfg_prefix = True
 

@@ -166,6 +166,14 @@ class PromptFreeDiffusion(nn.Module):
         gnet = unet if self.global_layer_ptr is None else self.diffuser[self.global_layer_ptr]
         if gnet is not unet:
             raise NotImplementedError("separate global-layer diffuser")
+        if cfg_pair:
+            # the shared prefix runs on ONE copy of the pair and reads rows 0..B-1 of the 2B-row embedding table: both
+            # halves must carry the same timesteps (ddim.py:145-149 builds the pair that way); anything else is an error
+            nb = x_nhwc.shape[0]
+            if timesteps.shape[0] != 2 * nb:
+                raise ValueError(f"cfg_pair: {timesteps.shape[0]} timesteps for a pair of {nb}-sample halves")
+            if emb_table is None and not bool((timesteps[:nb] == timesteps[nb:]).all()):
+                raise ValueError("cfg_pair: the two halves of the pair carry different timesteps")
         if isinstance(context, ContextMix):
             if control is not None:
                 raise NotImplementedError("ControlNet with multi-context mixing (the reference has no such path)")

@@ -36,6 +36,11 @@ class _Request:
         return (self.height, self.width, self.steps, float(self.scale), float(self.eta), self.control is None,
                 self.uncond is None, bool(self.as_uint8))
 
+    def shareable(self):
+        """eta > 0 draws its noise from the global RNG inside the loop (ddim.py:166): batched with other requests the
+        draw -- and so the result for a given seed -- would depend on the company; such requests run alone, seeded"""
+        return float(self.eta) == 0.0 and self.control is None
+
 
 class PromptFreeServer:
     def __init__(self, net, use_graph=True, max_batch=8, max_wait_s=0.0):
@@ -58,6 +63,21 @@ class PromptFreeServer:
             raise RuntimeError("server is closed")
         if height % 64 or width % 64:
             raise ValueError("output size must be a multiple of 64 (app.py:226-227)")
+        # everything a coalesced batch would first touch inside _generate is checked HERE, on the caller's thread: a
+        # malformed tensor must fail its own request, not the batch it was merged into
+        if n_samples < 1 or n_samples > self.max_batch:
+            raise ValueError(f"n_samples must be in [1, {self.max_batch}]")
+        if steps < 1:
+            raise ValueError("steps must be >= 1")
+        if not (torch.is_tensor(image) and image.dim() == 4 and image.shape[0] == 1 and image.shape[1] == 3 and
+                image.is_floating_point() and min(image.shape[2:]) >= 32):
+            raise ValueError("image must be a float tensor [1, 3, h, w] in [0, 1]")
+        if uncond is not None and not (torch.is_tensor(uncond) and uncond.is_floating_point() and
+                                       tuple(uncond.shape) == (1, 148, 768)):
+            raise ValueError("uncond must be a float tensor [1, 148, 768]")
+        if control is not None and not (torch.is_tensor(control) and control.is_floating_point() and
+                                        tuple(control.shape) == (1, 3, int(height), int(width))):
+            raise ValueError(f"control must be a float tensor [1, 3, {height}, {width}]")
         r = _Request(image=image, n=int(n_samples), height=int(height), width=int(width), steps=int(steps),
                      scale=scale, eta=eta, seed=int(seed), control=control, uncond=uncond, as_uint8=as_uint8,
                      future=Future())
@@ -80,6 +100,14 @@ class PromptFreeServer:
         self._stop = True
         self._q.put(None)
         self._worker.join()
+        while True:      # a submit() that raced past the _stop check sits behind the sentinel: fail it, never leave it pending
+            try:
+                item = self._q.get_nowait()
+            except queue.Empty:
+                break
+            f = item.future if isinstance(item, _Request) else (item[3] if isinstance(item, tuple) else None)
+            if f is not None and not f.done():
+                f.set_exception(RuntimeError("server is closed"))
 
     # ---- worker -------------------------------------------------------------------------------------
     def _run(self):
@@ -93,7 +121,7 @@ class PromptFreeServer:
                 self._control(item)
                 continue
             batch, total = [item], item.n
-            while total < self.max_batch:          # coalesce what is already queued (or arrives within max_wait_s)
+            while total < self.max_batch and item.shareable():   # coalesce what is already queued (or arrives within max_wait_s)
                 try:
                     nxt = self._q.get(timeout=self.max_wait_s) if self.max_wait_s > 0 else self._q.get_nowait()
                 except queue.Empty:
@@ -112,9 +140,19 @@ class PromptFreeServer:
                 for r, o in zip(batch, outs):
                     r.future.set_result(o)
             except BaseException as e:   # noqa: BLE001 -- delivered to the callers, the worker keeps serving
+                if len(batch) == 1:
+                    if not batch[0].future.done():
+                        batch[0].future.set_exception(e)
+                    continue
+                # a coalesced batch failed: run its requests one by one so that only the one that causes the error
+                # receives it (the others would otherwise fail with somebody else's exception)
                 for r in batch:
-                    if not r.future.done():
-                        r.future.set_exception(e)
+                    if r.future.done():
+                        continue
+                    try:
+                        r.future.set_result(self._generate([r])[0])
+                    except BaseException as e1:   # noqa: BLE001
+                        r.future.set_exception(e1)
 
     def _control(self, item):
         op, a, b, f = item
@@ -135,6 +173,8 @@ class PromptFreeServer:
         r0 = batch[0]
         dev = self.net.device
         with DEVICE_LOCK:
+            if float(r0.eta) != 0.0:       # runs alone (shareable()): its noise stream is a function of ITS seed only
+                torch.manual_seed(r0.seed)
             conds, xts, unconds = [], [], []
             for r in batch:
                 c, z = self.pipe.encode_reference(r.image.to(dev), r.n)

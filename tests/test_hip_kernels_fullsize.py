@@ -36,7 +36,9 @@ def rel(a, ref):
 
 def check(name, a, ref, tol=1e-2):
     e, l2 = rel(a, ref)
-    print(f"[fullsize] {name}: scaled max-abs {e:.3e}, rel-L2 {l2:.3e} (tol {tol:g})")
+    raw = float((a.detach().double().cpu() - ref.detach().double().cpu()).abs().max())
+    print(f"[fullsize] {name}: scaled max-abs {e:.3e}, rel-L2 {l2:.3e} (tol {tol:g}); unscaled max-abs {raw:.3e}, "
+          f"max|ref| {float(ref.detach().double().abs().max()):.3f}")
     assert e <= tol and l2 <= tol, f"{name}: max-abs {e}, rel-L2 {l2} > {tol}"
     return e, l2
 

@@ -25,7 +25,9 @@ def err(a, ref):
 
 def check(name, a, ref, tol=TOL):
     e = err(a, ref)
-    print(f"[parity] {name}: scaled max-abs err {e:.3e} (tol {tol:g})")
+    raw = float((a.detach().double().cpu() - torch.as_tensor(ref).double()).abs().max())
+    print(f"[parity] {name}: scaled max-abs err {e:.3e} (tol {tol:g}); unscaled max-abs {raw:.3e}, "
+          f"max|ref| {float(torch.as_tensor(ref).double().abs().max()):.3f}")
     assert e <= tol, f"{name}: {e} > {tol}"
 
 

@@ -269,3 +269,62 @@ def test_safetensors_hot_swap_is_strict_and_in_place(tmp_path):
     assert float(net.ctl.weight.detach().min()) == 1.0
     with pytest.raises(AssertionError):
         W.load_sd_from_file(str(tmp_path / "x.bin"))
+
+
+def test_serving_validates_at_submit_and_isolates_failures(monkeypatch):
+    """ADVICE r02 (serving.py): a malformed request is refused on the caller's thread before it can be merged into
+    somebody else's batch; if a coalesced batch still fails, its requests are re-run one by one and only the culprit
+    receives the exception; a request left behind the close() sentinel is failed, never left pending.  The device work
+    is stubbed (host logic only)."""
+    import threading
+    import torch
+    from lib import serving
+
+    class _Pipe:
+        def __init__(self, net):
+            pass
+
+        def enable_graph(self, on):
+            pass
+
+    monkeypatch.setattr(serving, "PromptFreePipeline", _Pipe)
+    srv = serving.PromptFreeServer(object(), use_graph=False, max_batch=4)
+    calls = []
+
+    def fake_generate(batch):
+        calls.append([r.seed for r in batch])
+        if any(r.seed == 13 for r in batch):
+            raise RuntimeError("bad request 13")
+        return [torch.full((r.n, 1), float(r.seed)) for r in batch]
+
+    srv._generate = fake_generate
+    img = torch.rand(1, 3, 64, 64)
+    for bad in (dict(image=torch.rand(3, 64, 64)), dict(image=img, uncond=torch.zeros(1, 77, 768)),
+                dict(image=img, control=torch.zeros(1, 3, 32, 32)), dict(image=img, n_samples=9),
+                dict(image=img.int()), dict(image=img, height=100)):
+        kw = dict(height=64, width=64)
+        kw.update(bad)
+        with pytest.raises(ValueError):
+            srv.submit(**kw)
+    gate = threading.Event()
+    srv.call(lambda n: gate.wait(30))
+    f1 = srv.submit(img, 1, 64, 64, seed=1)
+    f2 = srv.submit(img, 1, 64, 64, seed=13)
+    f3 = srv.submit(img, 1, 64, 64, seed=3)
+    f4 = srv.submit(img, 1, 64, 64, seed=4, eta=0.5)       # eta > 0 never shares a batch
+    gate.set()
+    assert float(f1.result(30)[0, 0]) == 1.0 and float(f3.result(30)[0, 0]) == 3.0 and float(f4.result(30)[0, 0]) == 4.0
+    with pytest.raises(RuntimeError, match="bad request 13"):
+        f2.result(30)
+    assert calls[0] == [1, 13, 3] and sorted(calls[1:4]) == [[1], [3], [13]] and calls[4] == [4]
+    # close(): anything still queued behind the sentinel is failed
+    gate2 = threading.Event()
+    srv.call(lambda n: gate2.wait(30))
+    srv._q.put(None)
+    late = serving._Request(image=img, n=1, height=64, width=64, steps=1, scale=2.0, eta=0.0, seed=5,
+                            future=serving.Future())
+    srv._q.put(late)
+    gate2.set()
+    srv.close()
+    with pytest.raises(RuntimeError, match="closed"):
+        late.future.result(5)
