@@ -300,6 +300,12 @@ int pfd_axpby_f16(const void* a, float alpha, const void* b, float beta, void* y
 int pfd_add_rowvec_f16(const void* x, int64_t ldx, const void* v, void* y, int64_t ldy, int32_t R,
                        int32_t C, pfd_stream_t stream);
 
+/* The same with the partial row sums of y in the layout PfdGemmDesc.ln_stats takes (f32 [R][C / 160][2]; C % 160 == 0,
+ * C <= 1280), in the summation order of pfd_ln_rowstats_f16 / the statistics-emitting GEMM epilogue: the `x + to_out.bias`
+ * rows of the zero-context cross-attention shortcut feed the next folded LayerNorm without another pass. */
+int pfd_add_rowvec_lnstats_f16(const void* x, int64_t ldx, const void* v, void* y, int64_t ldy, int32_t R, int32_t C,
+                               void* stats, pfd_stream_t stream);
+
 /* NHWC f16 -> packed uint8 image(s) [B, H, W, C]: v = clamp(x*mul + add, 0, 1), then uint8(v * 255)
  * truncated -- bit for bit what the reference's output stage does to the decoded image:
  * AutoencoderKL.decode's (x+1)/2 + clamp (autokl.py:47,53) followed by torchvision's ToPILImage, i.e.

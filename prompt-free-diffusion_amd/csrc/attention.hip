@@ -320,9 +320,17 @@ __global__ __launch_bounds__(256, (D <= 40 ? 4 : 1)) void attention_kernel(const
 //    sigma = d[1] | d[2] << 1 | d[3] << 3, which makes both ds_read_b64 of a fragment conflict free (rows of equal
 //    parity share a bank half; {sigma} and {sigma ^ 4} partition its 16 slots).
 // ------------------------------------------------------------------------------------------------
-template <int D, int NWAVES, bool PV16>
+//  * FOLD (d = 40): the running maximum is subtracted BY THE QK^T MFMA.  D pads 40 -> 48 in the contraction, so slot 40
+//    is free: K's LDS image carries 1.0 there, the (pre-scaled, Q' = scale log2(e) Q) query fragment carries -m, and the
+//    accumulator comes out as s' - m -- the per-score fma in front of v_exp_f32 (31 of the ~105 VALU instructions of a
+//    tile) disappears.  m is kept as an f16 value (it lives in an f16 operand slot); every use of it -- the fold, the
+//    accumulator rescale -- sees the same rounded number, so the rounding cancels in O / l exactly like any other
+//    common factor.  The maximum is only RAISED when a row's tile maximum exceeds the folded one by more than 6 (P <= 64
+//    in f16; the guide's T13 deferred rescale), or on the first tile; that path subtracts the increment explicitly.
+template <int D, int NWAVES, bool PV16, bool FOLD = false>
 __global__ __launch_bounds__(NWAVES * 64, (D <= 40 ? 4 : 1)) void attention2_kernel(const AttnParams p) {
   static_assert(!PV16 || D == 40, "the 16x16x32 PV path is laid out for d = 40 (48 padded rows, row 40 = ones)");
+  static_assert(!FOLD || D == 40, "the folded maximum uses contraction slot 40 of the d = 40 build (DQK = 48)");
   constexpr int KV_TILE = 64, NU = 2;
   constexpr int NTHR = NWAVES * 64;
   constexpr int QB = NWAVES * 32;
@@ -360,6 +368,10 @@ __global__ __launch_bounds__(NWAVES * 64, (D <= 40 ? 4 : 1)) void attention2_ker
     for (int i = tid; i < 2 * KV_TILE; i += NTHR)
       Vts[(i / KV_TILE) * V_TILE_HALFS + D * VT_LD + (i % KV_TILE)] = (half_t)1.f;
   }
+  if (FOLD) {       // column D of K = 1 in both stages (the staging writes columns 0 .. D - 1 only)
+    for (int i = tid; i < 2 * KV_TILE; i += NTHR)
+      Ks[(i / KV_TILE) * K_TILE_HALFS + (i % KV_TILE) * K_LD + D] = (half_t)1.f;
+  }
 
   half8_t qf[NS];
   {
@@ -371,8 +383,13 @@ __global__ __launch_bounds__(NWAVES * 64, (D <= 40 ? 4 : 1)) void attention2_ker
       t.u = *reinterpret_cast<const uint4*>(qp + min(d, D - 8));   // unconditional; padding slots zeroed below
       if (d >= D) t.u = make_uint4(0, 0, 0, 0);
       qf[s] = t.h;
+      if (FOLD) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) qf[s][e] = (half_t)((float)qf[s][e] * p.scale_log2);
+      }
     }
   }
+  bool first_tile = true;   // FOLD: the first tile always sets the folded maximum
 
   float16_t o32[PV16 ? 1 : ND];          // PV on 32x32x16: O^T tile i, col = q = l31
   float4_t o16[PV16 ? NDT : 1][2];       // PV on 16x16x32: [d tile][q tile], col = q % 16 = lane & 15, rows 4 (lane >> 4) + r
@@ -384,7 +401,7 @@ __global__ __launch_bounds__(NWAVES * 64, (D <= 40 ? 4 : 1)) void attention2_ker
   for (int i = 0; i < (PV16 ? NDT : 1); ++i)
 #pragma unroll
     for (int q = 0; q < 2; ++q) o16[i][q] = (float4_t){0.f, 0.f, 0.f, 0.f};
-  float m_run = -INFINITY, l_run = 0.f;
+  float m_run = FOLD ? 0.f : -INFINITY, l_run = 0.f;
 
   const half_t* kbase = p.K + (long)b * p.k_bs + h * D;
   const half_t* vbase = p.Vt + (long)h * D * p.ldvt + (long)b * p.vt_bs;
@@ -522,10 +539,7 @@ __global__ __launch_bounds__(NWAVES * 64, (D <= 40 ? 4 : 1)) void attention2_ker
 #pragma unroll
       for (int r = 0; r < 16; ++r) mx = fmaxf(mx, st[u][r]);
     mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-    const float m_new = fmaxf(m_run, mx);
-    if (__any(m_new > m_run)) {
-      const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c);   // 1 for rows whose max did not move; 0 at the start
-      l_run *= alpha;
+    auto rescale_o = [&](float alpha) __attribute__((always_inline)) {
       if constexpr (PV16) {
         const float a0 = __shfl(alpha, dl, 64), a1 = __shfl(alpha, dl + 16, 64);   // accumulator columns: q = dl + 16 qt
 #pragma unroll
@@ -541,21 +555,50 @@ __global__ __launch_bounds__(NWAVES * 64, (D <= 40 ? 4 : 1)) void attention2_ker
 #pragma unroll
           for (int r = 0; r < 16; ++r) o32[i][r] *= alpha;
       }
-      m_run = m_new;
-    }
-    const float mc = m_run * c;
+    };
     float rs = 0.f;
     half8_t pf[NU][2];
+    if constexpr (FOLD) {
+      // st = s' - m_run already (m_run: the f16-representable maximum folded into the query fragment; 0 before the first tile)
+      if (first_tile || __any(mx > 6.0f)) {
+        const bool up = first_tile || mx > 0.f;
+        const float m_new = up ? (float)(half_t)(m_run + mx) : m_run;
+        const float delta = m_new - m_run;                       // exact: both are f16 values
+        rescale_o(__builtin_amdgcn_exp2f(-delta));               // (accumulators are 0 on the first tile)
 #pragma unroll
-    for (int u = 0; u < NU; ++u)
+        for (int u = 0; u < NU; ++u)
 #pragma unroll
-      for (int bb = 0; bb < 2; ++bb)
+          for (int r = 0; r < 16; ++r) st[u][r] -= delta;
+        m_run = m_new;
+        if (hi) qf[NS - 1][0] = (half_t)(-m_new);                // contraction slot D = 40: k block 2, upper lane half, element 0
+        first_tile = false;
+      }
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          const float e = __builtin_amdgcn_exp2f(fmaf(st[u][bb * 8 + j], c, -mc));
-          if (!SUM_MFMA) rs += e;
-          pf[u][bb][j] = (half_t)e;
-        }
+      for (int u = 0; u < NU; ++u)
+#pragma unroll
+        for (int bb = 0; bb < 2; ++bb)
+#pragma unroll
+          for (int j = 0; j < 8; ++j) pf[u][bb][j] = (half_t)__builtin_amdgcn_exp2f(st[u][bb * 8 + j]);
+    } else {
+      const float m_new = fmaxf(m_run, mx);
+      if (__any(m_new > m_run)) {
+        const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c);   // 1 for rows whose max did not move; 0 at the start
+        l_run *= alpha;
+        rescale_o(alpha);
+        m_run = m_new;
+      }
+      const float mc = m_run * c;
+#pragma unroll
+      for (int u = 0; u < NU; ++u)
+#pragma unroll
+        for (int bb = 0; bb < 2; ++bb)
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            const float e = __builtin_amdgcn_exp2f(fmaf(st[u][bb * 8 + j], c, -mc));
+            if (!SUM_MFMA) rs += e;
+            pf[u][bb][j] = (half_t)e;
+          }
+    }
     if (!SUM_MFMA) {
       rs += __shfl_xor(rs, 32, 64);
       l_run += rs;
@@ -690,10 +733,11 @@ __global__ __launch_bounds__(NWAVES * 64, (D <= 40 ? 4 : 1)) void attention2_ker
 }
 
 // PFD_ATTN: 0 = round-2 kernel; 1 = peeled loop, 4 waves, PV on 32x32x16; 2 = + 8 waves per block (d = 40, big grids);
-// 3 = 4 waves + PV on 16x16x32 (d = 40); 4 (default) = 8 waves + PV on 16x16x32 where 8-wave blocks apply, mode 1 elsewhere.
+// 3 = 4 waves + PV on 16x16x32 (d = 40); 4 = 8 waves + PV on 16x16x32 where 8-wave blocks apply, mode 1 elsewhere;
+// 5 = mode 2 + the maximum folded into the QK^T MFMA; 6 (default) = mode 4 + fold.
 // PFD_ATTN_FORCE8=1 takes the 8-wave form for every d = 40 problem (tests).
 static int attn_mode() {
-  static const int m = getenv("PFD_ATTN") ? atoi(getenv("PFD_ATTN")) : 4;
+  static const int m = getenv("PFD_ATTN") ? atoi(getenv("PFD_ATTN")) : 6;
   return m;
 }
 static bool attn_force8() {
@@ -710,14 +754,16 @@ int launch(const AttnParams& p, hipStream_t s) {
   const int mode = attn_mode();
   // 8-wave blocks pay when a block has many queries to amortise the staging over and the grid still fills the chip twice
   const bool big = p.Nq >= 1024 && (long)p.B * p.H * ((p.Nq + 255) / 256) >= 512;
-  const bool w8 = (mode == 2 || mode == 4) && D == 40 && (big || attn_force8());
+  const bool w8 = (mode == 2 || mode == 4 || mode == 5 || mode == 6) && D == 40 && (big || attn_force8());
   const int qb = w8 ? 256 : 128;
   dim3 grid(((p.Nq + qb - 1) / qb) * p.H * p.B);
   if (mode == 0) {
     hipLaunchKernelGGL((attention_kernel<D, 64>), grid, dim3(256), 0, s, p);
   } else if constexpr (D == 40) {
-    const bool pv16 = mode == 3 || (mode == 4 && w8);   // (the 4-wave PV16 build spills 24 bytes at 128 VGPRs)
-    if (w8 && pv16) hipLaunchKernelGGL((attention2_kernel<D, 8, true>), grid, dim3(512), 0, s, p);
+    const bool pv16 = mode == 3 || ((mode == 4 || mode == 6) && w8);   // (the 4-wave PV16 build spills 24 bytes at 128 VGPRs)
+    if (w8 && mode == 6) hipLaunchKernelGGL((attention2_kernel<D, 8, true, true>), grid, dim3(512), 0, s, p);
+    else if (w8 && mode == 5) hipLaunchKernelGGL((attention2_kernel<D, 8, false, true>), grid, dim3(512), 0, s, p);
+    else if (w8 && pv16) hipLaunchKernelGGL((attention2_kernel<D, 8, true>), grid, dim3(512), 0, s, p);
     else if (w8) hipLaunchKernelGGL((attention2_kernel<D, 8, false>), grid, dim3(512), 0, s, p);
     else if (pv16) hipLaunchKernelGGL((attention2_kernel<D, 4, true>), grid, dim3(256), 0, s, p);
     else hipLaunchKernelGGL((attention2_kernel<D, 4, false>), grid, dim3(256), 0, s, p);

@@ -325,6 +325,62 @@ extern "C" int pfd_axpby_f16(const void* a, float alpha, const void* b, float be
   return pfd_check_launch("pfd_axpby_f16");
 }
 
+// y = x + v with the partial row sums of y (PfdGemmDesc.ln_stats layout) in the same launch: four lanes per
+// (row, 160-column slice), lane k takes chunks k, k + 4, ..., k + 16 -- the summation order of ln_rowstats_kernel
+// (norm.hip) and of the statistics-emitting GEMM epilogue, so the `x + bias` rows of the zero-context shortcut carry
+// bit-for-bit the statistics the full out-projection would have written.
+__global__ __launch_bounds__(256) void add_rowvec_lnstats_kernel(const half_t* __restrict__ x, long ldx,
+                                                                 const half_t* __restrict__ v, half_t* __restrict__ y,
+                                                                 long ldy, int R, int P, float2* __restrict__ st) {
+  const long grp = ((long)blockIdx.x * 256 + threadIdx.x) >> 2;
+  const int k = threadIdx.x & 3;
+  const long ngrp = (long)R * P;
+  const long g = min(grp, ngrp - 1);
+  const int m = (int)(g / P), p = (int)(g - (long)m * P);
+  const half_t* src = x + (long)m * ldx + p * 160;
+  const half_t* vv = v + p * 160;
+  Pack16 a[5], b[5];
+#pragma unroll
+  for (int j = 0; j < 5; ++j) {   // all loads first
+    a[j].u = *reinterpret_cast<const uint4*>(src + (k + 4 * j) * 8);
+    b[j].u = *reinterpret_cast<const uint4*>(vv + (k + 4 * j) * 8);
+  }
+  float s = 0.f, q = 0.f;
+#pragma unroll
+  for (int j = 0; j < 5; ++j) {
+    Pack16 o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      o.e[e] = (half_t)((float)a[j].e[e] + (float)b[j].e[e]);
+      const float f = (float)o.e[e];
+      s += f;
+      q = fmaf(f, f, q);
+    }
+    if (grp < ngrp) *reinterpret_cast<uint4*>(y + (long)m * ldy + p * 160 + (k + 4 * j) * 8) = o.u;
+  }
+  s += __shfl_xor(s, 1, 64);
+  q += __shfl_xor(q, 1, 64);
+  s += __shfl_xor(s, 2, 64);
+  q += __shfl_xor(q, 2, 64);
+  if (k == 0 && grp < ngrp) st[grp] = make_float2(s, q);
+}
+
+extern "C" int pfd_add_rowvec_lnstats_f16(const void* x, int64_t ldx, const void* v, void* y, int64_t ldy, int32_t R,
+                                          int32_t C, void* stats, pfd_stream_t stream) {
+  if (!x || !v || !y || !stats || R <= 0 || C <= 0) return PFD_EINVAL;
+  if ((C % 160) || C > 1280) return PFD_ESHAPE;
+  if ((ldx & 7) || (ldy & 7) || (reinterpret_cast<uintptr_t>(stats) & 7)) return PFD_EINVAL;
+  if ((reinterpret_cast<uintptr_t>(x) & 15) || (reinterpret_cast<uintptr_t>(v) & 15) || (reinterpret_cast<uintptr_t>(y) & 15))
+    return PFD_EINVAL;
+  const int P = C / 160;
+  const long ngrp = (long)R * P;
+  PfdProfScope prof_scope(15, 0.0, 0.0, (hipStream_t)stream);
+  hipLaunchKernelGGL(add_rowvec_lnstats_kernel, dim3((unsigned)((ngrp + 63) / 64)), dim3(256), 0, (hipStream_t)stream,
+                     (const half_t*)x, (long)ldx, (const half_t*)v, (half_t*)y, (long)ldy, R, P,
+                     reinterpret_cast<float2*>(stats));
+  return pfd_check_launch("pfd_add_rowvec_lnstats_f16");
+}
+
 extern "C" int pfd_add_rowvec_f16(const void* x, int64_t ldx, const void* v, void* y, int64_t ldy, int32_t R,
                                   int32_t C, pfd_stream_t stream) {
   if (!x || !v || !y || R <= 0 || C <= 0) return PFD_EINVAL;

@@ -348,7 +348,29 @@ static void run_ln_fold_case(int M, int C, int N, int act, int tile_prod, int ti
   }
 }
 
+// pfd_add_rowvec_lnstats_f16 == pfd_add_rowvec_f16 followed by pfd_ln_rowstats_f16, bit for bit (values and statistics)
+static void run_add_rowvec_lnstats_case(int R, int C) {
+  auto X = rand_h((size_t)R * C, 3.0f), V = rand_h(C, 1.0f);
+  Dev<h16> dX(X), dV(V), dY1((size_t)R * C), dY2((size_t)R * C);
+  const int P = C / 160;
+  Dev<float> s1((size_t)R * P * 2), s2((size_t)R * P * 2);
+  int rc = pfd_add_rowvec_lnstats_f16(dX.p, C, dV.p, dY1.p, C, R, C, s1.p, nullptr);
+  if (rc == 0) rc = pfd_add_rowvec_f16(dX.p, C, dV.p, dY2.p, C, R, C, nullptr);
+  if (rc == 0) rc = pfd_ln_rowstats_f16(dY2.p, C, R, C, s2.p, nullptr);
+  char name[128];
+  snprintf(name, sizeof(name), "add_rowvec + row statistics R%d C%d (bitwise vs two launches)", R, C);
+  ++g_total;
+  if (rc != 0) { ++g_fail; printf("FAIL %-58s rc=%d (%s)\n", name, rc, pfd_last_error()); return; }
+  auto y1 = dY1.get(), y2 = dY2.get();
+  auto a = s1.get(), b = s2.get();
+  const bool same = !memcmp(y1.data(), y2.data(), y1.size() * sizeof(h16)) && !memcmp(a.data(), b.data(), a.size() * sizeof(float));
+  if (!same) { ++g_fail; printf("FAIL %-58s outputs differ\n", name); }
+  else printf("ok   %-58s\n", name);
+}
+
 static void run_ln_fold_suite() {
+  run_add_rowvec_lnstats_case(130, 320);
+  run_add_rowvec_lnstats_case(77, 1280);
   run_ln_fold_case(300, 320, 960, 0, 0, 0, 640);            // fused q | k | v^T of a 320-wide block (transposed tail)
   run_ln_fold_case(700, 320, 320, 0, 3400, 3400, 0);        // 128-row tiles, 4 waves
   run_ln_fold_case(520, 640, 640, 0, 9200, 9200, 0);        // 128-row tiles, 8 waves
@@ -360,7 +382,9 @@ static void run_ln_fold_suite() {
 }
 
 // ------------------------------------------------------------------ attention
-static void run_attn_case(int B, int H, int Nq, int Nk, int D, bool fused_layout) {
+// spike > 0: key `spike` of every (b, h) is set to 4 x query (spike % Nq) -- its score jumps far above everything before
+// it, which forces the running-maximum update (and the deferred-rescale path of the folded form) in the middle of the stream
+static void run_attn_case(int B, int H, int Nq, int Nk, int D, bool fused_layout, int spike = 0) {
   const int C = H * D;
   const float scale = 1.0f / sqrtf((float)D);
   // fused_layout: Q and K are column slices of one [B*N, 2C] matrix (self-attention producer layout)
@@ -368,6 +392,13 @@ static void run_attn_case(int B, int H, int Nq, int Nk, int D, bool fused_layout
   const int Nkp = (Nk + 7) / 8 * 8;
   const long ldvt = (long)B * Nkp;
   auto Qh = rand_h((size_t)B * Nq * ldq, 1.5f), Kh = rand_h((size_t)B * Nk * ldk, 1.5f), Vt = rand_h((size_t)C * ldvt, 1.0f);
+  if (spike > 0 && spike < Nk) {
+    const int koff0 = fused_layout ? C : 0;
+    for (int b = 0; b < B; ++b)
+      for (int c = 0; c < C; ++c)
+        Kh[(size_t)b * Nk * ldk + (size_t)spike * ldk + koff0 + c] =
+            (h16)(4.0f * (float)Qh[(size_t)b * Nq * ldq + (size_t)(spike % Nq) * ldq + c]);
+  }
   Dev<h16> dQ(Qh), dK(Kh), dV(Vt), dO((size_t)B * Nq * ldo);
   PfdAttnDesc d;
   memset(&d, 0, sizeof(d));
@@ -377,7 +408,7 @@ static void run_attn_case(int B, int H, int Nq, int Nk, int D, bool fused_layout
   d.B = B; d.H = H; d.Nq = Nq; d.Nk = Nk; d.D = D; d.scale = scale;
   const int rc = pfd_attention_f16(&d, nullptr);
   char name[128];
-  snprintf(name, sizeof(name), "attention B%d H%d Nq%d Nk%d D%d fused%d", B, H, Nq, Nk, D, (int)fused_layout);
+  snprintf(name, sizeof(name), "attention B%d H%d Nq%d Nk%d D%d fused%d spike%d", B, H, Nq, Nk, D, (int)fused_layout, spike);
   if (rc != 0) { ++g_total; ++g_fail; printf("FAIL %-58s rc=%d (%s)\n", name, rc, pfd_last_error()); return; }
   auto got = dO.get();
   std::vector<double> ref(got.size(), 0.0);
@@ -1014,6 +1045,9 @@ int main(int argc, char** argv) {
     run_attn_case(1, 3, 148, 148, 96, false);
     run_attn_case(2, 2, 64, 148, 160, false);
     run_attn_case(1, 1, 256, 320, 160, true);
+    run_attn_case(1, 2, 520, 1000, 40, false, 700);   // maximum jumps at key 700 (tile 10 of 16)
+    run_attn_case(2, 2, 512, 256, 40, true, 130);
+    run_attn_case(1, 2, 300, 148, 40, false, 140);    // ... inside the ragged tile
     printf("SELFTEST %d/%d passed, %d failed\n", g_total - g_fail, g_total, g_fail);
     return g_fail;
   }

@@ -79,6 +79,7 @@ SIGNATURES = {
     "pfd_add_f16": (_i32, [_vp, _vp, _vp, _i64, _vp]),
     "pfd_axpby_f16": (_i32, [_vp, _f32, _vp, _f32, _vp, _i64, _vp]),
     "pfd_add_rowvec_f16": (_i32, [_vp, _i64, _vp, _vp, _i64, _i32, _i32, _vp]),
+    "pfd_add_rowvec_lnstats_f16": (_i32, [_vp, _i64, _vp, _vp, _i64, _i32, _i32, _vp, _vp]),
     "pfd_act_f16": (_i32, [_vp, _vp, _i64, _i32, _vp]),
     "pfd_image_u8_f16": (_i32, [_vp, _vp, _i64, _f32, _f32, _i32, _vp]),
     "pfd_prof_enable": (_i32, [_i32]),

@@ -484,11 +484,19 @@ def axpby(a, alpha, b=None, beta=0.0, out=None):
     return out
 
 
-def add_rowvec(x, v, out=None):
+def add_rowvec(x, v, out=None, ln_out=None):
+    """out = x + v[None, :]; ln_out: a float32 [R, C/160, 2] tensor that receives the partial row sums of `out` in the
+    same launch (the layout gemm(ln=...) takes)"""
     _chk16(x, "add_rowvec x")
     R, Cc, ldx = _rows(x)
     if out is None:
         out = torch.empty(x.shape, dtype=torch.float16, device=x.device)
+    if ln_out is not None:
+        if ln_out.dtype != torch.float32 or not ln_out.is_contiguous() or ln_out.numel() != R * (Cc // 160) * 2:
+            raise ValueError("add_rowvec: ln_out must be a contiguous float32 [R, C/160, 2]")
+        _b.check(_lib().pfd_add_rowvec_lnstats_f16(x.data_ptr(), ldx, v.data_ptr(), out.data_ptr(), _rows(out)[2], R, Cc,
+                                                   ln_out.data_ptr(), _stream()), "pfd_add_rowvec_lnstats_f16")
+        return out
     _b.check(_lib().pfd_add_rowvec_f16(x.data_ptr(), ldx, v.data_ptr(), out.data_ptr(), _rows(out)[2], R, Cc,
                                        _stream()), "pfd_add_rowvec_f16")
     return out

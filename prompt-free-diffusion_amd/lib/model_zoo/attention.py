@@ -243,14 +243,15 @@ class CrossAttention(nn.Module, L._Packed):
                 Bc = B - z
                 out = torch.empty_like(res)
                 w_o, b_o = self.to_out[0]._pk()
-                ops.add_rowvec(res[:z * N], b_o, out=out[:z * N])
+                st_o = None
+                if stats_out:   # the `x + bias` rows write their statistics with the add (same order as the GEMM epilogue)
+                    st_o = torch.empty((B * N, out.shape[1] // 160, 2), dtype=torch.float32, device=out.device)
+                ops.add_rowvec(res[:z * N], b_o, out=out[:z * N], ln_out=None if st_o is None else st_o[:z * N])
                 q = self.to_q.hip(x[z * N:], ln=None if ln is None else (ln[0], ln[1][z * N:]))
                 o = ops.attention(q, k[z * context.Nkp:], vt[:, z * context.Nkp:], Bc, H, N, context.Nk, D,
                                   self.scale, ldq=Cd, ldk=Cd, ldvt=B * context.Nkp, q_bs=N * Cd,
                                   k_bs=context.Nkp * Cd, vt_bs=context.Nkp)
                 if stats_out:
-                    st_o = torch.empty((B * N, out.shape[1] // 160, 2), dtype=torch.float32, device=out.device)
-                    ops.ln_rowstats(out[:z * N], out=st_o[:z * N])     # the `x + bias` rows: stand-alone statistics
                     self.to_out[0].hip(o, res=res[z * N:], out=out[z * N:], ln_out=st_o[z * N:])
                     return out, st_o
                 self.to_out[0].hip(o, res=res[z * N:], out=out[z * N:])
