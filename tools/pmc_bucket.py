@@ -26,8 +26,11 @@ def dispatches(db, counter):
 def bucket(name):
     m = re.match(r"void gemm160_kernel<(\d), (\d), (true|false)", name)
     if m:
-        tile = {"44": "256x160", "24": "128x160", "22": "64x160"}[m.group(1) + m.group(2)]
-        return f"gemm160_kernel<{m.group(1)},{m.group(2)}{',conv' if m.group(3) == 'true' else ''}>({tile})"
+        # bench.py's buckets are keyed by the ROW count of the tile (256 / 128 / 64): the 8-wave forms of round 3
+        # (<4,2> = 128 rows, <4,1> = 64 rows) and the 256 x 320 GEGLU tile (<4,4,...,10>) share the bucket of their rows
+        rows = int(m.group(1)) * int(m.group(2)) * 16
+        key = {256: ("4,4", "256x160"), 128: ("2,4", "128x160"), 64: ("2,2", "64x160")}[rows]
+        return f"gemm160_kernel<{key[0]}{',conv' if m.group(3) == 'true' else ''}>({key[1]})"
     m = re.match(r"void gemm160ws_kernel<(true|false)", name)
     if m:
         return f"gemm160_kernel<4,4{',conv' if m.group(1) == 'true' else ''}>(256x160)"

@@ -11,9 +11,24 @@ rocprofv3 --kernel-trace --stats -d $OUT/kt -o kt -- python $REPO/bench.py --ste
 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $OUT/pmc_fetch -o f -- $S --replay $L > $OUT/pmc_fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $OUT/pmc_write -o w -- $S --replay $L > $OUT/pmc_write.log 2>&1
 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_VALU SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT --kernel-trace -d $OUT/pmc_sq -o q -- $S --replay $L > $OUT/pmc_sq.log 2>&1
+# attention / GroupNorm / LayerNorm: HBM traffic and GB/s from PMC passes over the torch-free kernel benches
+for w in attn gn; do
+  rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $OUT/pmc_fetch_$w -o f -- $S --bench-$w > $OUT/pmc_fetch_$w.log 2>&1
+  rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $OUT/pmc_write_$w -o w -- $S --bench-$w > $OUT/pmc_write_$w.log 2>&1
+done
+# kernel stats of the other BASELINE configs (C3 ControlNet + SeeCoder-PA, C5 768^2)
+for c in c3 c5; do
+  rocprofv3 --kernel-trace --stats -d $OUT/kt_$c -o kt -- python $REPO/bench.py --config $c --steps 2 --warmup 1 --no-cpu-baseline --no-prof > $OUT/kt_bench_$c.json 2> $OUT/kt_$c.log
+done
 cd $REPO
+for c in c3 c5; do
+  python tools/rocpd_stats.py $(find $OUT/kt_$c -name '*results.db' | head -1) $OUT/${TAG}_rocprof_kernel_stats_$c.md > /dev/null 2>&1
+done
 python tools/rocpd_stats.py $(find $OUT/kt -name '*results.db' | head -1) $OUT/${TAG}_rocprof_kernel_stats.md > /dev/null 2>&1
 python tools/pmc_bucket.py $(find $OUT/pmc_fetch -name '*results.db' | head -1) $(find $OUT/pmc_write -name '*results.db' | head -1) $OUT/pmc_traffic.json $OUT/${TAG}_pmc_traffic_per_bucket.md > $OUT/pmc_bucket.log 2>&1
 python tools/pmc_sq.py $(find $OUT/pmc_sq -name '*results.db' | head -1) $OUT/${TAG}_pmc_sq_gemm.md > /dev/null 2>&1
+for w in attn gn; do
+  python tools/pmc_kernels.py $(find $OUT/pmc_fetch_$w -name '*results.db' | head -1) $(find $OUT/pmc_write_$w -name '*results.db' | head -1) $OUT/${TAG}_pmc_hbm_$w.md $OUT/pmc_traffic.json > $OUT/pmc_kernels_$w.log 2>&1
+done
 find $OUT -name '*results.db' -size +20M -delete    # keep gpurun_out under its 64 MiB cap
 ls -la $OUT
