@@ -912,6 +912,14 @@ static int replay(const char* path, bool timed = false, int force_tile = 0) {
   }
   Dev<h16> dA(rand_h(maxA)), dW(rand_h(maxW, 0.05f)), dB(rand_h(maxV)), dRV(rand_h(maxC)), dR(rand_h(maxC)), dC(maxC);
   Dev<float> dWS((size_t)24 << 20);
+  size_t maxM = 1;
+  for (auto& q : rows) maxM = std::max(maxM, (size_t)q[0]);
+  Dev<float> dLnS(rand_f(maxM * 16, 1.0f)), dLnC(rand_f(16384, 1.0f)), dLnO(maxM * 16);   // [M][<= 8][2] statistics, column sums
+  {  // plausible statistics: sum ~ 0, sum of squares ~ K (so that rstd is finite)
+    std::vector<float> st(maxM * 16);
+    for (size_t i = 0; i < st.size(); i += 2) { st[i] = 0.5f; st[i + 1] = 200.f; }
+    HIP_OK(hipMemcpy(dLnS.p, st.data(), st.size() * sizeof(float), hipMemcpyHostToDevice));
+  }
   int bad = 0;
   // --replay-time: every launch reads its weights from a fresh slice of a 2 GB pool (as in the UNet,
   // where 1.7 GB of other layers' weights pass through the caches between two uses of a layer) and is
@@ -946,6 +954,17 @@ static int replay(const char* path, bool timed = false, int force_tile = 0) {
         if (pool_off + wn > pool_elems) pool_off = 0;
         d.W = dPool.p + pool_off;
         pool_off += wn;
+      }
+      // PFD_REPLAY_LN=1: the launches that carry a folded LayerNorm in the UNet do so here too (q|k|v, q and GEGLU
+      // projections consume row statistics; proj_in / out-projections emit them) -- prices the fold per shape
+      static const bool replay_ln = getenv("PFD_REPLAY_LN") && atoi(getenv("PFD_REPLAY_LN")) != 0;
+      if (replay_ln && d.ksize == 0 && d.N % 160 == 0 && !d.bias_per_row) {
+        const bool cwidth = d.K == 320 || d.K == 640 || d.K == 1280;
+        if (cwidth && (d.act == PFD_ACT_GEGLU || d.N == 3 * d.K || (d.N == d.K && !d.R && !d.bias))) {
+          d.ln_stats = dLnS.p; d.ln_colsum = dLnC.p; d.ln_parts = d.K / 160; d.ln_eps = 1e-5f;
+        } else if ((d.N == 320 || d.N == 640 || d.N == 1280) && d.act == 0 && d.bias && d.K == d.N) {   // out-projections, proj_in
+          d.ln_out = dLnO.p;
+        }
       }
       static const bool replay_tiled = getenv("PFD_REPLAY_TILED") && atoi(getenv("PFD_REPLAY_TILED")) != 0;
       if (replay_tiled && (d.N % 160 == 0 || d.N % 128 == 0) && d.K % 64 == 0 && !d.bias_per_row) d.w_tiled = 1;
