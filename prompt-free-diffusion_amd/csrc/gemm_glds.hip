@@ -61,6 +61,11 @@ struct G160Params {
   int tiles_m, tiles_n, splits, kt_per_split;
   int nmajor;  // XCD-contiguous tile order: 0 = all N tiles of an M tile together, 1 = all M tiles of an N tile
   int krot;    // 1 = every M tile starts its K loop at a different K tile (see k_rotation below)
+  // 3x3 patch kernels on images wider than a tile row (round 3: 48- and 96-wide latents): an output tile is TH x pt_w
+  // pixels (pt_w = 16 | 32, TH = 256 / pt_w) instead of whole image rows, so the 256 rows of a tile are not consecutive
+  // in M: row r of the tile is output row m0 + (r >> pt_sh) * Wd + (r & (pt_w - 1)), m0 = the tile's first pixel.
+  // pt_w == 0: rows are consecutive (every other kernel, and patch tiles of whole image rows).
+  int pt_w, pt_sh;
   // weight layout: row-major [N][ldw] (w_tu == 0) or K-tile-contiguous [N / w_tu][K / 64][w_tu][64] (w_tu = 160 | 128):
   // a block's weight tile of one K step is then ONE contiguous (w_tu x 128)-byte run of HBM instead of w_tu separate
   // 128-byte pieces a whole weight row (2 K bytes) apart -- the cold weight streams of the 8^2 / 16^2 levels ran at
@@ -90,6 +95,14 @@ __device__ __forceinline__ const half_t* w_row_ptr(const G160Params& p, int n, i
   if (p.w_tu == 0) return p.W + (long)n * p.ldw + c8;
   const int tn = n / p.w_tu;
   return p.W + ((long)tn * (p.K / BK) * p.w_tu + (n - tn * p.w_tu)) * BK + c8;
+}
+
+// output row (index into M) of row `row` of the tile that starts at m0 (see G160Params.pt_w)
+// PT = false (every kernel but the 3x3 patch kernels): rows are consecutive, the mapping folds away
+template <bool PT>
+__device__ __forceinline__ int tile_row_m(const G160Params& p, int m0, int row) {
+  if constexpr (PT) return p.pt_w ? m0 + (row >> p.pt_sh) * p.Wd + (row & (p.pt_w - 1)) : m0 + row;
+  else return m0 + row;
 }
 
 // K rotation.  All blocks of a launch start together and take the same time per K step, so the tiles_m blocks that
@@ -137,13 +150,14 @@ constexpr int stage_row_bytes(int cols) { return cols * 2 + 16; }
 
 // pass 1 (the waves that hold accumulators): returns true when the tile was staged in LDS and needs pass 2
 // lnstat: per-row {rstd, -rstd * mean} of this block's rows in LDS (LayerNorm folded into the GEMM), or nullptr
-template <int WMB, int NT>
+template <int WMB, int NT, bool PT = false>
 __device__ __forceinline__ bool epilogue_stage(float4_t (&acc)[WMB][NT], const G160Params& p, int lane, int m0,
                                                int n0, int wm, int wn, int split, char* smem,
                                                const float2* lnstat = nullptr) {
   constexpr int BN = 32 * NT;
   const int l15 = lane & 15, g = lane >> 4;
-  const int mw = m0 + wm * WMB * 16 + l15;   // + i*16: this lane's output row in row-tile i
+  const int lr0 = wm * WMB * 16 + l15;       // + i*16: this lane's row inside the tile, row-tile i
+  auto mrow = [&](int lr) __attribute__((always_inline)) { return tile_row_m<PT>(p, m0, lr); };   // -> output row (index into M)
   const int nw = n0 + wn * (16 * NT) + 4 * g;       // + j*16: first of this lane's 4 columns in column-tile j
   constexpr bool GEGLU_ONLY = NT == 10;      // the 320-wide tile is dispatched for GEGLU projections only
   if (lnstat && p.splits == 1) {
@@ -165,7 +179,7 @@ __device__ __forceinline__ bool epilogue_stage(float4_t (&acc)[WMB][NT], const G
   if (!GEGLU_ONLY && p.splits > 1) {  // split-K: raw fp32 partials, [split][M][N]
 #pragma unroll
     for (int i = 0; i < WMB; ++i) {
-      const int m = mw + i * 16;
+      const int m = mrow(lr0 + i * 16);
       if (m >= p.M) continue;
 #pragma unroll
       for (int j = 0; j < NT; ++j)
@@ -187,7 +201,7 @@ __device__ __forceinline__ bool epilogue_stage(float4_t (&acc)[WMB][NT], const G
     }
 #pragma unroll
     for (int i = 0; i < WMB; ++i) {
-      const int m = mw + i * 16;
+      const int m = mrow(lr0 + i * 16);
       if (m >= p.M) continue;
 #pragma unroll
       for (int j = 0; j < NT; ++j)
@@ -215,11 +229,8 @@ __device__ __forceinline__ bool epilogue_stage(float4_t (&acc)[WMB][NT], const G
   Pack8 bq[NT];
 #pragma unroll
   for (int j = 0; j < NT; ++j) bq[j].u = *reinterpret_cast<const uint2*>(bp + j * bstep);
-  float bv[NT][4];
-#pragma unroll
-  for (int j = 0; j < NT; ++j)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) bv[j][r] = (float)bq[j].e[r];
+  // (the bias stays packed f16 and is widened where it is added: 10 registers instead of 20 through the staging pass of
+  //  the loader-wave kernels, which sit at their 168-register limit)
   if (geglu) {
     // packed weight rows come in groups of four: x(2c), x(2c+1), gate(2c), gate(2c+1) -- exactly the four
     // columns a lane owns, so out(2c..2c+1) = x * gelu(gate) needs no exchange
@@ -230,8 +241,8 @@ __device__ __forceinline__ bool epilogue_stage(float4_t (&acc)[WMB][NT], const G
 #pragma unroll
       for (int j = 0; j < NT; ++j) {
         half2_t o;
-        o[0] = (half_t)((acc[i][j][0] + bv[j][0]) * pfd_gelu(acc[i][j][2] + bv[j][2]));
-        o[1] = (half_t)((acc[i][j][1] + bv[j][1]) * pfd_gelu(acc[i][j][3] + bv[j][3]));
+        o[0] = (half_t)((acc[i][j][0] + (float)bq[j].e[0]) * pfd_gelu(acc[i][j][2] + (float)bq[j].e[2]));
+        o[1] = (half_t)((acc[i][j][1] + (float)bq[j].e[1]) * pfd_gelu(acc[i][j][3] + (float)bq[j].e[3]));
         *reinterpret_cast<half2_t*>(sp + j * 16) = o;
       }
     }
@@ -249,7 +260,7 @@ __device__ __forceinline__ bool epilogue_stage(float4_t (&acc)[WMB][NT], const G
         Pack8 o;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          float v = acc[i][j][r] + bv[j][r] + (float)rv[j].e[r];
+          float v = acc[i][j][r] + (float)bq[j].e[r] + (float)rv[j].e[r];
           if constexpr (ACT == PFD_ACT_GELU) v = pfd_gelu(v);
           else if constexpr (ACT == PFD_ACT_RELU) v = fmaxf(v, 0.f);
           else if constexpr (ACT == PFD_ACT_SILU) v = pfd_silu(v);
@@ -272,22 +283,23 @@ __device__ __forceinline__ bool epilogue_stage(float4_t (&acc)[WMB][NT], const G
     };
     auto run = [&](auto act) __attribute__((always_inline)) {
       Pack8 cur[NT];
-      const int first = m0 + wm * WMB * 16;
+      const int first = mrow(wm * WMB * 16), last = mrow(wm * WMB * 16 + WMB * 16 - 1);   // this wave's first / last output row
       if (!p.rowvec) {
 #pragma unroll
         for (int j = 0; j < NT; ++j) cur[j].u = make_uint2(0, 0);
         for_rows([&](auto it) __attribute__((always_inline)) { put_row(act, it, cur); });
-      } else if (min(first, p.M - 1) / p.rows_per_rv == min(first + WMB * 16 - 1, p.M - 1) / p.rows_per_rv) {
+      } else if (PT || min(first, p.M - 1) / p.rows_per_rv == min(last, p.M - 1) / p.rows_per_rv) {
+        // (a patch tile never leaves its sample: the per-lane form below is not even compiled for those kernels)
         // every row of this wave belongs to one sample (the convolutions' per-sample time embedding): NT loads
         load_rv(cur, first);
         for_rows([&](auto it) __attribute__((always_inline)) { put_row(act, it, cur); });
-      } else {
+      } else if constexpr (!PT) {
         // rows of several samples: per-lane vectors, the next row tile's loads in flight under the current one
         Pack8 nxt[NT];
-        load_rv(cur, mw);
+        load_rv(cur, mrow(lr0));
         for_rows([&](auto it) __attribute__((always_inline)) {
           constexpr int i = decltype(it)::value;
-          if constexpr (i + 1 < WMB) load_rv(nxt, mw + (i + 1) * 16);
+          if constexpr (i + 1 < WMB) load_rv(nxt, mrow(lr0 + (i + 1) * 16));
           put_row(act, it, cur);
           if constexpr (i + 1 < WMB) {
 #pragma unroll
@@ -309,7 +321,7 @@ __device__ __forceinline__ bool epilogue_stage(float4_t (&acc)[WMB][NT], const G
 // pass 2 (every thread of the block, after a barrier): + residual, 16-byte chunks of contiguous row segments
 // LNOUT: compile the statistics-emitting store pass (linear kernels only: convolutions never feed a LayerNorm, and the
 // loader-wave kernels have no registers to spare for it)
-template <int BM, int NT, int NTHREADS, bool LNOUT = false>
+template <int BM, int NT, int NTHREADS, bool LNOUT = false, bool PT = false>
 __device__ __forceinline__ void epilogue_store(const G160Params& p, int m0, int n0, const char* smem, int tid) {
   constexpr int BN = 32 * NT;
   constexpr bool GEGLU_ONLY = NT == 10;
@@ -379,14 +391,14 @@ __device__ __forceinline__ void epilogue_store(const G160Params& p, int m0, int 
         for (int u = 0; u < U; ++u) {
           const int c = min(tid + (it0 + u) * NTHREADS, TOTAL - 1);
           const int row = c / CPR, cc = c - row * CPR;
-          r[u].u = *reinterpret_cast<const uint4*>(p.R + (long)min(m0 + row, p.M - 1) * p.ldr + nc0 + cc * 8);
+          r[u].u = *reinterpret_cast<const uint4*>(p.R + (long)min(tile_row_m<PT>(p, m0, row), p.M - 1) * p.ldr + nc0 + cc * 8);
         }
       }
 #pragma unroll
       for (int u = 0; u < U; ++u) {
         const int c = tid + (it0 + u) * NTHREADS;
         const int row = c / CPR, cc = c - row * CPR;
-        const int m = m0 + row;
+        const int m = tile_row_m<PT>(p, m0, row);
         if (it0 + u >= ITERS || c >= TOTAL || m >= p.M) continue;
         Pack16 v;
         v.u = *reinterpret_cast<const uint4*>(smem + row * RS + cc * 16);
@@ -402,13 +414,13 @@ __device__ __forceinline__ void epilogue_store(const G160Params& p, int m0, int 
   else if constexpr (!GEGLU_ONLY) store_pass(std::integral_constant<int, BN>{});
 }
 
-template <int WMB, int NT, int NTHREADS, bool LNOUT = false>
+template <int WMB, int NT, int NTHREADS, bool LNOUT = false, bool PT = false>
 __device__ __forceinline__ void epilogue160(float4_t (&acc)[WMB][NT], const G160Params& p, int lane, int m0,
                                             int n0, int wm, int wn, int split, char* smem, int tid,
                                             const float2* lnstat = nullptr) {
-  epilogue_stage<WMB, NT>(acc, p, lane, m0, n0, wm, wn, split, smem, lnstat);
+  epilogue_stage<WMB, NT, PT>(acc, p, lane, m0, n0, wm, wn, split, smem, lnstat);
   __syncthreads();
-  epilogue_store<(NTHREADS / 128) * WMB * 16, NT, NTHREADS, LNOUT>(p, m0, n0, smem, tid);
+  epilogue_store<(NTHREADS / 128) * WMB * 16, NT, NTHREADS, LNOUT, PT>(p, m0, n0, smem, tid);
 }
 
 template <int WAVES_M, int WMB, bool CONV, int NBUF, int NT>
@@ -947,18 +959,22 @@ __global__ __launch_bounds__(512) void conv3x3_patch_kernel(const G160Params p) 
   // XCD streams 1/8 of W instead -- 3.4-6x less L2-miss traffic on exactly the weight-bound launches
   const int tile_m = p.nmajor ? t % p.tiles_m : t / p.tiles_n;
   const int tile_n = p.nmajor ? t / p.tiles_m : t - tile_m * p.tiles_n;
-  const int m0 = tile_m * 256;
   const int n0 = tile_n * BN;
   const int split = blockIdx.z;
   const int ncb = p.Cin / BK;
   const int cb_begin = split * p.kt_per_split;
   const int cb_end = min(ncb, cb_begin + p.kt_per_split);
 
+  // output tile: TH x TW pixels (TW = the image width when a tile is whole image rows, else p.pt_w)
   const int W = p.Wd, H = p.H;
-  const int TH = 256 / W, PW = W + 2;
+  const int TW = p.pt_w ? p.pt_w : W;
+  const int TH = 256 / TW, PW = TW + 2;
   const int hw = H * W;
-  const int b = m0 / hw;
-  const int y0 = (m0 - b * hw) / W;
+  const int tpi = hw / 256, ntx = W / TW;
+  const int b = tile_m / tpi;
+  const int ti = tile_m - b * tpi;
+  const int y0 = (ti / ntx) * TH, x0 = (ti % ntx) * TW;
+  const int m0 = b * hw + y0 * W + x0;          // first output pixel of the tile (see tile_row_m)
   const int prow_count = (TH + 2) * PW;
   const half_t* img = p.A + (long)b * hw * p.lda;
 
@@ -969,7 +985,7 @@ __global__ __launch_bounds__(512) void conv3x3_patch_kernel(const G160Params p) 
   for (int j = 0; j < P_SLOTS; ++j) {
     const int r = (wave + NW * j) * 8 + srow;
     const int py = r / PW, px = r - py * PW;
-    const int y = y0 - 1 + py, x = px - 1;
+    const int y = y0 - 1 + py, x = x0 - 1 + px;
     const int c = (cpos - (r & ~1)) & 7;   // rotation swizzle of the patch rows, see the fragment read below
     const bool ok = r < prow_count && y >= 0 && y < H && x >= 0 && x < W;
     pp[j] = ok ? img + ((long)y * W + x) * p.lda + c * 8 : nullptr;
@@ -1001,7 +1017,7 @@ __global__ __launch_bounds__(512) void conv3x3_patch_kernel(const G160Params p) 
 #pragma unroll
   for (int i = 0; i < WMB; ++i) {
     const int ql = wm * 64 + i * 16;
-    const int ty = ql / W, tx = ql - ty * W;
+    const int ty = ql / TW, tx = ql - ty * TW;
     rbase[i] = ty * PW + tx + l15;
   }
   const int sw = (l15 >> 1) & 7;
@@ -1067,7 +1083,7 @@ __global__ __launch_bounds__(512) void conv3x3_patch_kernel(const G160Params p) 
       }
     }
   }
-  epilogue160<WMB, 5, 512>(acc, p, lane, m0, n0, wm, wn, split, smem, tid);
+  epilogue160<WMB, 5, 512, false, true>(acc, p, lane, m0, n0, wm, wn, split, smem, tid);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1095,17 +1111,21 @@ __global__ __launch_bounds__(768) void conv3x3_patch_ws_kernel(const G160Params 
   const int t = xcd_remap(blockIdx.x, nblk);
   const int tile_m = p.nmajor ? t % p.tiles_m : t / p.tiles_n;
   const int tile_n = p.nmajor ? t / p.tiles_m : t - tile_m * p.tiles_n;
-  const int m0 = tile_m * 256;
   const int n0 = tile_n * BN;
   const int split = blockIdx.z;
   const int ncb = p.Cin / BK;
   const int cb_begin = split * p.kt_per_split;
   const int cb_end = min(ncb, cb_begin + p.kt_per_split);
+  // output tile: TH x TW pixels (TW = the image width when a tile is whole image rows, else p.pt_w)
   const int W = p.Wd, H = p.H;
-  const int TH = 256 / W, PW = W + 2;
+  const int TW = p.pt_w ? p.pt_w : W;
+  const int TH = 256 / TW, PW = TW + 2;
   const int hw = H * W;
-  const int b = m0 / hw;
-  const int y0 = (m0 - b * hw) / W;
+  const int tpi = hw / 256, ntx = W / TW;
+  const int b = tile_m / tpi;
+  const int ti = tile_m - b * tpi;
+  const int y0 = (ti / ntx) * TH, x0 = (ti % ntx) * TW;
+  const int m0 = b * hw + y0 * W + x0;          // first output pixel of the tile (see tile_row_m)
   const int ncbs = max(0, cb_end - cb_begin);
   const int nsteps = ncbs * 9;
   // channel blocks are walked in rotated order (k_rotation): the i-th block of this tile is cbv(i)
@@ -1142,7 +1162,7 @@ __global__ __launch_bounds__(768) void conv3x3_patch_ws_kernel(const G160Params 
     auto piece_off = [&](int q) -> int {   // element offset of this lane's source chunk from `img`, -1 = zero padding
       const int r = q * 8 + srow;
       const int py = r / PW, px = r - py * PW;
-      const int y = y0 - 1 + py, x = px - 1;
+      const int y = y0 - 1 + py, x = x0 - 1 + px;
       const int c = (cpos - (r & ~1)) & 7;   // rotation swizzle of the patch rows
       const bool ok = q < P_INSTR && r < prow_count && y >= 0 && y < H && x >= 0 && x < W;
       return ok ? (int)((y * W + x) * p.lda + c * 8) : -1;
@@ -1181,7 +1201,7 @@ __global__ __launch_bounds__(768) void conv3x3_patch_ws_kernel(const G160Params 
       auto piece_pix = [&](int q) -> int {   // pixel index of this lane's patch row inside the sample, -1 = zero padding
         const int r = q * 8 + srow;
         const int py = r / PW, px = r - py * PW;
-        const int y = y0 - 1 + py, x = px - 1;
+        const int y = y0 - 1 + py, x = x0 - 1 + px;
         const bool ok = q < P_INSTR && r < prow_count && y >= 0 && y < H && x >= 0 && x < W;
         return ok ? y * W + x : -1;
       };
@@ -1318,7 +1338,7 @@ __global__ __launch_bounds__(768) void conv3x3_patch_ws_kernel(const G160Params 
 #pragma unroll
     for (int i = 0; i < WMB; ++i) {
       const int ql = wm * 64 + i * 16;
-      const int ty = ql / W, tx = ql - ty * W;
+      const int ty = ql / TW, tx = ql - ty * TW;
       rbase[i] = ty * PW + tx + l15;
     }
     const int sw = (l15 >> 1) & 7;
@@ -1412,11 +1432,11 @@ __global__ __launch_bounds__(768) void conv3x3_patch_ws_kernel(const G160Params 
       }
       block_barrier();                          // (B)
     }
-    epilogue_stage<WMB, 5>(acc, p, lane, m0, n0, wm, wn, split, smem);
+    epilogue_stage<WMB, 5, true>(acc, p, lane, m0, n0, wm, wn, split, smem);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     block_barrier();                          // (C)
   }
-  epilogue_store<256, 5, 768>(p, m0, n0, smem, tid);
+  epilogue_store<256, 5, 768, false, true>(p, m0, n0, smem, tid);
 }
 
 // sum the split-K slabs and apply the epilogue (bias, row vector, activation, residual)
@@ -1663,6 +1683,7 @@ int pfd_gemm160_try(const PfdGemmDesc* d, int variant, int splits, hipStream_t s
   p.B = d->B; p.H = d->H; p.Wd = d->Wd; p.Cin = d->Cin; p.Ho = d->Ho; p.Wo = d->Wo;
   p.tiles_m = p.tiles_n = 0;
   p.kt_per_split = 0;
+  p.pt_w = p.pt_sh = 0;
   p.gn_table = (const float*)d->gn_table; p.A2 = (const half_t*)d->A2; p.lda2 = d->lda2;
   p.gn_c1 = d->gn_c1; p.gn_act = d->gn_act;
   p.ln_in = (const float2*)d->ln_stats; p.ln_cs = (const float*)d->ln_colsum; p.ln_P = d->ln_parts; p.ln_eps = d->ln_eps;
@@ -1688,9 +1709,19 @@ int pfd_gemm160_try(const PfdGemmDesc* d, int variant, int splits, hipStream_t s
   const int tn = p.N / bn;
   auto tiles = [&](int bm) { return (long)((p.M + bm - 1) / bm) * tn; };
   // 3x3 / s1 / p1 convolution on a 16-, 32- or 64-wide image: the patch kernel (variant 0 or 99)
+  // patch tile: whole image rows on 16- / 32- / 64-wide images, TH x 32 or TH x 16 pixel tiles on wider ones whose width
+  // they divide (96-, 48-wide latents of the 768^2 / 512 x 768 configurations; round 3)
+  int pt_w = 0;
+  if (p.ksize == 3 && p.Wd != 16 && p.Wd != 32 && p.Wd != 64) {
+    if (p.Wd % 32 == 0 && p.H % 8 == 0) pt_w = 32;
+    else if (p.Wd % 16 == 0 && p.H % 16 == 0) pt_w = 16;
+  }
+  const bool patch_w = p.Wd == 16 || p.Wd == 32 || p.Wd == 64 || (pt_w != 0 && r3tiles_on());
   if (bn == 160 && (variant == 0 || variant == 99 || variant == 98 || variant == 97) && p.ksize == 3 && p.stride == 1 && p.pad == 1 && !p.ups &&
-      (p.Wd == 16 || p.Wd == 32 || p.Wd == 64) && p.Ho == p.H && p.Wo == p.Wd && p.H % (256 / p.Wd) == 0 &&
-      p.M % 256 == 0 && p.act != PFD_ACT_GEGLU) {
+      patch_w && p.Ho == p.H && p.Wo == p.Wd && (pt_w != 0 || p.H % (256 / p.Wd) == 0) &&
+      p.M % 256 == 0 && ((long)p.H * p.Wd) % 256 == 0 && p.act != PFD_ACT_GEGLU) {
+    p.pt_w = pt_w;
+    p.pt_sh = pt_w == 32 ? 5 : 4;
     // (The 8-wave 128-row ring beats the patch kernel on its smallest problems -- 16384 x 320 x 2880: 50 -> 43 us,
     //  profiles/r03_tile_variants_replay.log -- but the GroupNorm-prologue form lives in the patch kernel only and the two
     //  must stay bit-identical, for 1 ms per batch: not taken.)

@@ -1046,6 +1046,19 @@ int main(int argc, char** argv) {
     printf("SELFTEST %d/%d passed, %d failed\n", g_total - g_fail, g_total, g_fail);
     return g_fail;
   }
+  if (argc > 1 && !strcmp(argv[1], "--patch-wide")) {   // 3x3 patch kernels on 48- / 96-wide images (2-D output tiles)
+    for (int v : {0, 10800, 10900}) {
+      run_gemm_case({0, 160, 0, PFD_ACT_SILU, true, true, true, false, v, 0, 3, 1, 1, 0, 1, 16, 48, 128});   // 16 x 16 tiles
+      run_gemm_case({0, 320, 0, 0, true, true, true, false, v, 0, 3, 1, 1, 0, 2, 8, 96, 64});                 // 8 x 32 tiles
+      run_gemm_case({0, 160, 0, 0, true, false, true, false, v, 0, 3, 1, 1, 0, 1, 32, 96, 128});              // 4 x 3 tiles
+      run_gemm_case({0, 160, 0, 0, true, true, false, false, v, 0, 3, 1, 1, 0, 3, 32, 48, 64});               // several samples
+    }
+    run_gemm_case({0, 160, 0, 0, true, true, true, false, 10802, 0, 3, 1, 1, 0, 1, 16, 96, 256});             // split over channel blocks
+    { GemmCase c{0, 320, 0, 0, true, true, true, false, 0, 0, 3, 1, 1, 0, 2, 16, 96, 128}; c.w_tiled = 1; run_gemm_case(c); }
+    run_gemm_case({0, 160, 0, 0, true, true, false, false, 5400, 0, 3, 1, 1, 0, 1, 16, 48, 128});             // same shape, implicit GEMM
+    printf("SELFTEST %d/%d passed, %d failed\n", g_total - g_fail, g_total, g_fail);
+    return g_fail;
+  }
   if (argc > 1 && !strcmp(argv[1], "--ln")) {
     run_ln_fold_suite();
     printf("SELFTEST %d/%d passed, %d failed\n", g_total - g_fail, g_total, g_fail);
@@ -1201,6 +1214,8 @@ int main(int argc, char** argv) {
     run_gemm_case({0, 320, 0, 0, true, false, false, false, 0, 8, 3, 2, 0, 0, 1, 9, 9, 64});               // pad 0, ld+8
     run_gemm_case({0, 160, 0, 0, true, false, false, false, 0, 0, 1, 1, 0, 0, 2, 6, 6, 128});              // 1x1 as conv
 
+    run_gemm_case({0, 160, 0, PFD_ACT_SILU, true, true, true, false, 0, 0, 3, 1, 1, 0, 1, 16, 48, 128});   // patch kernel, 2-D tiles
+    run_gemm_case({0, 320, 0, 0, true, true, true, false, 0, 0, 3, 1, 1, 0, 2, 8, 96, 64});
     run_ln_fold_suite();
     run_attn_case(2, 2, 128, 128, 40, true);
     run_attn_case(1, 2, 300, 148, 40, false);    // ragged queries and keys (2 full tiles + 20 keys)
