@@ -176,8 +176,10 @@ int32_t pfd_gemm_geglu_group(int32_t N);
  *   O  element (b,i,h,d) at O [b*o_bs + i*ldo + h*D + d]
  * Replaces CrossAttention.forward attention.py:178-201 (einsum, *scale, softmax,
  * einsum and the two rearranges), xformers memory_efficient_attention :264, and
- * nn.MultiheadAttention's core in seecoder.py:133,186.
+ * nn.MultiheadAttention's core in seecoder.py:133,186; with D = 512, H = 1 also the VAE
+ * mid-block AttnBlock.forward autokl_modules.py:186-197 (bmm, *C^-1/2, softmax, bmm).
  * D in {40, 80, 96, 160}; ldq/ldk/ldo % 8 == 0, ldvt/vt_bs % 8 == 0; Nq, Nk arbitrary.
+ * D = 512: H must be 1 and Nk a multiple of 32 (PFD_ESHAPE otherwise); Nq arbitrary.
  * Every V^T row must be readable up to the next multiple of 8 keys (the values there are masked).
  * ---------------------------------------------------------------------------------- */
 typedef struct PfdAttnDesc {

@@ -732,6 +732,189 @@ __global__ __launch_bounds__(NWAVES * 64, (D <= 40 ? 4 : 1)) void attention2_ker
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// d = 512, one head: the VAE mid-block attention (autokl_modules.py:186-197).  Same transposed formulation
+// (S^T = K Q^T, O^T = V^T P^T on v_mfma_f32_32x32x16_f16, online softmax per query = per lane column), but the head does
+// not fit one wave's registers as a whole: a wave keeps the Q fragments of its 32 queries for the full contraction
+// (32 k-steps x 4 VGPRs = 128) and the O^T accumulators of ONE 128-column slice of V (4 tiles x 16 = 64); the four
+// slices are four blocks (blockIdx -> (batch, query tile, slice)), each of which recomputes QK^T -- 4 x 34 + 34 GFLOP per
+// 512^2 image instead of 68, for no [N, N] score matrix in HBM at any resolution.  KV tile = 32 keys: the K image
+// (32 x 520 halfs) and the V^T slice image (128 x 36 halfs) are double buffered in 85 KB of LDS; one block per CU,
+// four waves on four SIMDs, up to 512 unified registers per wave (accumulators in AGPRs).
+// Requires Nk % 32 == 0 (the VAE's token counts are multiples of 64).
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256, 1) void attention512_kernel(const AttnParams p) {
+  constexpr int D = 512, DVC = 128, KV_TILE = 32, NTHR = 256, QB = 128;
+  constexpr int K_LD = D + 8;           // 1040-B rows: an odd multiple of 16 B, conflict-free ds_read_b128 over 32 rows
+  constexpr int VT_LD = KV_TILE + 4;    // 72-B rows: 18 dwords, conflict-free ds_read_b64 over 32 rows
+  constexpr int NS = D / 16;            // 32 k-steps of the QK^T contraction
+  constexpr int ND = DVC / 32;          // 4 O^T tiles
+  constexpr int K_PT = KV_TILE * (D / 8) / NTHR;        // 8 16-byte chunks of K per thread and tile
+  constexpr int V_PT = DVC * (KV_TILE / 8) / NTHR;      // 2 of V^T
+  constexpr int K_TILE_HALFS = KV_TILE * K_LD;
+  constexpr int V_TILE_HALFS = DVC * VT_LD;
+  __shared__ __attribute__((aligned(16))) half_t lds[2 * K_TILE_HALFS + 2 * V_TILE_HALFS];
+  half_t* const Ks = lds;
+  half_t* const Vts = lds + 2 * K_TILE_HALFS;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l31 = lane & 31, hi = lane >> 5;
+  const int nqb = (p.Nq + QB - 1) / QB;
+  const int lin = xcd_remap(blockIdx.x, gridDim.x);
+  const int slice = lin & 3;                     // the four slices of a query tile are neighbours: they read the same K stream
+  const int qb = (lin >> 2) % nqb;
+  const int b = (lin >> 2) / nqb;
+  const int q_row = qb * QB + wave * 32 + l31;
+
+  half8_t qf[NS];
+  {
+    const half_t* qp = p.Q + (long)b * p.q_bs + (long)min(q_row, p.Nq - 1) * p.ldq + hi * 8;
+#pragma unroll
+    for (int s = 0; s < NS; ++s) qf[s] = *reinterpret_cast<const half8_t*>(qp + s * 16);
+  }
+  float16_t o32[ND];
+#pragma unroll
+  for (int i = 0; i < ND; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o32[i][r] = 0.f;
+  float m_run = -INFINITY, l_run = 0.f;
+  const float c = p.scale_log2;
+
+  // staging: thread t moves K chunks t + 256 j (row = chunk / 64, 16-byte column = chunk % 64) and V^T chunks t + 256 j
+  // (row = chunk / 4 of the slice, 8-key column = chunk % 4); the source pointers advance by a constant per tile
+  const half_t* kptr[K_PT];
+  const half_t* vptr[V_PT];
+  int k_lds[K_PT], v_lds[V_PT];
+#pragma unroll
+  for (int j = 0; j < K_PT; ++j) {
+    const int ch = tid + NTHR * j, row = ch >> 6, cc = ch & 63;
+    k_lds[j] = row * K_LD + cc * 8;
+    kptr[j] = p.K + (long)b * p.k_bs + (long)row * p.ldk + cc * 8;
+  }
+#pragma unroll
+  for (int j = 0; j < V_PT; ++j) {
+    const int ch = tid + NTHR * j, d = ch >> 2, cc = ch & 3;
+    v_lds[j] = d * VT_LD + cc * 8;
+    vptr[j] = p.Vt + (long)(slice * DVC + d) * p.ldvt + (long)b * p.vt_bs + cc * 8;
+  }
+  u32x4 kreg[K_PT], vreg[V_PT];
+  auto load_tile = [&]() __attribute__((always_inline)) {
+#pragma unroll
+    for (int j = 0; j < K_PT; ++j) {
+      kreg[j] = *reinterpret_cast<const u32x4*>(kptr[j]);
+      kptr[j] += (long)KV_TILE * p.ldk;
+    }
+#pragma unroll
+    for (int j = 0; j < V_PT; ++j) {
+      vreg[j] = *reinterpret_cast<const u32x4*>(vptr[j]);
+      vptr[j] += KV_TILE;
+    }
+  };
+  auto store_tile = [&](int stage) __attribute__((always_inline)) {
+    half_t* Kd = Ks + stage * K_TILE_HALFS;
+    half_t* Vd = Vts + stage * V_TILE_HALFS;
+#pragma unroll
+    for (int j = 0; j < K_PT; ++j) *reinterpret_cast<u32x4*>(Kd + k_lds[j]) = kreg[j];
+#pragma unroll
+    for (int j = 0; j < V_PT; ++j) {   // 72-byte rows are 8-byte aligned only
+      *reinterpret_cast<uint2*>(Vd + v_lds[j]) = make_uint2(vreg[j][0], vreg[j][1]);
+      *reinterpret_cast<uint2*>(Vd + v_lds[j] + 4) = make_uint2(vreg[j][2], vreg[j][3]);
+    }
+  };
+  auto compute_tile = [&](int stage) __attribute__((always_inline)) {
+    const half_t* Kt = Ks + stage * K_TILE_HALFS;
+    const half_t* Vt = Vts + stage * V_TILE_HALFS;
+    float16_t st;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) st[r] = 0.f;
+    const half_t* kp = Kt + l31 * K_LD + hi * 8;
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+      const half8_t kf = *reinterpret_cast<const half8_t*>(kp + s * 16);
+      st = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[s], st, 0, 0, 0);
+    }
+    float mx = st[0];
+#pragma unroll
+    for (int r = 1; r < 16; ++r) mx = fmaxf(mx, st[r]);
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    const float m_new = fmaxf(m_run, mx);
+    if (__any(m_new > m_run)) {
+      const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c);   // 0 on the first tile, 1 where the maximum stayed
+      l_run *= alpha;
+#pragma unroll
+      for (int i = 0; i < ND; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o32[i][r] *= alpha;
+      m_run = m_new;
+    }
+    const float mc = m_run * c;
+    float rs = 0.f;
+    half8_t pf[2];
+#pragma unroll
+    for (int bb = 0; bb < 2; ++bb)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float e = __builtin_amdgcn_exp2f(fmaf(st[bb * 8 + j], c, -mc));
+        rs += e;
+        pf[bb][j] = (half_t)e;
+      }
+    rs += __shfl_xor(rs, 32, 64);
+    l_run += rs;
+    // P^T slot j of lane half hi in 16-key block bb is key 16 bb + 8 (j / 4) + 4 hi + j % 4: read V^T in that order
+#pragma unroll
+    for (int i = 0; i < ND; ++i) {
+      const half_t* vp = Vt + (i * 32 + l31) * VT_LD + 4 * hi;
+#pragma unroll
+      for (int bb = 0; bb < 2; ++bb) {
+        const half4_t lo4 = *reinterpret_cast<const half4_t*>(vp + bb * 16);
+        const half4_t hi4 = *reinterpret_cast<const half4_t*>(vp + bb * 16 + 8);
+        half8_t vf;
+        vf[0] = lo4[0]; vf[1] = lo4[1]; vf[2] = lo4[2]; vf[3] = lo4[3];
+        vf[4] = hi4[0]; vf[5] = hi4[1]; vf[6] = hi4[2]; vf[7] = hi4[3];
+        o32[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf[bb], o32[i], 0, 0, 0);
+      }
+    }
+  };
+
+  const int ntiles = p.Nk / KV_TILE;
+  load_tile();
+  store_tile(0);
+  __syncthreads();
+  for (int t = 0; t + 1 < ntiles; ++t) {
+    load_tile();
+    __builtin_amdgcn_sched_barrier(0);   // the next tile's loads stay in front of this tile's MFMAs (left alone, the
+    compute_tile(t & 1);                 // scheduler sinks them behind the QK^T chain to shorten their live ranges)
+    store_tile((t & 1) ^ 1);
+    __syncthreads();
+  }
+  compute_tile((ntiles - 1) & 1);
+
+  if (q_row < p.Nq) {
+    const float inv = 1.0f / l_run;
+    half_t* op = p.O + (long)b * p.o_bs + (long)q_row * p.ldo + slice * DVC;
+#pragma unroll
+    for (int i = 0; i < ND; ++i)
+#pragma unroll
+      for (int rq = 0; rq < 4; ++rq) {
+        half4_t o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = (half_t)(o32[i][rq * 4 + e] * inv);
+        *reinterpret_cast<half4_t*>(op + i * 32 + 8 * rq + 4 * hi) = o;
+      }
+  }
+}
+
+static int launch512(const AttnParams& p, hipStream_t s) {
+  if (p.H != 1 || p.Nk % 32 != 0) return PFD_ESHAPE;
+  const bool prof = pfd_prof_on();
+  if (prof)
+    pfd_prof_begin(8, 4.0 * p.B * (double)p.Nq * p.Nk * 512, 2.0 * p.B * 512 * (2.0 * p.Nq + 2.0 * p.Nk), s);
+  dim3 grid(((p.Nq + 127) / 128) * 4 * p.B);
+  hipLaunchKernelGGL(attention512_kernel, grid, dim3(256), 0, s, p);
+  if (prof) pfd_prof_end(s);
+  return pfd_check_launch("pfd_attention_f16");
+}
+
 // PFD_ATTN: 0 = round-2 kernel; 1 = peeled loop, 4 waves, PV on 32x32x16; 2 = + 8 waves per block (d = 40, big grids);
 // 3 = 4 waves + PV on 16x16x32 (d = 40); 4 = 8 waves + PV on 16x16x32 where 8-wave blocks apply, mode 1 elsewhere;
 // 5 = mode 2 + the maximum folded into the QK^T MFMA; 6 (default) = mode 4 + fold.
@@ -797,6 +980,7 @@ extern "C" int pfd_attention_f16(const PfdAttnDesc* d, pfd_stream_t stream) {
     case 80: return launch<80>(p, s);
     case 96: return launch<96>(p, s);
     case 160: return launch<160>(p, s);
+    case 512: return launch512(p, s);
     default: return PFD_ESHAPE;
   }
 }

@@ -1083,6 +1083,17 @@ int main(int argc, char** argv) {
     printf("SELFTEST %d/%d passed, %d failed\n", g_total - g_fail, g_total, g_fail);
     return g_fail;
   }
+  if (argc > 1 && !strcmp(argv[1], "--attn512")) {   // VAE mid-block attention (d = 512, one head): cases + bench
+    run_attn_case(2, 1, 256, 256, 512, false);
+    run_attn_case(1, 1, 200, 96, 512, false);          // ragged query tile, 3 key tiles
+    run_attn_case(1, 1, 128, 32, 512, false);          // a single key tile
+    run_attn_case(2, 1, 128, 512, 512, true);          // Q / K as column slices of one matrix
+    run_attn_case(1, 1, 128, 512, 512, false, 300);    // the maximum jumps in the middle of the stream
+    bench_attn("vae mid attention 64^2 d512", 4, 1, 4096, 4096, 512);
+    bench_attn("vae mid attention 96^2 d512", 2, 1, 9216, 9216, 512);
+    printf("%d checks, %d failed\n", g_total, g_fail);
+    return g_fail ? 1 : 0;
+  }
   if (argc > 1 && !strcmp(argv[1], "--bench-attn")) {
     bench_attn("self-attn 64^2 d40", 8, 8, 4096, 4096, 40);
     bench_attn("self-attn 32^2 d80", 8, 8, 1024, 1024, 80);
@@ -1229,6 +1240,8 @@ int main(int argc, char** argv) {
     run_attn_case(1, 3, 148, 148, 96, false);
     run_attn_case(2, 2, 64, 148, 160, false);
     run_attn_case(1, 1, 256, 320, 160, true);
+    run_attn_case(2, 1, 256, 256, 512, false);   // VAE mid-block attention (attention512_kernel)
+    run_attn_case(1, 1, 200, 96, 512, false);
 
     run_swin_case(1, 14, 17, 2, 0);
     run_swin_case(1, 14, 17, 2, 6);

@@ -7,6 +7,8 @@ Module tree and state-dict keys follow the reference's lib/model_zoo/autokl_modu
 swish; both are fused into one kernel, and nearest-2x upsampling is a gather inside the
 following conv.  The unused classes of that file (:216-365, :571-835) are out of scope.
 """
+import os
+
 import numpy as np
 import torch
 import torch.nn as nn
@@ -68,12 +70,12 @@ class ResnetBlock(nn.Module):
 
 
 class AttnBlock(nn.Module):
-    """single-head spatial self-attention with d = C = 512 (autokl_modules.py:186-197): scores via GEMM, scaled
-    row softmax, PV via GEMM against the transposed V the v-projection writes directly.  The [N, N] score
-    matrix is materialised in fp16 -- NOT a flash kernel (the d = 512 accumulator does not fit the register
-    budget of pfd_attention_f16's one-wave-per-32-queries layout) -- but only for `ROWS` query rows at a time:
-    at the 36 864 tokens of a 1536^2 output that is 0.3 GB of scratch instead of the 2.7 GB per image the
-    reference materialises (in fp32).  The block is 34 of the decoder's 2514 GFLOP per 512^2 image."""
+    """single-head spatial self-attention with d = C = 512 (autokl_modules.py:186-197): ONE fused launch
+    (pfd_attention_f16 with D = 512 -> attention512_kernel: QK^T, online softmax and PV per 128-query tile, four
+    128-column slices of V per tile) on Q / K from the 1x1 convolutions and the transposed V the v-projection GEMM writes
+    directly.  No [N, N] score matrix exists at any resolution (the reference materialises it in fp32: 2.7 GB per image
+    at the 36 864 tokens of a 1536^2 output).  PFD_VAE_ATTN=gemm selects the round-1/2 form for A/B measurements:
+    scores via GEMM in fp16 for `ROWS` query rows at a time, row softmax, PV via GEMM."""
     ROWS = 4096
 
     def __init__(self, in_channels):
@@ -95,8 +97,12 @@ class AttnBlock(nn.Module):
         k = self.k.hip(hn).view(B, N, Cc)
         wv, bv = self.v._pk()
         vt = ops.gemm(wv, hn.view(B * N, Cc), bias=bv, bias_per_row=True)      # [C, B*N]
-        o = torch.empty((B, N, Cc), dtype=torch.float16, device=x.device)
         scale = float(int(Cc) ** (-0.5))
+        if Cc == 512 and os.environ.get("PFD_VAE_ATTN", "fused") != "gemm":
+            o = ops.attention(q, k, vt, B, 1, N, N, Cc, scale, ldq=Cc, ldk=Cc, ldvt=B * N, q_bs=N * Cc, k_bs=N * Cc,
+                              vt_bs=N)
+            return self.proj_out.hip(o.view(B, H, W_, Cc), res=x)
+        o = torch.empty((B, N, Cc), dtype=torch.float16, device=x.device)
         rows = min(N, self.ROWS)
         s = torch.empty((rows, N), dtype=torch.float16, device=x.device)        # one scratch for all chunks
         for b in range(B):

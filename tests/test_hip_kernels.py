@@ -170,7 +170,8 @@ def test_groupnorm_concat_and_layernorm():
 
 
 @pytest.mark.parametrize("B,H,Nq,Nk,D", [(2, 8, 64, 64, 160), (2, 8, 300, 148, 40), (1, 8, 144, 1000, 96),
-                                          (1, 8, 148, 148, 96), (3, 8, 256, 256, 80)])
+                                          (1, 8, 148, 148, 96), (3, 8, 256, 256, 80),
+                                          (2, 1, 320, 256, 512)])   # the last: VAE mid-block attention (K18)
 def test_attention(B, H, Nq, Nk, D):
     from lib.hip import ops
     Cd = H * D
