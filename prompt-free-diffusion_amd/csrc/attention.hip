@@ -743,8 +743,9 @@ __global__ __launch_bounds__(NWAVES * 64, (D <= 40 ? 4 : 1)) void attention2_ker
 // four waves on four SIMDs, up to 512 unified registers per wave (accumulators in AGPRs).
 // Requires Nk % 32 == 0 (the VAE's token counts are multiples of 64).
 // ------------------------------------------------------------------------------------------------
+template <int NSL>   // V column slices per query tile: 4 (128 columns, 64 accumulator registers) or 2 (256 columns, 128)
 __global__ __launch_bounds__(256, 1) void attention512_kernel(const AttnParams p) {
-  constexpr int D = 512, DVC = 128, KV_TILE = 32, NTHR = 256, QB = 128;
+  constexpr int D = 512, DVC = D / NSL, KV_TILE = 32, NTHR = 256, QB = 128;
   constexpr int K_LD = D + 8;           // 1040-B rows: an odd multiple of 16 B, conflict-free ds_read_b128 over 32 rows
   constexpr int VT_LD = KV_TILE + 4;    // 72-B rows: 18 dwords, conflict-free ds_read_b64 over 32 rows
   constexpr int NS = D / 16;            // 32 k-steps of the QK^T contraction
@@ -761,9 +762,10 @@ __global__ __launch_bounds__(256, 1) void attention512_kernel(const AttnParams p
   const int l31 = lane & 31, hi = lane >> 5;
   const int nqb = (p.Nq + QB - 1) / QB;
   const int lin = xcd_remap(blockIdx.x, gridDim.x);
-  const int slice = lin & 3;                     // the four slices of a query tile are neighbours: they read the same K stream
-  const int qb = (lin >> 2) % nqb;
-  const int b = (lin >> 2) / nqb;
+  constexpr int SL_SH = NSL == 4 ? 2 : 1;
+  const int slice = lin & (NSL - 1);             // the slices of a query tile are neighbours: they read the same K stream
+  const int qb = (lin >> SL_SH) % nqb;
+  const int b = (lin >> SL_SH) / nqb;
   const int q_row = qb * QB + wave * 32 + l31;
 
   half8_t qf[NS];
@@ -909,8 +911,13 @@ static int launch512(const AttnParams& p, hipStream_t s) {
   const bool prof = pfd_prof_on();
   if (prof)
     pfd_prof_begin(8, 4.0 * p.B * (double)p.Nq * p.Nk * 512, 2.0 * p.B * 512 * (2.0 * p.Nq + 2.0 * p.Nk), s);
-  dim3 grid(((p.Nq + 127) / 128) * 4 * p.B);
-  hipLaunchKernelGGL(attention512_kernel, grid, dim3(256), 0, s, p);
+  // PFD_ATTN512_SLICES: 4 (default) or 2 -- two 256-column slices recompute QK^T twice instead of four times and keep
+  // 128 accumulator registers per wave in AGPRs (256 + 129 registers, no scratch).  One 512-column slice (256 accumulator
+  // registers) crashes hipcc 7.2's register allocator, so it is not instantiated.
+  static const int nsl = getenv("PFD_ATTN512_SLICES") && atoi(getenv("PFD_ATTN512_SLICES")) == 2 ? 2 : 4;
+  dim3 grid(((p.Nq + 127) / 128) * nsl * p.B);
+  if (nsl == 2) hipLaunchKernelGGL(attention512_kernel<2>, grid, dim3(256), 0, s, p);
+  else hipLaunchKernelGGL(attention512_kernel<4>, grid, dim3(256), 0, s, p);
   if (prof) pfd_prof_end(s);
   return pfd_check_launch("pfd_attention_f16");
 }
