@@ -182,7 +182,7 @@ def main():
 
     def barrier():
         if world > 1:
-            dist.barrier()
+            dist.barrier(device_ids=[local])   # (explicit device: no guess from the rank, no warning, no wrong-GPU context)
         torch.cuda.synchronize()
 
     barrier()
