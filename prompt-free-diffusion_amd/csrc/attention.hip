@@ -911,10 +911,13 @@ static int launch512(const AttnParams& p, hipStream_t s) {
   const bool prof = pfd_prof_on();
   if (prof)
     pfd_prof_begin(8, 4.0 * p.B * (double)p.Nq * p.Nk * 512, 2.0 * p.B * 512 * (2.0 * p.Nq + 2.0 * p.Nk), s);
-  // PFD_ATTN512_SLICES: 4 (default) or 2 -- two 256-column slices recompute QK^T twice instead of four times and keep
-  // 128 accumulator registers per wave in AGPRs (256 + 129 registers, no scratch).  One 512-column slice (256 accumulator
-  // registers) crashes hipcc 7.2's register allocator, so it is not instantiated.
-  static const int nsl = getenv("PFD_ATTN512_SLICES") && atoi(getenv("PFD_ATTN512_SLICES")) == 2 ? 2 : 4;
+  // PFD_ATTN512_SLICES: 2 (default since round 4) or 4 -- two 256-column slices recompute QK^T twice instead of four times
+  // and keep 128 accumulator registers per wave in AGPRs (256 + 129 registers, no scratch): 0.363 vs 0.547 ms at the C2
+  // shape, 1.39 vs 1.61 ms at 96^2 (profiles/r03_k18_vae_attention512.log).  One 512-column slice (256 accumulator
+  // registers) crashes hipcc 7.2's register allocator, so it is not instantiated.  Read per launch (once per decoded
+  // batch), so the GPU suite exercises both instantiations in one process.
+  const char* nsl_env = getenv("PFD_ATTN512_SLICES");
+  const int nsl = nsl_env && atoi(nsl_env) == 4 ? 4 : 2;
   dim3 grid(((p.Nq + 127) / 128) * nsl * p.B);
   if (nsl == 2) hipLaunchKernelGGL(attention512_kernel<2>, grid, dim3(256), 0, s, p);
   else hipLaunchKernelGGL(attention512_kernel<4>, grid, dim3(256), 0, s, p);

@@ -701,7 +701,9 @@ __global__ __launch_bounds__(WAVES_M * 128) void gemm160_kernel(const G160Params
 //   group 0:    L(s,0)    M(s,0)    L(s,1)    M(s,1)    L(s+1,0)
 //   group 1:    M(s-1,1)  L(s,0)    M(s,0)    L(s,1)    M(s,1)
 //   loaders:    issue tile s+1 (its buffer was last read in interval 4s-1), then wait for it before barrier 4s+4
-template <bool CONV, int NT, bool PP>
+// NST: operand stages.  2 = one K tile ahead (loaders wait vmcnt(0) per K step); 3 = two K tiles ahead with a counted
+// vmcnt (round 4; 156 KiB of LDS at the 160-wide tile), lock-step consumers only.
+template <bool CONV, int NT, bool PP, int NST = 2>
 __global__ __launch_bounds__(768) void gemm160ws_kernel(const G160Params p) {
   constexpr int WMB = 4, NCW = 8, NLW = 4;
   constexpr int BN = 32 * NT, BM = 256;
@@ -709,7 +711,9 @@ __global__ __launch_bounds__(768) void gemm160ws_kernel(const G160Params p) {
   constexpr int A_PL = A_INSTR / NLW, B_PL = B_INSTR / NLW;      // pieces per loader wave: 8 + 5 | 4
   static_assert(A_INSTR % NLW == 0 && B_INSTR % NLW == 0, "pieces must split evenly over the loader waves");
   constexpr int STAGE = (BM + BN) * ROWB;
-  constexpr int SMEM = 2 * STAGE;
+  constexpr int SMEM = NST * STAGE;
+  static_assert(NST == 2 || (NST == 3 && !PP), "the 3-stage ring serves the lock-step consumers");
+  static_assert(SMEM <= 160 * 1024, "LDS");
   static_assert(BM * stage_row_bytes(BN) <= SMEM, "the epilogue's staging image reuses the operand ring");
   __shared__ __attribute__((aligned(1024))) char smem[SMEM];
 
@@ -828,6 +832,20 @@ __global__ __launch_bounds__(768) void gemm160ws_kernel(const G160Params p) {
         }
       }
     };
+    if constexpr (NST == 3) {
+      constexpr int PER_STEP = A_PL + B_PL;   // 13 (12): the pieces of tile s + 1 may stay in flight behind barrier (A) of s
+      static_assert(PER_STEP < 16, "one s_waitcnt immediate");
+      if (nsteps > 0) issue(0);
+      if (nsteps > 1) issue(1);
+      int nst = 2;
+      for (int s = 0; s < nsteps; ++s) {
+        if (s + 1 < nsteps) __builtin_amdgcn_s_waitcnt(0x0F70 | PER_STEP);
+        else __builtin_amdgcn_s_waitcnt(0x0F70);
+        block_barrier();                      // (A) tile s complete; every consumer is done reading tile s - 1
+        if (s + 2 < nsteps) issue(nst);       // into the stage tile s - 1 just left
+        if (++nst == 3) nst = 0;
+      }
+    } else {
     if (nsteps > 0) issue(0);
     for (int s = 0; s < nsteps; ++s) {
       __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): this wave's pieces of K tile s are in LDS
@@ -838,6 +856,7 @@ __global__ __launch_bounds__(768) void gemm160ws_kernel(const G160Params p) {
         block_barrier();
         block_barrier();
       }
+    }
     }
     block_barrier();                        // (B) consumers finished reading the last tile: LDS is free
     block_barrier();                        // (C) the staging image is written
@@ -893,9 +912,11 @@ __global__ __launch_bounds__(768) void gemm160ws_kernel(const G160Params p) {
       }
       if (!g1) block_barrier();               // (B)
     } else {
+      int cst = 0;
       for (int s = 0; s < nsteps; ++s) {
         block_barrier();                      // (A)
-        const char* base = smem + (s & 1) * STAGE;
+        const char* base = smem + cst * STAGE;
+        if (++cst == NST) cst = 0;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
           const int off = ks ? off_k1 : off_k0;
@@ -1094,13 +1115,18 @@ __global__ __launch_bounds__(512) void conv3x3_patch_kernel(const G160Params p) 
 // ------------------------------------------------------------------------------------------------
 // GN: 0 = plain input, 1 = GroupNorm affine map in the staging path, 2 = affine map + SiLU
 // PP: ping-pong consumer groups, four barrier intervals per tap (see gemm160ws_kernel)
-template <int GN, bool PP>
+// NWS: weight stages.  2 = one tap ahead, loaders wait vmcnt(0) per tap (a tap's 20 KB weight tile has one tap of MFMA
+//      work, ~0.55 us, to arrive -- less than the loaded LDS-DMA round trip, so every tap ends in a wait);
+//      3 = two taps ahead with counted vmcnt (round 4): the whole 160 KiB of LDS (2 patches + 3 weight tiles).
+template <int GN, bool PP, int NWS = 2>
 __global__ __launch_bounds__(768) void conv3x3_patch_ws_kernel(const G160Params p) {
   constexpr int NCW = 8, NLW = 4, WMB = 4;
   constexpr int PATCH_BYTES = PATCH_ROWS * ROWB;  // 51200
   constexpr int WT_BYTES = BN * ROWB;             // 20480
   constexpr int OFF_W = 2 * PATCH_BYTES;
-  constexpr int SMEM = OFF_W + 2 * WT_BYTES;      // 143360
+  constexpr int SMEM = OFF_W + NWS * WT_BYTES;    // 143360 | 163840
+  static_assert(NWS == 2 || (NWS == 3 && GN == 0 && !PP), "the 3-stage weight ring serves the plain lock-step form");
+  static_assert(SMEM <= 160 * 1024, "LDS");
   constexpr int P_INSTR = PATCH_ROWS / 8;          // 50 DMA pieces per patch
   __shared__ __attribute__((aligned(1024))) char smem[SMEM];
 
@@ -1298,6 +1324,53 @@ __global__ __launch_bounds__(768) void conv3x3_patch_ws_kernel(const G160Params 
           pp_barriers();
         }
       }
+    } else if constexpr (NWS == 3) {
+      // Two taps of weights in flight.  Patch pieces of the NEXT channel block: slots s = 2 tap + {0, 1} for tap <= 6,
+      // piece q = 4 s + lw (56 slots for 50 pieces; a slot past the patch re-issues piece q - 8, which this loader
+      // issued one tap earlier -- same source, same destination -- so every loader issues the SAME number of pieces
+      // per tap and the counted waits below are wave-independent constants).
+      // Wait before barrier (A) of step t: W(t) must have landed.  Issued after W(t): P(t-2), W(t+1), P(t-1), so
+      // vmcnt may stay at np(t-2) + 5 + np(t-1) (np = 2 on taps 0..6 of a block that has a successor, else 0);
+      // at tap 0 that is 5: everything older than W(t+1), i.e. the whole patch of this block, has landed too.
+      int off_p[14], q_p[14];
+#pragma unroll
+      for (int sl = 0; sl < 14; ++sl) {
+        int q = 4 * sl + lw;
+        if (q >= P_INSTR) q -= 8;
+        q_p[sl] = q;
+        off_p[sl] = piece_off(q);
+      }
+      if (nsteps > 0) {
+#pragma unroll
+        for (int sl = 0; sl < 14; ++sl)
+          if (4 * sl + lw < P_INSTR) issue_patch(0, cbv(0), q_p[sl], off_p[sl]);
+        issue_w(0, 0, cbv(0));
+        issue_w(1, 1, cbv(0));
+      }
+      for (int ci = 0; ci < ncbs; ++ci) {
+        const int cb = cbv(ci);
+        const int pbuf = ci & 1;
+        const bool more = ci + 1 < ncbs;
+        const int cb1 = more ? cbv(ci + 1) : cb;
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+          if (more) {
+            if (tap == 0) __builtin_amdgcn_s_waitcnt(0x0F70 | 5);
+            else if (tap == 1 || tap == 8) __builtin_amdgcn_s_waitcnt(0x0F70 | 7);
+            else __builtin_amdgcn_s_waitcnt(0x0F70 | 9);
+          } else {
+            if (tap <= 7) __builtin_amdgcn_s_waitcnt(0x0F70 | 5);
+            else __builtin_amdgcn_s_waitcnt(0x0F70);
+          }
+          block_barrier();                      // (A) W(t) complete; every consumer is done with step t - 1
+          if (tap + 2 < 9) issue_w((tap + 2) % 3, tap + 2, cb);
+          else if (more) issue_w((tap + 2) % 3, tap + 2 - 9, cb1);
+          if (more && tap <= 6) {
+            issue_patch(pbuf ^ 1, cb1, q_p[2 * tap], off_p[2 * tap]);
+            issue_patch(pbuf ^ 1, cb1, q_p[2 * tap + 1], off_p[2 * tap + 1]);
+          }
+        }
+      }
     } else {
       if (nsteps > 0) {
 #pragma unroll
@@ -1424,7 +1497,8 @@ __global__ __launch_bounds__(768) void conv3x3_patch_ws_kernel(const G160Params 
                 for (int j = 0; j < 5; ++j)
                   acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[j], af[i], acc[i][j], 0, 0, 0);
             }
-            stage ^= 1;
+            if constexpr (NWS == 2) stage ^= 1;
+            else if (++stage == NWS) stage = 0;
             toff += 1;
           }
           toff += PW - 3;
@@ -1528,6 +1602,17 @@ inline bool pp_on() {
   return on;
 }
 
+// 3-stage weight ring of the wave-specialised patch kernel (round 4): PFD_PATCH_RING=0 keeps the 2-stage form
+inline bool patch_ring_on() {
+  static const bool on = !(getenv("PFD_PATCH_RING") && atoi(getenv("PFD_PATCH_RING")) == 0);
+  return on;
+}
+// same for the loader-wave implicit-GEMM kernel (gemm160ws_kernel): PFD_WS_RING=0 keeps two stages
+inline bool ws_ring_on() {
+  static const bool on = !(getenv("PFD_WS_RING") && atoi(getenv("PFD_WS_RING")) == 0);
+  return on;
+}
+
 // PFD_R3TILES=0 keeps the round-2 tile choice (A/B runs of the round-3 rules in pfd_gemm160_try)
 inline bool r3tiles_on() {
   static const bool on = !(getenv("PFD_R3TILES") && atoi(getenv("PFD_R3TILES")) == 0);
@@ -1575,7 +1660,8 @@ int launch160(G160Params& p, int bucket, hipStream_t s) {
 }
 
 template <int NT>
-int launch160ws(G160Params& p, int bucket, hipStream_t s, bool pp) {
+// mode: 0 = two stages, 1 = ping-pong consumer groups, 2 = 3-stage ring
+int launch160ws(G160Params& p, int bucket, hipStream_t s, int pp) {
   p.tiles_m = (p.M + 255) / 256;
   p.tiles_n = p.N / (32 * NT);
   p.nmajor = pick_nmajor(p);
@@ -1591,10 +1677,12 @@ int launch160ws(G160Params& p, int bucket, hipStream_t s, bool pp) {
     pfd_prof_begin(bucket, 2.0 * p.M * p.N * p.K, a_bytes + 2.0 * p.N * p.K + 2.0 * p.M * n_out * (p.R ? 2 : 1), s);
   }
   if (p.ksize > 0) {
-    if (pp) hipLaunchKernelGGL((gemm160ws_kernel<true, NT, true>), grid, dim3(768), 0, s, p);
+    if (pp == 1) hipLaunchKernelGGL((gemm160ws_kernel<true, NT, true>), grid, dim3(768), 0, s, p);
+    else if (pp == 2) hipLaunchKernelGGL((gemm160ws_kernel<true, NT, false, 3>), grid, dim3(768), 0, s, p);
     else hipLaunchKernelGGL((gemm160ws_kernel<true, NT, false>), grid, dim3(768), 0, s, p);
   } else {
-    if (pp) hipLaunchKernelGGL((gemm160ws_kernel<false, NT, true>), grid, dim3(768), 0, s, p);
+    if (pp == 1) hipLaunchKernelGGL((gemm160ws_kernel<false, NT, true>), grid, dim3(768), 0, s, p);
+    else if (pp == 2) hipLaunchKernelGGL((gemm160ws_kernel<false, NT, false, 3>), grid, dim3(768), 0, s, p);
     else hipLaunchKernelGGL((gemm160ws_kernel<false, NT, false>), grid, dim3(768), 0, s, p);
   }
   if (p.splits > 1) {
@@ -1609,7 +1697,7 @@ int launch160ws(G160Params& p, int bucket, hipStream_t s, bool pp) {
   return pfd_check_launch("pfd_gemm_f16(wave-specialised)");
 }
 
-// ws: 0 = 8-wave kernel, 1 = + 4 loader waves, 2 = + ping-pong consumer groups
+// ws: 0 = 8-wave kernel, 1 = + 4 loader waves, 2 = + ping-pong consumer groups, 3 = loader waves + 3-stage weight ring
 int launch_patch(G160Params& p, hipStream_t s, int ws) {
   p.tiles_m = p.M / 256;
   p.tiles_n = p.N / BN;
@@ -1625,6 +1713,7 @@ int launch_patch(G160Params& p, hipStream_t s, int ws) {
                    2.0 * p.B * p.H * p.Wd * p.Cin + 2.0 * p.N * p.K + 2.0 * p.M * p.N * (p.R ? 2 : 1), s);
   if (p.gn_table && p.gn_act == PFD_ACT_SILU) hipLaunchKernelGGL((conv3x3_patch_ws_kernel<2, false>), grid, dim3(768), 0, s, p);
   else if (p.gn_table) hipLaunchKernelGGL((conv3x3_patch_ws_kernel<1, false>), grid, dim3(768), 0, s, p);
+  else if (ws == 3) hipLaunchKernelGGL((conv3x3_patch_ws_kernel<0, false, 3>), grid, dim3(768), 0, s, p);
   else if (ws == 2) hipLaunchKernelGGL((conv3x3_patch_ws_kernel<0, true>), grid, dim3(768), 0, s, p);
   else if (ws) hipLaunchKernelGGL((conv3x3_patch_ws_kernel<0, false>), grid, dim3(768), 0, s, p);
   else hipLaunchKernelGGL(conv3x3_patch_kernel, grid, dim3(512), 0, s, p);
@@ -1691,11 +1780,11 @@ int pfd_gemm160_try(const PfdGemmDesc* d, int variant, int splits, hipStream_t s
   if (p.ln_in) {   // LayerNorm fold: plain linear, statistics over K = ln_parts slices of 160 columns
     if (d->ksize > 0 || !p.ln_cs || p.ln_P < 1 || p.ln_P > 8 || p.ln_P * 160 != d->K) return 1;
     if ((reinterpret_cast<uintptr_t>(p.ln_in) & 7) || (reinterpret_cast<uintptr_t>(p.ln_cs) & 15)) return 1;
-    if (variant == 48 || variant == 49) return 1;   // the loader-wave kernels serve convolutions
+    if (variant == 47 || variant == 48 || variant == 49) return 1;   // the loader-wave kernels serve convolutions
   }
   if (p.ln_out) {  // statistics of the output rows for the consumer's fold
     if (bn != 160 || d->ksize > 0 || d->act == PFD_ACT_GEGLU || d->Ct || (reinterpret_cast<uintptr_t>(p.ln_out) & 7)) return 1;
-    if (variant == 48 || variant == 49) return 1;
+    if (variant == 47 || variant == 48 || variant == 49) return 1;
   }
   if (p.gn_table) {   // GroupNorm prologue: patch kernel or nothing (validated here, PFD_ESHAPE by the caller otherwise)
     if (bn != 160 || (variant != 0 && variant != 98)) return 1;
@@ -1717,7 +1806,7 @@ int pfd_gemm160_try(const PfdGemmDesc* d, int variant, int splits, hipStream_t s
     else if (p.Wd % 16 == 0 && p.H % 16 == 0) pt_w = 16;
   }
   const bool patch_w = p.Wd == 16 || p.Wd == 32 || p.Wd == 64 || (pt_w != 0 && r3tiles_on());
-  if (bn == 160 && (variant == 0 || variant == 99 || variant == 98 || variant == 97) && p.ksize == 3 && p.stride == 1 && p.pad == 1 && !p.ups &&
+  if (bn == 160 && (variant == 0 || variant == 99 || variant == 98 || variant == 97 || variant == 96) && p.ksize == 3 && p.stride == 1 && p.pad == 1 && !p.ups &&
       patch_w && p.Ho == p.H && p.Wo == p.Wd && (pt_w != 0 || p.H % (256 / p.Wd) == 0) &&
       p.M % 256 == 0 && ((long)p.H * p.Wd) % 256 == 0 && p.act != PFD_ACT_GEGLU) {
     p.pt_w = pt_w;
@@ -1741,10 +1830,11 @@ int pfd_gemm160_try(const PfdGemmDesc* d, int variant, int splits, hipStream_t s
     // default: the wave-specialised form (4 loader waves): +4 ... 13 % on every patch-eligible conv of the UNet, most
     // on the long-K ones (32768 x 320 x 8640: 149 -> 131 us = 1435 TF; profiles/r02_patch_ws_ab.log), with ping-pong
     // consumer groups (round 3); 99 forces the 8-wave form, 98 loader waves + lock-step consumers, 97 ping-pong
-    const int ws = variant == 99 ? 0 : variant == 98 ? 1 : variant == 97 ? 2 : (pp_on() ? 2 : 1);
+    // 96 forces the 3-stage weight ring (two taps of weights in flight, counted vmcnt; round 4); PFD_PATCH_RING=0/1 picks the default
+    const int ws = variant == 99 ? 0 : variant == 98 ? 1 : variant == 97 ? 2 : variant == 96 ? 3 : (pp_on() ? 2 : patch_ring_on() ? 3 : 1);
     return launch_patch(p, s, ws) < 0 ? PFD_ELAUNCH : 0;
   }
-  if (variant == 99 || variant == 98 || variant == 97 || p.gn_table) return 1;
+  if (variant == 99 || variant == 98 || variant == 97 || variant == 96 || p.gn_table) return 1;
   const bool auto_variant = variant == 0;
   const int nk_all = p.K / BK;
   if (auto_variant) {
@@ -1770,7 +1860,7 @@ int pfd_gemm160_try(const PfdGemmDesc* d, int variant, int splits, hipStream_t s
     // implicit-GEMM convolutions (stride 2, fused upsample, widths the patch kernel does not take) run long K loops
     // of 53 KB stages: with the DMA pieces on four dedicated loader waves they gain 5-17 % (32768 x 640 x 5760
     // upsample conv: 225 -> 192 us = 1260 TF); the short-K linears do not (profiles/r02_wave_specialised_ab.log)
-    if (variant == 44 && p.ksize > 0) variant = pp_on() ? 49 : 48;
+    if (variant == 44 && p.ksize > 0) variant = pp_on() ? 49 : ws_ring_on() ? 47 : 48;
     // round 3 (cold replay under every forced variant, profiles/r03_tile_variants_replay.log): the 128-row tile on EIGHT
     // waves (4 x 2 wave layout, wave tile 32 x 80; variants 82 / 83) instead of four beats the 4-wave form wherever
     // that was chosen (qkv 8192 x 1920 x 640: 32.5 -> 27.3 us, 32768 x 960 x 320: 34.3 -> 31.8, ff-out 8192 x 640 x 2560
@@ -1786,13 +1876,13 @@ int pfd_gemm160_try(const PfdGemmDesc* d, int variant, int splits, hipStream_t s
       else if (variant == 25) variant = 83;
     }
   }
-  const int bm = (variant == 44 || variant == 48 || variant == 49 || variant == 84) ? 256
+  const int bm = (variant == 44 || variant == 48 || variant == 49 || variant == 47 || variant == 84) ? 256
                  : (variant == 24 || variant == 25 || variant == 82 || variant == 83) ? 128 : 64;
   if (splits == 0) {
     splits = 1;
     const long tl = tiles(bm);
     const int nk = nk_all;
-    if (p.act != PFD_ACT_GEGLU && d->ws && (variant == 44 || variant == 48 || variant == 49) && tl < 200 && nk >= 48 &&
+    if (p.act != PFD_ACT_GEGLU && d->ws && (variant == 44 || variant == 48 || variant == 49 || variant == 47) && tl < 200 && nk >= 48 &&
         (size_t)2 * p.M * p.N * 4 <= d->ws_bytes) {
       splits = 2;  // 128 tiles of 256x160: two K halves fill the chip (758 vs 579 TF at 640->640 @32^2)
     } else if (p.act != PFD_ACT_GEGLU && d->ws && (variant == 24 || variant == 25 || variant == 82 || variant == 83) && tl < 256) {
@@ -1820,9 +1910,10 @@ int pfd_gemm160_try(const PfdGemmDesc* d, int variant, int splits, hipStream_t s
     if (variant == 82 && (p.ksize == 0 || (p.stride == 1 && !p.ups)) && tiles(128) <= 256 && nk_split >= 6) variant = 83;
   }
   const int conv = p.ksize > 0 ? 1 : 0;
-  if (variant == 48 || variant == 49) {   // 8 MFMA waves + 4 loader waves (49: ping-pong consumer groups)
-    if (bn == 128) return launch160ws<4>(p, 12 + 4 * conv, s, variant == 49) < 0 ? PFD_ELAUNCH : 0;
-    return launch160ws<5>(p, 12 + 4 * conv, s, variant == 49) < 0 ? PFD_ELAUNCH : 0;
+  if (variant == 48 || variant == 49 || variant == 47) {   // 8 MFMA waves + 4 loader waves (49: ping-pong consumer groups, 47: 3-stage ring)
+    const int mode = variant == 49 ? 1 : variant == 47 ? 2 : 0;
+    if (bn == 128) return launch160ws<4>(p, 12 + 4 * conv, s, mode) < 0 ? PFD_ELAUNCH : 0;
+    return launch160ws<5>(p, 12 + 4 * conv, s, mode) < 0 ? PFD_ELAUNCH : 0;
   }
   if (bn == 128) {
     switch (variant) {

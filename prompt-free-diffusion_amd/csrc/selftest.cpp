@@ -1046,6 +1046,31 @@ int main(int argc, char** argv) {
     printf("SELFTEST %d/%d passed, %d failed\n", g_total - g_fail, g_total, g_fail);
     return g_fail;
   }
+  if (argc > 1 && !strcmp(argv[1], "--r4")) {   // round-4 kernels: 3-stage weight ring of the patch kernel (96), 3-stage loader-wave GEMM (47)
+    for (int v : {10600, 10800}) {
+      run_gemm_case({0, 320, 0, 0, true, true, true, false, v, 0, 3, 1, 1, 0, 2, 16, 16, 320});               // 16^2, 5 channel blocks
+      run_gemm_case({0, 160, 0, PFD_ACT_SILU, true, true, true, false, v, 0, 3, 1, 1, 0, 1, 32, 32, 128});    // 32^2, 2 blocks
+      run_gemm_case({0, 320, 0, 0, true, false, true, false, v, 0, 3, 1, 1, 0, 1, 64, 64, 64});               // 64^2, ONE block (no successor)
+      run_gemm_case({0, 160, 0, 0, true, true, false, false, v, 0, 3, 1, 1, 0, 3, 16, 16, 192});              // several samples, 3 blocks
+      run_gemm_case({0, 160, 0, 0, true, true, true, false, v, 0, 3, 1, 1, 0, 1, 16, 48, 128});               // 2-D tiles (48-wide)
+      run_gemm_case({0, 320, 0, 0, true, true, true, false, v, 0, 3, 1, 1, 0, 2, 8, 96, 64});                 // 2-D tiles (96-wide)
+      run_gemm_case({0, 160, 0, 0, true, true, true, false, v + 2, 0, 3, 1, 1, 0, 1, 16, 16, 256});           // split over channel blocks (2 x 2)
+      run_gemm_case({0, 160, 0, 0, true, true, true, false, v + 3, 0, 3, 1, 1, 0, 1, 16, 16, 448});           // uneven split (3, 2, 2)
+    }
+    for (int v : {5700, 5800}) {
+      run_gemm_case({0, 320, 0, 0, true, true, true, false, v, 0, 3, 1, 1, 0, 2, 16, 16, 128});               // 3x3 s1
+      run_gemm_case({0, 160, 0, 0, true, false, false, false, v, 0, 3, 2, 1, 0, 2, 16, 16, 128});             // stride 2
+      run_gemm_case({0, 320, 0, 0, true, false, false, false, v, 0, 3, 1, 1, 1, 1, 8, 8, 192});               // fused nearest-2x upsample
+      run_gemm_case({0, 160, 0, 0, true, false, false, false, v, 0, 3, 1, 1, 0, 1, 16, 16, 64});              // one K tile per tap, 9 steps
+      run_gemm_case({300, 320, 64, 0, true, true, false, false, v});                                        // ONE K step
+      run_gemm_case({300, 320, 128, PFD_ACT_SILU, true, true, true, false, v});                             // two K steps
+      run_gemm_case({1100, 320, 1024, 0, true, true, true, false, v});
+      run_gemm_case({520, 256, 512, 0, true, true, false, false, v});                                       // 128-wide tiles
+      run_gemm_case({0, 160, 0, 0, true, true, false, false, v + 2, 0, 3, 1, 1, 0, 1, 16, 16, 1024});         // split-K 2
+    }
+    printf("SELFTEST %d/%d passed, %d failed\n", g_total - g_fail, g_total, g_fail);
+    return g_fail;
+  }
   if (argc > 1 && !strcmp(argv[1], "--patch-wide")) {   // 3x3 patch kernels on 48- / 96-wide images (2-D output tiles)
     for (int v : {0, 10800, 10900}) {
       run_gemm_case({0, 160, 0, PFD_ACT_SILU, true, true, true, false, v, 0, 3, 1, 1, 0, 1, 16, 48, 128});   // 16 x 16 tiles

@@ -160,8 +160,12 @@ class Linear(nn.Linear, _Packed):
         return self._packed("w", lambda: (pack_matrix(self.weight), pack_vec(self.bias)), self.weight, self.bias)
 
     def _pk_ln(self, norm):
-        """(W o gamma, column sums, b') for `norm` folded into this Linear (fold_layernorm)"""
-        return self._packed(("ln", id(norm)), lambda: fold_layernorm(*self._pk(), norm.weight, norm.bias),
+        """(W o gamma, column sums, b') for `norm` folded into this Linear (fold_layernorm).  A Linear is always folded
+        with the same LayerNorm (the one in front of it), so the cache slot is just "ln"; the signature covers the norm's
+        parameters (a swapped module or a reloaded weight rebuilds).  Built from the parameters directly: the plain pack
+        of a folded Linear is never used on the default path and is not kept alive by this one."""
+        return self._packed("ln", lambda: fold_layernorm(pack_matrix(self.weight), pack_vec(self.bias),
+                                                         norm.weight, norm.bias),
                             self.weight, self.bias, norm.weight, norm.bias)
 
     def hip(self, x, *, act=ACT_NONE, res=None, rowvec=None, rows_per_rv=1, out=None, ln=None, ln_out=None):

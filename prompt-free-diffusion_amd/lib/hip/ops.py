@@ -51,11 +51,33 @@ _WS = {}
 _WS_BYTES = 96 << 20
 
 
+# Launch sequences that run CONCURRENTLY on different streams (the sub-batch lanes of DDIMSampler, lib/model_zoo/ddim.py)
+# must not share the split-K slabs: each lane selects its own slot while it enqueues (or captures) its launches.
+_WS_SLOT = threading.local()
+
+
+class workspace_slot:
+    """`with workspace_slot(i):` -- the split-K scratch used by the launches enqueued inside is slot i's"""
+
+    def __init__(self, slot):
+        self.slot = int(slot)
+
+    def __enter__(self):
+        self.prev = getattr(_WS_SLOT, "v", 0)
+        _WS_SLOT.v = self.slot
+        return self
+
+    def __exit__(self, *exc):
+        _WS_SLOT.v = self.prev
+        return False
+
+
 def _workspace(device):
-    """per-device fp32 scratch for split-K GEMMs (single-stream use; stable address for hipGraphs)"""
-    ws = _WS.get(device)
+    """per-(device, slot) fp32 scratch for split-K GEMMs (one stream per slot; stable address for hipGraphs)"""
+    key = (device, getattr(_WS_SLOT, "v", 0))
+    ws = _WS.get(key)
     if ws is None:
-        ws = _WS[device] = torch.empty(_WS_BYTES, dtype=torch.uint8, device=device)
+        ws = _WS[key] = torch.empty(_WS_BYTES, dtype=torch.uint8, device=device)
     return ws
 
 
@@ -102,8 +124,9 @@ def _rows(t):
 # GEMM / convolution
 # ----------------------------------------------------------------------------------------------
 def ln_fold_ok(C):
-    """widths whose LayerNorm can be folded into the consumer GEMM (PfdGemmDesc.ln_stats: 160-column slices, <= 8)"""
-    return LN_FOLD and C % 160 == 0 and C // 160 <= 8
+    """widths whose LayerNorm can be folded into the consumer GEMM (PfdGemmDesc.ln_stats: 160-column slices, <= 8; the
+    contraction must not need K padding -- pack_matrix pads K to 64 and the fold's gamma has C entries)"""
+    return LN_FOLD and C % 160 == 0 and C // 160 <= 8 and C % 64 == 0
 
 
 def ln_rowstats(x, out=None):

@@ -126,7 +126,8 @@ class GEGLU(nn.Module, L._Packed):
         return self._packed("geglu", build, self.proj.weight, self.proj.bias)
 
     def _pk_ln(self, norm):
-        return self._packed(("geglu_ln", id(norm)), lambda: L.fold_layernorm(*self._pk(), norm.weight, norm.bias),
+        # fixed slot (a GEGLU is always folded with the one LayerNorm in front of it; its parameters are in the signature)
+        return self._packed("geglu_ln", lambda: L.fold_layernorm(*self._pk(), norm.weight, norm.bias),
                             self.proj.weight, self.proj.bias, norm.weight, norm.bias)
 
     def hip(self, x2d, ln=None):
@@ -190,8 +191,12 @@ class CrossAttention(nn.Module, L._Packed):
             self.to_q.weight, self.to_k.weight, self.to_v.weight)
 
     def _pk_qkv_ln(self, norm):
-        return self._packed(("qkv_ln", id(norm)), lambda: L.fold_layernorm(self._pk_qkv(), None, norm.weight, norm.bias),
-                            self.to_q.weight, self.to_k.weight, self.to_v.weight, norm.weight, norm.bias)
+        # (one LayerNorm per attention, so the slot name is fixed; its parameters are part of the signature.  The stacked
+        #  [Wq; Wk; Wv] is built here and dropped: with the fold on, the plain "qkv" pack is never requested.)
+        def build():
+            w = torch.cat([L._dev16(self.to_q.weight), L._dev16(self.to_k.weight), L._dev16(self.to_v.weight)], 0)
+            return L.fold_layernorm(w.contiguous(), None, norm.weight, norm.bias)
+        return self._packed("qkv_ln", build, self.to_q.weight, self.to_k.weight, self.to_v.weight, norm.weight, norm.bias)
 
     def ln_foldable(self, x, N, context):
         """can the LayerNorm in front of this attention be folded into its first projection?"""
@@ -200,7 +205,7 @@ class CrossAttention(nn.Module, L._Packed):
             return False
         if context is None:
             return N % 8 == 0 and Cd % 160 == 0 and x.shape[1] % 64 == 0
-        return True
+        return Cd % 160 == 0 or Cd % 128 == 0          # to_q on the wide-tile kernels (the fold lives there only)
 
     def hip(self, x, B, N, context=None, res=None, ln=None, stats_out=False):
         """x: [B*N, query_dim] tokens (already normalised, or UN-normalised with ln = (LayerNorm, partial row sums of
@@ -367,7 +372,7 @@ class SpatialTransformer(nn.Module):
         blocks = list(self.transformer_blocks)
         hs = None
         inner = self.proj_in.out_features if self.use_linear else self.proj_in.out_channels
-        if ops.ln_fold_ok(inner) and inner % 160 == 0:
+        if ops.ln_fold_ok(inner) and inner % 160 == 0 and Cc % 64 == 0:   # (a 1x1 conv on Cc % 64 != 0 goes through im2col: no statistics)
             # proj_in stores the tokens the first LayerNorm reads: it emits their partial row sums with them
             h, hs = self.proj_in.hip(self.norm.hip(x), ln_out=True)
             h = h.view(B * N, -1)

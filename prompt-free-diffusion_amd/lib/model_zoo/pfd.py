@@ -172,7 +172,11 @@ class PromptFreeDiffusion(nn.Module):
             nb = x_nhwc.shape[0]
             if timesteps.shape[0] != 2 * nb:
                 raise ValueError(f"cfg_pair: {timesteps.shape[0]} timesteps for a pair of {nb}-sample halves")
-            if emb_table is None and not bool((timesteps[:nb] == timesteps[nb:]).all()):
+            # (checked where it costs nothing: on the host for CPU timesteps; for device timesteps only outside stream
+            #  capture and only when no precomputed table says the caller built the pair itself -- the sampler always
+            #  passes emb_table, so its eager path never pays this device-to-host sync)
+            if emb_table is None and (not timesteps.is_cuda or not torch.cuda.is_current_stream_capturing()) and \
+                    not bool((timesteps[:nb] == timesteps[nb:]).all()):
                 raise ValueError("cfg_pair: the two halves of the pair carry different timesteps")
         if isinstance(context, ContextMix):
             if control is not None:

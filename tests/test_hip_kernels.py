@@ -186,6 +186,51 @@ def test_attention(B, H, Nq, Nk, D):
     close(o.view(B, Nq, H, D), ref.permute(0, 2, 1, 3), 5e-3)
 
 
+@pytest.mark.parametrize("slices", ["2", "4"])
+def test_vae_attention512_both_slice_forms(slices, monkeypatch):
+    """d = 512 fused VAE attention: the two-slice instantiation (default since round 4) and the four-slice one, at a ragged
+    query tile and at a 64^2-token shape, vs fp32 torch (PFD_ATTN512_SLICES is read per launch)"""
+    from lib.hip import ops
+    monkeypatch.setenv("PFD_ATTN512_SLICES", slices)
+    for (B, Nq, Nk) in ((2, 200, 96), (1, 4096, 4096)):
+        D = Cd = 512
+        q, k, v = _dev(B, Nq, Cd), _dev(B, Nk, Cd, seed=1), _dev(B, Nk, Cd, seed=2)
+        vt = v.permute(2, 0, 1).contiguous()
+        o = ops.attention(q, k, vt, B, 1, Nq, Nk, D, D ** -0.5, ldq=Cd, ldk=Cd, ldvt=B * Nk, q_bs=Nq * Cd,
+                          k_bs=Nk * Cd, vt_bs=Nk)
+        ref = ((q.float() @ k.float().transpose(-1, -2)) * D ** -0.5).softmax(-1) @ v.float()
+        close(o.view(B, Nq, Cd), ref, 5e-3)
+
+
+def test_self_attention_at_36864_tokens():
+    """app.py:197-207 allows a 1536 x 1536 output: the UNet's first self-attention (attention.py:188-199) then runs over
+    192 x 192 = 36 864 tokens with 8 heads of d = 40 -- the largest attention problem the path can be asked for
+    (tests/test_hip_parity.py::test_tall_and_wide_resolutions only checks that such a request is finite).  Numeric check of
+    the fused kernel at that size against an fp32 reference on the same device, computed in query chunks (the score
+    matrix of one chunk is 8 x 2048 x 36 864 fp32 = 2.4 GB), and against itself on a permuted key order (softmax is
+    permutation invariant: a size-independent property)."""
+    from lib.hip import ops
+    B, H, N, D = 1, 8, 36864, 40
+    Cd = H * D
+    q, k, v = _dev(B, N, Cd), _dev(B, N, Cd, seed=1), _dev(B, N, Cd, seed=2)
+    q[:, 17] *= 6.0                                           # one query row with a peaked distribution
+    vt = v.permute(2, 0, 1).contiguous()
+    o = ops.attention(q, k, vt, B, H, N, N, D, D ** -0.5, ldq=Cd, ldk=Cd, ldvt=B * N, q_bs=N * Cd, k_bs=N * Cd, vt_bs=N)
+    sp = lambda t: t.float().view(N, H, D).permute(1, 0, 2)   # noqa: E731
+    qf, kf, vf = sp(q[0]), sp(k[0]), sp(v[0])
+    worst = 0.0
+    for c0 in range(0, N, 2048):
+        ref = ((qf[:, c0:c0 + 2048] @ kf.transpose(-1, -2)) * D ** -0.5).softmax(-1) @ vf     # [H, 2048, D]
+        got = o[c0:c0 + 2048].view(-1, H, D).permute(1, 0, 2).float()
+        worst = max(worst, float((got - ref).abs().max() / max(1.0, float(ref.abs().max()))))
+    print(f"[kernels] self-attention at 36 864 tokens (8 heads, d = 40): scaled max-abs error {worst:.3e} vs fp32")
+    assert worst <= 5e-3
+    perm = torch.randperm(N, generator=torch.Generator().manual_seed(9)).cuda()
+    o2 = ops.attention(q, k[:, perm].contiguous(), v[:, perm].permute(2, 0, 1).contiguous(), B, H, N, N, D, D ** -0.5,
+                       ldq=Cd, ldk=Cd, ldvt=B * N, q_bs=N * Cd, k_bs=N * Cd, vt_bs=N)
+    assert float((o2.float() - o.float()).abs().max()) <= 5e-3
+
+
 def test_vae_attention_beyond_16k_tokens():
     """tall / wide outputs up to 1536 px (app.py:197-207): the VAE mid attention sees up to 36 864 tokens;
     rows longer than 16 384 take the streaming softmax.  Checked against torch fp32 on the same device."""

@@ -96,6 +96,36 @@ def test_swin_and_decoder_stages(net, golden):
         check(f"seecoder decoder {k}", flat[idx.cuda()], golden[f"see.dec.{k}.sample"])
 
 
+def test_controlnet_and_swin_full_tensors_vs_oracle(net, golden, param_shapes):
+    """Every element of the 13 ControlNet residuals, the three Swin stage outputs and the three SeeCoder-decoder levels
+    (the fixtures above hold 64 / 256 sampled values per tensor, because the reference's full tensors are large): the
+    oracle -- itself pinned to those reference samples at the same positions, re-checked here -- is evaluated on the
+    fixture's inputs and compared with the GPU tensors in full."""
+    import pfd_oracle as O
+    x, t, c, hint = (T(golden[k]) for k in ("unet.x", "unet.t", "unet.c", "ctl.hint"))
+    outs = net.ctl(x.cuda(), hint=hint.cuda(), timesteps=t.cuda(), context=c.cuda())
+    ref = O.controlnet_apply(seeded_sd(param_shapes, "ctl."), "ctl.", x.float(), hint.float(), t, c.float())
+    assert len(outs) == len(ref) == 13
+    for i, (o, r) in enumerate(zip(outs, ref)):
+        idx = torch.linspace(0, r.numel() - 1, 64).long()
+        assert err(r.flatten()[idx], golden[f"ctl.res{i}.sample"]) <= 1e-3      # oracle == reference at the sampled spots
+        check(f"controlnet residual {i}, all {r.numel()} elements", o, r)
+    img = T(golden["see.img"])
+    sd_c = seeded_sd(param_shapes, "ctx.image.")
+    fea = net.ctx['image'].imencoder(img.cuda())
+    rfea = O.swin_forward(sd_c, "ctx.image.imencoder.", img.float())
+    for k in ("res3", "res4", "res5"):
+        idx = torch.linspace(0, rfea[k].numel() - 1, 256).long()
+        assert err(rfea[k].flatten()[idx], golden[f"see.swin.{k}.sample"]) <= 1e-3
+        check(f"swin {k}, all {rfea[k].numel()} elements", fea[k], rfea[k])
+    dec = net.ctx['image'].imdecoder({k: fea[k] for k in ("res3", "res4", "res5")})
+    rdec = O.seecoder_decoder(sd_c, "ctx.image.imdecoder.", {k: rfea[k] for k in ("res3", "res4", "res5")})
+    for k in ("res3", "res4", "res5"):
+        idx = torch.linspace(0, rdec[k].numel() - 1, 256).long()
+        assert err(rdec[k].flatten()[idx], golden[f"see.dec.{k}.sample"]) <= 1e-3
+        check(f"seecoder decoder {k}, all {rdec[k].numel()} elements", dec[k], rdec[k])
+
+
 def test_seecoder_context(net, golden):
     ctx = net.ctx_encode(T(golden["see.img"]).cuda().half(), 'image')
     assert ctx.shape == (1, 148, 768) and ctx.dtype == torch.float16
@@ -484,3 +514,28 @@ def test_zero_uncond_shortcut_is_exact(net, golden):
     nz[:, 0, 0] = 1.0          # not all zero -> the shortcut must not trigger
     assert torch.equal(run(True, nz), run(False, nz))
     assert not torch.equal(run(True, nz), run(True, zeros))
+
+
+@pytest.mark.parametrize("cfg_pair", [False, True])
+def test_layernorm_fold_matches_standalone_layernorm(net, monkeypatch, cfg_pair):
+    """the LayerNorm fold (statistics from the producer's epilogue, affine map on the consumer's accumulators)
+    against the same SpatialTransformer with every LayerNorm as its own launch (PFD_LN_FOLD=0), at model shapes, with a
+    zero-context lead (the `x + bias` shortcut rows) and with the CFG pair doubling in the middle of the block."""
+    from lib.hip import ops
+    g = torch.Generator().manual_seed(17)
+    for blk_idx, (hw, C) in ((0, (32, 320)), (2, (16, 640)), (4, (8, 1280))):
+        st = net.diffuser['image'].context_blocks[blk_idx][0]
+        assert st.in_channels == C
+        B = 4
+        x = (torch.randn((B // 2 if cfg_pair else B, hw, hw, C), generator=g)).half().cuda()
+        c = torch.randn((B, 148, 768), generator=g).half().cuda()
+        c[:B // 2] = 0
+        ctx = net.prepare_context(c)
+        ctx.zero_lead = B // 2
+        assert ops.LN_FOLD
+        y_fold = st.hip(x, ctx, cfg_pair=cfg_pair)
+        monkeypatch.setattr(ops, "LN_FOLD", False)
+        y_plain = st.hip(x, ctx, cfg_pair=cfg_pair)
+        monkeypatch.setattr(ops, "LN_FOLD", True)
+        assert y_fold.shape == y_plain.shape == (B, hw, hw, C)
+        check(f"LayerNorm fold vs standalone LayerNorm, C={C} @{hw}x{hw}, cfg_pair={cfg_pair}", y_fold, y_plain.float().cpu(), 5e-3)

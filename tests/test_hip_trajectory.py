@@ -8,8 +8,9 @@ weights, reference image and x_T:
 
   * C2 (headline): 512x512, 50 DDIM steps, CFG 2.0, batch 4 on the GPU; the oracle runs sample 0 (samples are
     independent) for the same 50 steps on the host -- about five minutes of CPU time, the long pole of the suite;
-  * C5 shape: 768x768 (96x96 latent, 9216-token self-attention), batch 2, NON-ZERO unconditional context (the
-    SeeCoder-Anime case, app.py:238-241: no zero-context shortcut), 5 DDIM steps;
+  * C5: 768x768 (96x96 latent, 9216-token self-attention), batch 2, NON-ZERO unconditional context (the
+    SeeCoder-Anime case, app.py:238-241: no zero-context shortcut), all 31 real DDIM steps of the "30-step" schedule;
+  * C3: ControlNet + SeeCoder-PA + a control hint, 512x512, batch 4, 10 DDIM steps;
   * SeeCoder-PA (position-aware MLP attached like app.py:166-177) at 512x512;
   * the C4 per-rank shape (8 images per GPU -> UNet batch 16): determinism and batch invariance against the batch-4 run.
 
@@ -76,10 +77,11 @@ def test_config_c2_trajectory_vs_oracle(net, param_shapes):
     assert mx <= 2e-2
 
 
-def test_config_c5_shape_nonzero_uncond_trajectory(net, param_shapes):
-    """BASELINE configs[4] shape: 768x768 (96x96 latent, self-attention over 9216 tokens, convolutions on widths the
+def test_config_c5_trajectory_all_31_steps(net, param_shapes):
+    """BASELINE configs[4] end to end: 768x768 (96x96 latent, self-attention over 9216 tokens, convolutions on widths the
     patch kernel does not take), batch 2, a NON-ZERO unconditional context (SeeCoder-Anime, app.py:238-241: the
-    zero-context shortcut must not trigger), 5 DDIM steps vs the oracle."""
+    zero-context shortcut must not trigger), "30" DDIM steps = the 31 real steps of make_ddim_timesteps
+    (diffusion_utils.py:32-46: 1000 // 30 = 33 -> range(0, 1000, 33)), sample 0 vs the oracle for the same 31 steps."""
     import pfd_oracle as O
     from lib.pipeline import PromptFreePipeline, shard_xT
     torch.set_num_threads(max(1, min(64, os.cpu_count() or 1)))
@@ -88,12 +90,72 @@ def test_config_c5_shape_nonzero_uncond_trajectory(net, param_shapes):
     ug = torch.zeros((1, 148, 768))
     ug[:, :77] = torch.randn((1, 77, 768), generator=g) - 0.1
     ug = ug.half().float()                                       # the fp16 values the GPU path is handed
-    lat = PromptFreePipeline(net).generate(img, 2, 768, 768, steps=5, scale=2.0, seed=31, decode=False,
-                                           uncond=ug.half().repeat(2, 1, 1).cuda())[0]
+    pipe = PromptFreePipeline(net)
+    lat = pipe.generate(img, 2, 768, 768, steps=30, scale=2.0, seed=31, decode=False,
+                        uncond=ug.half().repeat(2, 1, 1).cuda())[0]
     assert lat.shape == (2, 4, 96, 96)
+    assert len(pipe.sampler.ddim_timesteps) == 31
+    t0 = time.time()
     cond = O.seecoder_encode(seeded_sd(param_shapes, "ctx.image."), "ctx.image.", img)
-    x = _oracle_trajectory(param_shapes, cond, ug, shard_xT(2, 768, 768, 31, 0, 1)[:1], 5)
-    rel, _ = _report("C5 shape (768x768, non-zero uncond, 5 steps) latent of sample 0 vs oracle", lat[:1], x)
+    x = _oracle_trajectory(param_shapes, cond, ug, shard_xT(2, 768, 768, 31, 0, 1)[:1], 30)
+    print(f"[trajectory] C5 oracle: 31 CFG steps at 96x96 in {time.time() - t0:.0f} s")
+    rel, _ = _report("C5 (768x768, non-zero uncond, 31 real steps, batch 2) latent of sample 0 vs oracle", lat[:1], x)
+    assert rel <= 1e-2
+
+
+def test_config_c3_trajectory_vs_oracle(net, golden, param_shapes):
+    """BASELINE configs[2]: ControlNet + SeeCoder-PA (PPE_MLP attached like app.py:166-177) + control hint
+    (`do_preprocess=False`: the hint is used as given), 512x512, batch 4, CFG 2.0, 10 DDIM steps on the GPU; the oracle
+    runs sample 0 through the same 10 steps with the reference's control flow (pfd.py:466-528: ControlNet on the
+    CFG-doubled batch with the same context, 13 residuals added at mid / on every popped skip; controlnet.py:302-324)."""
+    import pfd_oracle as O
+    from lib.model_zoo.seecoder import PPE_MLP
+    from lib.pipeline import PromptFreePipeline, shard_xT
+    from weights import seeded_tensor
+    torch.set_num_threads(max(1, min(64, os.cpu_count() or 1)))
+    spec = json.loads(str(golden["seepa.spec"]))
+    pfx = "ctx.image.qtransformer.pe_layer."
+    pe_sd = {k: seeded_tensor(k, s, 0) for k, s in spec.items()}
+    pe = PPE_MLP(freq_num=20, freq_max=None, out_channel=768, mlp_layer=3)
+    pe.load_state_dict({k[len(pfx):]: v for k, v in pe_sd.items()}, strict=True)
+    img = torch.rand((1, 3, 512, 512), generator=torch.Generator().manual_seed(1234))
+    hint = torch.rand((1, 3, 512, 512), generator=torch.Generator().manual_seed(4321))
+    qt = net.ctx['image'].qtransformer
+    qt.pe_layer = pe.half().to('cuda')
+    try:
+        lat = PromptFreePipeline(net).generate(img, 4, 512, 512, steps=10, scale=2.0, seed=20, decode=False,
+                                               control=hint.half())[0]
+    finally:
+        qt.pe_layer = None
+    assert lat.shape == (4, 4, 64, 64) and torch.isfinite(lat).all()
+    t0 = time.time()
+    sd_c = seeded_sd(param_shapes, "ctx.image.")
+    sd_c.update(pe_sd)
+    sd_u, sd_ctl = seeded_sd(param_shapes, "diffuser.image."), seeded_sd(param_shapes, "ctl.")
+    cond = O.seecoder_encode(sd_c, "ctx.image.", img)
+    hint16 = hint.half().float()                       # the fp16 values the GPU path is handed
+
+    def eps_fn(xx, tt, cc):
+        res = O.controlnet_apply(sd_ctl, "ctl.", xx, hint16, tt, cc)
+        return O.unet_apply(sd_u, "diffuser.image.", xx, tt, cc, control=res)
+    acp = O.schedule_buffers()["alphas_cumprod"]
+    ts, a, ap, sg = O.ddim_tables(acp, 10, 0.0)
+    x = shard_xT(4, 512, 512, 20, 0, 1)[:1].clone()
+    x_plain = x.clone()
+    for i, step in enumerate(np.flip(ts)):
+        idx = len(ts) - i - 1
+        t = torch.full((1,), int(step), dtype=torch.long)
+        if i == 0:   # the control must matter: one uncontrolled step from the same x_T for comparison
+            x_plain, _ = O.ddim_step(lambda xx, tt, cc: O.unet_apply(sd_u, "diffuser.image.", xx, tt, cc), x, t, cond,
+                                     torch.zeros_like(cond), 2.0, float(a[idx]), float(ap[idx]), float(sg[idx]))
+            x1, _ = O.ddim_step(eps_fn, x, t, cond, torch.zeros_like(cond), 2.0, float(a[idx]), float(ap[idx]), float(sg[idx]))
+            assert float((x1 - x_plain).abs().max()) > 1e-2
+            x = x1
+        else:
+            x, _ = O.ddim_step(eps_fn, x, t, cond, torch.zeros_like(cond), 2.0, float(a[idx]), float(ap[idx]), float(sg[idx]))
+    print(f"[trajectory] C3 oracle: SeeCoder-PA + 10 ControlNet-guided CFG steps in {time.time() - t0:.0f} s; "
+          f"latent std {float(x.std()):.2f}")
+    rel, _ = _report("C3 (ControlNet + SeeCoder-PA, 512x512, 10 steps, batch 4) latent of sample 0 vs oracle", lat[:1], x)
     assert rel <= 1e-2
 
 
