@@ -3,7 +3,10 @@ only) against the oracle port on the same host, same threads, same input -- one 
 64x64, SeeCoder at 512x512, VAE decode of a 64x64 latent.  bench.py's `cpu_baseline` must use the port on the
 GPU box (the reference tree does not travel); this script shows how the two compare where both can run.
     python oracle/time_reference_vs_port.py > profiles/rNN_cpu_reference_vs_port.log
+Also writes profiles/cpu_reference_vs_port.json (tracked): bench.py's `cpu_baseline.reference_vs_port` is read from
+that file, so the numbers in a bench line are the ones THIS script measured, with their provenance.
 """
+import json
 import os
 import sys
 import time
@@ -53,11 +56,20 @@ def main():
         ("VAE decode 64x64 latent", lambda: net.vae_decode(z, which='image'),
          lambda: O.vae_decode(sd, "vae.image.", z)),
     ]
+    out = {"host_cpus": os.cpu_count(), "torch_threads": torch.get_num_threads(), "torch": torch.__version__,
+           "measured": time.strftime("%Y-%m-%d"), "script": "oracle/time_reference_vs_port.py", "stages": {}}
     for name, ref, port in rows:
         a, b = ref(), port()
         err = float((a - b).abs().max())
         tr, tp = timed(ref), timed(port)
         print(f"{name}: reference {tr:.2f} s, port {tp:.2f} s (port/reference {tp / tr:.2f}), max|diff| {err:.2e}")
+        out["stages"][name] = {"reference_s": round(tr, 3), "port_s": round(tp, 3), "port_over_reference": round(tp / tr, 3),
+                               "max_abs_diff": err}
+    ratios = [v["port_over_reference"] for v in out["stages"].values()]
+    out["max_abs_diff"] = max(v["max_abs_diff"] for v in out["stages"].values())
+    out["port_time_over_reference_time"] = [min(ratios), max(ratios)]
+    with open(os.path.join(os.path.dirname(HERE), "profiles", "cpu_reference_vs_port.json"), "w") as f:
+        json.dump(out, f, indent=1)
 
 
 if __name__ == "__main__":

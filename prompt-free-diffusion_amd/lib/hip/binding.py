@@ -30,7 +30,7 @@ class PfdGemmDesc(C.Structure):
         ("ksize", _i32), ("stride", _i32), ("pad", _i32), ("ups", _i32),
         ("B", _i32), ("H", _i32), ("Wd", _i32), ("Cin", _i32), ("Ho", _i32), ("Wo", _i32),
         ("ws", _vp), ("ws_bytes", _sz),
-        ("Ct", _vp), ("ldct", _i64), ("n_split", _i32), ("reserved0", _i32),
+        ("Ct", _vp), ("ldct", _i64), ("n_split", _i32), ("w_tiled", _i32),
         ("gn_table", _vp), ("A2", _vp), ("lda2", _i64), ("gn_c1", _i32), ("gn_act", _i32),
         ("ln_stats", _vp), ("ln_colsum", _vp), ("ln_parts", _i32), ("ln_eps", _f32), ("ln_out", _vp),
     ]
@@ -54,7 +54,7 @@ class PfdSwinAttnDesc(C.Structure):
     ]
 
 
-# name -> (restype, argtypes); this table is also what tests/test_cabi.py checks against the header
+# name -> (restype, argtypes); this table is also what tests/test_host.py (test_cabi_exports_every_declared_symbol) checks against the header
 SIGNATURES = {
     "pfd_abi_version": (_i32, []),
     "pfd_last_error": (C.c_char_p, []),

@@ -1,11 +1,16 @@
 """CPU, world_size 2, gloo: the sharding + all-gather logic of the multi-GPU path (the compute
 itself needs a GPU and is covered by -m gpu; the collective here is the same call on gloo)."""
+import json
 import os
 import socket
+import subprocess
+import sys
 
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 
 
 def _free_port():
@@ -37,33 +42,7 @@ def _worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
-class _StubNet:
-    """stand-in for the GPU compute of the composite (samples are independent on the real path too):
-    deterministic, per-sample functions with the real shapes"""
-    device = 'cpu'
-    num_timesteps = 1000
-
-    def ctx_encode(self, image, which):
-        assert which == 'image' and image.shape[0] == 1
-        return image.mean().reshape(1, 1, 1).expand(1, 148, 768).clone()
-
-    def vae_decode(self, z, which, out_uint8=False):
-        img = z[:, :3].repeat_interleave(8, -1).repeat_interleave(8, -2).mul(0.1).add(0.5).clamp(0, 1)
-        return (img * 255).to(torch.uint8).permute(0, 2, 3, 1).contiguous() if out_uint8 else img
-
-
-class _StubSampler:
-    def __init__(self, rank):
-        self.rank, self.calls = rank, 0
-
-    def sample(self, steps, shape, x_info, c_info, eta=0., verbose=True):
-        import time
-        self.calls += 1
-        x = x_info['xt']
-        assert list(x.shape) == list(shape) and c_info['conditioning'].shape == (shape[0], 148, 768)
-        assert not bool(c_info['unconditional_conditioning'].any())
-        time.sleep(0.02 * (self.rank + 1))               # ranks finish at different times
-        return x * 0.5 + c_info['conditioning'][:, :1, :1].reshape(-1, 1, 1, 1), {}
+from stubs import StubNet as _StubNet, StubSampler as _StubSampler  # noqa: E402  (shared with `bench.py --stub`)
 
 
 def _pipeline_worker(rank, world, port, q):
@@ -142,3 +121,37 @@ def test_sharding_is_independent_of_world_size():
         parts = [shard_xT(8, 64, 96, 7, r, P) for r in range(P)]
         assert torch.equal(torch.cat(parts), full)
     assert full.shape == (8, 4, 8, 12)
+
+
+def _bench(*extra, timeout=300, env=None):
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    e = dict(os.environ)
+    e.pop("WORLD_SIZE", None)
+    e.update(env or {})
+    return subprocess.run([sys.executable, os.path.join(repo, "bench.py"), "--stub", "--backend", "gloo", "--steps", "2",
+                           "--warmup", "1", "--height", "64", "--width", "96", *extra],
+                          capture_output=True, text=True, timeout=timeout, env=e)
+
+
+def test_bench_starts_its_own_ranks():
+    """`python bench.py --gpus 2` with no WORLD_SIZE (how the driver runs --gpus 1) must not die at argument parsing: it
+    spawns the two ranks under torch.distributed.run on 127.0.0.1, the ranks shard / all-gather / reduce their times
+    (gloo + the stand-in compute here, RCCL + the HIP path on a GPU node) and ONE JSON line comes back."""
+    r = _bench("--gpus", "2")
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    res = json.loads(lines[0])
+    assert res["n_gpus"] == 2 and res["config"]["global_batch"] == 8 and res["config"]["parallelism"] == "dp2"
+    assert res["config"]["world_size_reported_by_backend"] == 2 and res["config"]["workload"].startswith("[c2-weak]")
+    assert res["steps"] == 2 and res["warmup"] == 1 and res["scaling"] == "weak" and res["value"] > 0
+    assert res["ms_per_step"] >= 40.0            # the slowest rank's time (rank 1 sleeps 40 ms per batch)
+
+
+def test_bench_launcher_fails_loudly_instead_of_hanging():
+    """a job whose ranks cannot finish in time is killed and reported (exit code 124), not waited for forever"""
+    r = _bench("--gpus", "2", "--launch-timeout", "0.5", timeout=120)
+    assert r.returncode == 124 and "did not finish within" in r.stderr
+    # a world size that contradicts --gpus is an error message, not a hang
+    r = _bench("--gpus", "2", env={"WORLD_SIZE": "1"})
+    assert r.returncode != 0 and "WORLD_SIZE=1" in (r.stderr + r.stdout)
