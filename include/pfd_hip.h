@@ -34,7 +34,7 @@ extern "C" {
 #define PFD_ESHAPE (-2)   /* shape outside what the kernels are built for           */
 #define PFD_ELAUNCH (-3)  /* hipGetLastError() != hipSuccess after the launch       */
 
-#define PFD_ABI_VERSION 7
+#define PFD_ABI_VERSION 8
 
 typedef void* pfd_stream_t; /* hipStream_t */
 
@@ -149,6 +149,19 @@ typedef struct PfdGemmDesc {
   int32_t ln_parts;
   float ln_eps;
   void* ln_out;
+  /* Two-source contraction and zero rows (ABI 8; plain GEMM, ksize == 0, wide-tile kernels only: N % 160 == 0 or
+   * N % 128 == 0, anything else is PFD_ESHAPE and callers run the two-launch forms).
+   * k_split > 0: the operand is the virtual COLUMN concat [A (k_split columns, row stride lda) | A2 (K - k_split
+   *   columns, row stride lda2)], k_split % 64 == 0 -- the 1x1 skip convolution of an output-half ResBlock over
+   *   `torch.cat([h, skip], dim=1)` (openaimodel.py:274 after pfd.py:356) as ONE launch instead of a GEMM over h and a
+   *   second GEMM over the skip tensor that re-reads and re-writes the result (gn_c1 / gn_table are not involved).
+   * zero_rows > 0: output rows m < zero_rows have an all-zero operand row (they are never read; A / A2 point at the
+   *   data of row zero_rows), so their result is epi(0) = act(bias + rowvec) + R, and tiles that lie entirely below
+   *   zero_rows skip their K loop -- the cross-attention out-projection of a CFG batch whose unconditional context is
+   *   all zero (app.py:236: K = V = 0, so `to_out(attn) + x` of those samples is `to_out.bias + x`, attention.py:
+   *   178-201) in ONE launch with the conditional half, statistics (ln_out) included.  Not with ln_stats. */
+  int32_t k_split;
+  int32_t zero_rows;
 } PfdGemmDesc;
 int pfd_gemm_f16(const PfdGemmDesc* d, pfd_stream_t stream);
 /* Same, with the kernel variant forced (tests and tuning only); 0 = the library's heuristic.

@@ -80,9 +80,11 @@ struct G160Params {
   int ln_P;
   float ln_eps;
   const float* gn_table;   // [B][2][Cin]: scale plane, shift plane
-  const half_t* A2;        // channels >= gn_c1 of the virtual concat
+  const half_t* A2;        // channels >= gn_c1 of the virtual concat (GroupNorm prologue) / columns >= k_split (linear)
   long lda2;
   int gn_c1, gn_act;
+  int k_split;             // linear kernels: K tiles at k >= k_split come from A2 (== K when there is no second source)
+  int zero_rows;           // linear kernels: operand rows below this are all zero and are never read (PfdGemmDesc.zero_rows)
 };
 
 __device__ __forceinline__ void glds16(const void* src, void* lds_dst) {
@@ -474,6 +476,7 @@ __global__ __launch_bounds__(WAVES_M * 128) void gemm160_kernel(const G160Params
   const int srow = lane >> 3;
   const int cpos = lane & 7;
   const half_t* a_ptr[A_PER_WAVE];   // linear mode: pointer to (row, swizzled source chunk) at k = 0
+  const half_t* a2_ptr[A_PER_WAVE];  // ... of the second source (columns >= k_split), see PfdGemmDesc.k_split
   int a_oy[A_PER_WAVE], a_ox[A_PER_WAVE];
   long a_img[A_PER_WAVE];
   bool a_ok[A_PER_WAVE];
@@ -493,9 +496,12 @@ __global__ __launch_bounds__(WAVES_M * 128) void gemm160_kernel(const G160Params
       a_oy[j] = oy * p.stride - p.pad;
       a_ox[j] = (rem - oy * p.Wo) * p.stride - p.pad;
       a_img[j] = (long)b * p.H * p.Wd * p.lda;
-      a_ptr[j] = p.A;
+      a_ptr[j] = a2_ptr[j] = p.A;
     } else {
-      a_ptr[j] = a_ok[j] ? p.A + (long)m * p.lda + c * 8 : g_zero_page;
+      const int mz = m - p.zero_rows;           // A / A2 start at the first row that holds data
+      a_ok[j] = a_ok[j] && mz >= 0;
+      a_ptr[j] = a_ok[j] ? p.A + (long)mz * p.lda + c * 8 : g_zero_page;
+      a2_ptr[j] = a_ok[j] ? p.A2 + (long)mz * p.lda2 + c * 8 : g_zero_page;
       a_oy[j] = a_ox[j] = 0;
       a_img[j] = 0;
     }
@@ -513,7 +519,8 @@ __global__ __launch_bounds__(WAVES_M * 128) void gemm160_kernel(const G160Params
   const int Win = p.ups ? 2 * p.Wd : p.Wd;
 
   // K tiles are walked in rotated order (k_rotation): step i works on tile kt_begin + (i + rot) % nsteps
-  const int nsteps = kt_end - kt_begin;
+  // (a tile whose rows all lie below zero_rows has nothing to contract: epi(0))
+  const int nsteps = (!CONV && m0 + BM <= p.zero_rows) ? 0 : kt_end - kt_begin;
   int kt_issue = kt_begin + k_rotation(p.krot, tile_m, p.tiles_m, nsteps);   // next tile to be issued (wave-uniform)
   // conv K walk: tap (ky, kx) outer, channel block inner
   int tap_ky = 0, tap_kx = 0, ci0 = 0;
@@ -552,9 +559,12 @@ __global__ __launch_bounds__(WAVES_M * 128) void gemm160_kernel(const G160Params
         glds16(src, As + (wave + NW * j) * 1024);
       }
     } else {
+      const bool first = k0 < p.k_split;   // wave-uniform: which source this K tile comes from
 #pragma unroll
-      for (int j = 0; j < A_PER_WAVE; ++j)
-        glds16(a_ok[j] ? a_ptr[j] + k0 : a_ptr[j], As + (wave + NW * j) * 1024);
+      for (int j = 0; j < A_PER_WAVE; ++j) {
+        const half_t* src = first ? a_ptr[j] + k0 : a2_ptr[j] + (k0 - p.k_split);
+        glds16(a_ok[j] ? src : a_ptr[j], As + (wave + NW * j) * 1024);
+      }
     }
 #pragma unroll
     for (int j = 0; j < B_PER_WAVE; ++j) {
@@ -1777,6 +1787,19 @@ int pfd_gemm160_try(const PfdGemmDesc* d, int variant, int splits, hipStream_t s
   p.gn_c1 = d->gn_c1; p.gn_act = d->gn_act;
   p.ln_in = (const float2*)d->ln_stats; p.ln_cs = (const float*)d->ln_colsum; p.ln_P = d->ln_parts; p.ln_eps = d->ln_eps;
   p.ln_out = (float2*)d->ln_out;
+  // two-source contraction / zero rows (ABI 8): the 8-wave / 4-wave linear kernels only
+  p.k_split = d->K; p.zero_rows = 0;
+  if (d->k_split > 0 || d->zero_rows > 0) {
+    if (d->ksize > 0 || d->gn_table || d->bias_per_row || d->Ct) return 1;
+    if (d->zero_rows < 0 || d->zero_rows >= d->M || (d->zero_rows > 0 && d->ln_stats)) return 1;
+    if (variant == 47 || variant == 48 || variant == 49 || variant == 84) return 1;
+    if (d->k_split > 0) {
+      if (d->k_split >= d->K || (d->k_split % BK) || !d->A2 || (d->lda2 & 7) || (reinterpret_cast<uintptr_t>(d->A2) & 15)) return 1;
+      p.k_split = d->k_split;
+    }
+    p.zero_rows = d->zero_rows;
+  }
+  if (p.ksize == 0 && p.k_split == d->K) { p.A2 = p.A; p.lda2 = p.lda; }
   if (p.ln_in) {   // LayerNorm fold: plain linear, statistics over K = ln_parts slices of 160 columns
     if (d->ksize > 0 || !p.ln_cs || p.ln_P < 1 || p.ln_P > 8 || p.ln_P * 160 != d->K) return 1;
     if ((reinterpret_cast<uintptr_t>(p.ln_in) & 7) || (reinterpret_cast<uintptr_t>(p.ln_cs) & 15)) return 1;

@@ -110,6 +110,8 @@ struct GemmCase {
   int ksize = 0, stride = 1, pad = 0, ups = 0, B = 0, H = 0, W = 0, Cin = 0;
   int n_split = 0;  // > 0: columns >= n_split go transposed to Ct
   int w_tiled = 0;  // 1: the weight is uploaded K-tile-contiguous (PfdGemmDesc.w_tiled)
+  int k_split = 0;  // > 0: columns >= k_split of the operand come from a second buffer (PfdGemmDesc.k_split)
+  int zero_rows = 0;  // > 0: the first rows of the operand are all zero and not stored (PfdGemmDesc.zero_rows)
 };
 
 static void run_gemm_case(const GemmCase& c) {
@@ -142,7 +144,18 @@ static void run_gemm_case(const GemmCase& c) {
       for (int k = 0; k < K; ++k)
         Wup[(((size_t)(n / T) * nkt + k / 64) * T + n % T) * 64 + k % 64] = W[(size_t)n * ldw + k];
   }
-  Dev<h16> dA(A), dW(Wup), dB(bias), dRV(rv), dR(R), dC((size_t)M * ldc);
+  for (long r = 0; r < c.zero_rows; ++r)                     // the reference sees zero rows ...
+    for (long k = 0; k < lda; ++k) A[r * lda + k] = (h16)0;
+  // ... the device sees the operand without them, and split in two buffers at k_split (second one with its own stride)
+  const long lda2 = c.k_split ? (K - c.k_split) + 8 : 8;
+  std::vector<h16> Adev(A.begin() + (long)c.zero_rows * lda, A.end()), A2dev((size_t)std::max<long>(1, M - c.zero_rows) * lda2);
+  if (c.k_split)
+    for (long r = 0; r < M - c.zero_rows; ++r)
+      for (long k = c.k_split; k < K; ++k) {
+        A2dev[r * lda2 + (k - c.k_split)] = Adev[r * lda + k];
+        Adev[r * lda + k] = (h16)7.0f;                        // must never be read
+      }
+  Dev<h16> dA(Adev), dA2(A2dev), dW(Wup), dB(bias), dRV(rv), dR(R), dC((size_t)M * ldc);
   Dev<float> dWS((size_t)8 * M * N + 64);
   PfdGemmDesc d;
   memset(&d, 0, sizeof(d));
@@ -157,10 +170,12 @@ static void run_gemm_case(const GemmCase& c) {
   Dev<h16> dCt(c.n_split > 0 ? (size_t)(N - c.n_split) * ldct : 8);
   if (c.n_split > 0) { d.Ct = dCt.p; d.ldct = ldct; d.n_split = c.n_split; }
   d.w_tiled = c.w_tiled;
+  if (c.k_split) { d.A2 = dA2.p; d.lda2 = lda2; d.k_split = c.k_split; }
+  d.zero_rows = c.zero_rows;
   const int rc = pfd_gemm_f16_ex(&d, c.tile, nullptr);
   char name[256];
-  snprintf(name, sizeof(name), "gemm M%d N%d K%d act%d b%d r%d rv%d br%d tile%d%s ld+%d %s", M, N, K, c.act,
-           c.bias, c.res, c.rowvec, c.bias_row, c.tile, c.w_tiled ? "T" : "", c.extra_ld,
+  snprintf(name, sizeof(name), "gemm M%d N%d K%d act%d b%d r%d rv%d br%d tile%d%s ks%d zr%d ld+%d %s", M, N, K, c.act,
+           c.bias, c.res, c.rowvec, c.bias_row, c.tile, c.w_tiled ? "T" : "", c.k_split, c.zero_rows, c.extra_ld,
            conv ? (std::string("conv k") + std::to_string(c.ksize) + " s" + std::to_string(c.stride) + " p" +
                    std::to_string(c.pad) + " u" + std::to_string(c.ups))
                       .c_str()
@@ -1068,6 +1083,13 @@ int main(int argc, char** argv) {
       run_gemm_case({520, 256, 512, 0, true, true, false, false, v});                                       // 128-wide tiles
       run_gemm_case({0, 160, 0, 0, true, true, false, false, v + 2, 0, 3, 1, 1, 0, 1, 16, 16, 1024});         // split-K 2
     }
+    // ABI 8: two-source contraction (k_split) and zero rows, every linear tile family, with / without split-K
+    for (int v : {0, 3200, 3300, 3400, 3500, 5400, 5100, 5300, 9200, 9300, 3202, 9203}) {
+      { GemmCase c{700, 320, 1024, 0, true, true, true, false, v}; c.k_split = 384; run_gemm_case(c); }
+      { GemmCase c{1100, 320, 512, 0, true, true, false, false, v}; c.zero_rows = 512; run_gemm_case(c); }     // whole tiles + a straddling one
+      { GemmCase c{600, 160, 256, PFD_ACT_SILU, true, true, true, false, v}; c.zero_rows = 300; c.k_split = 64; run_gemm_case(c); }
+    }
+    { GemmCase c{520, 256, 512, 0, true, true, false, false, 0}; c.k_split = 128; c.zero_rows = 256; run_gemm_case(c); }   // 128-wide tiles
     printf("SELFTEST %d/%d passed, %d failed\n", g_total - g_fail, g_total, g_fail);
     return g_fail;
   }

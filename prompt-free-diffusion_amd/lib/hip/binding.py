@@ -14,7 +14,7 @@ import os
 _LIB = None
 _LIB_PATH = os.path.normpath(os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "..", "libpfd_hip.so"))
 
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 ACT_NONE, ACT_GELU, ACT_RELU, ACT_SILU, ACT_GEGLU = 0, 1, 2, 3, 4
 
@@ -33,6 +33,7 @@ class PfdGemmDesc(C.Structure):
         ("Ct", _vp), ("ldct", _i64), ("n_split", _i32), ("w_tiled", _i32),
         ("gn_table", _vp), ("A2", _vp), ("lda2", _i64), ("gn_c1", _i32), ("gn_act", _i32),
         ("ln_stats", _vp), ("ln_colsum", _vp), ("ln_parts", _i32), ("ln_eps", _f32), ("ln_out", _vp),
+        ("k_split", _i32), ("zero_rows", _i32),
     ]
 
 

@@ -142,9 +142,22 @@ def ln_rowstats(x, out=None):
     return out
 
 
+# ABI 8 forms (PfdGemmDesc.k_split / zero_rows); PFD_GEMM_FUSE=0 keeps the two-launch forms (A/B runs)
+GEMM_FUSE = os.environ.get("PFD_GEMM_FUSE", "1") != "0"
+
+
+def wide_tile_ok(N, K):
+    """shapes the wide-tile linear kernels take (they alone serve gemm(a2=...) / gemm(zero_rows=...))"""
+    return GEMM_FUSE and (N % 160 == 0 or N % 128 == 0) and K % 64 == 0
+
+
 def gemm(a, w, *, bias=None, rowvec=None, rows_per_rv=1, res=None, act=ACT_NONE, out=None,
-         bias_per_row=False, n=None, k=None, tile=0, out_t=None, n_split=None, ln=None, ln_out=None):
+         bias_per_row=False, n=None, k=None, tile=0, out_t=None, n_split=None, ln=None, ln_out=None,
+         a2=None, zero_rows=0):
     """out[M, N] = epi(a[M, K] @ w[N, K]^T); see pfd_gemm_f16 in include/pfd_hip.h.
+    a2: second source of the contraction -- the operand is the virtual column concat [a | a2] (K = Ka + Ka2; the
+    1x1 skip convolution over a skip concat).  zero_rows: that many all-zero operand rows come in front of a's rows
+    (M = zero_rows + rows of a); their result is epi(0).  Both: wide-tile kernels only (wide_tile_ok).
     out_t / n_split: columns >= n_split go, transposed, to out_t[N - n_split, M] (wide-tile path only).
     ln = (stats, colsum, eps): LayerNorm of `a` folded into the contraction (w is the gamma-scaled weight, bias is b';
     PfdGemmDesc.ln_stats).  ln_out: True (allocate) or a float32 [M, N/160, 2] tensor -> the partial row sums of the
@@ -155,6 +168,19 @@ def gemm(a, w, *, bias=None, rowvec=None, rows_per_rv=1, res=None, act=ACT_NONE,
     Nw, Kw, ldw = _rows(w)
     N = Nw if n is None else n
     K = min(Ka, Kw) if k is None else k
+    if a2 is not None:
+        _chk16(a2, "gemm A2")
+        M2, Ka2, lda2 = _rows(a2)
+        if M2 != M or a2.device != a.device:
+            raise ValueError(f"gemm: a2 {tuple(a2.shape)} does not pair with a {tuple(a.shape)}")
+        if k is None:
+            K = Ka + Ka2
+        if Ka % 64 or Ka >= K or K - Ka > Ka2:
+            raise ValueError(f"gemm: a2 needs a first source of a multiple of 64 columns below K (Ka {Ka}, K {K})")
+    if zero_rows:
+        if zero_rows < 0 or ln is not None:
+            raise ValueError("gemm: zero_rows must be >= 0 and cannot be combined with ln=")
+        M += zero_rows
     n_out = N // 2 if act == ACT_GEGLU else N
     if out_t is not None:
         n_out = n_split
@@ -180,6 +206,9 @@ def gemm(a, w, *, bias=None, rowvec=None, rows_per_rv=1, res=None, act=ACT_NONE,
     d.rows_per_rv, d.act, d.bias_per_row = rows_per_rv, act, 1 if bias_per_row else 0
     d.ksize = 0
     d.ws, d.ws_bytes = _workspace(a.device).data_ptr(), _WS_BYTES
+    if a2 is not None:
+        d.A2, d.lda2, d.k_split = a2.data_ptr(), lda2, Ka
+    d.zero_rows = zero_rows
     if ln is not None:
         st, cs, eps = ln
         if st.dtype != torch.float32 or not st.is_contiguous() or st.dim() != 3 or st.shape[0] != M or \

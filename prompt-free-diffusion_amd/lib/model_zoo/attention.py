@@ -251,11 +251,16 @@ class CrossAttention(nn.Module, L._Packed):
                 st_o = None
                 if stats_out:   # the `x + bias` rows write their statistics with the add (same order as the GEMM epilogue)
                     st_o = torch.empty((B * N, out.shape[1] // 160, 2), dtype=torch.float32, device=out.device)
-                ops.add_rowvec(res[:z * N], b_o, out=out[:z * N], ln_out=None if st_o is None else st_o[:z * N])
                 q = self.to_q.hip(x[z * N:], ln=None if ln is None else (ln[0], ln[1][z * N:]))
                 o = ops.attention(q, k[z * context.Nkp:], vt[:, z * context.Nkp:], Bc, H, N, context.Nk, D,
                                   self.scale, ldq=Cd, ldk=Cd, ldvt=B * context.Nkp, q_bs=N * Cd,
                                   k_bs=context.Nkp * Cd, vt_bs=context.Nkp)
+                if ops.wide_tile_ok(w_o.shape[0], Cd):
+                    # ONE out-projection launch for the whole batch: the zero-context rows are `zero_rows` of the
+                    # operand (their tiles skip the K loop: bias + residual, statistics from the same store pass)
+                    ops.gemm(o, w_o, bias=b_o, res=res, out=out, zero_rows=z * N, ln_out=st_o)
+                    return (out, st_o) if stats_out else out
+                ops.add_rowvec(res[:z * N], b_o, out=out[:z * N], ln_out=None if st_o is None else st_o[:z * N])
                 if stats_out:
                     self.to_out[0].hip(o, res=res[z * N:], out=out[z * N:], ln_out=st_o[z * N:])
                     return out, st_o

@@ -179,9 +179,13 @@ class ResBlock(TimestepBlock):
         elif skip.kernel_size[0] == 1:
             w, b = skip._pk()
             B, H, W_, _ = x.shape
-            sk = ops.gemm(x.view(-1, C1), w[:, :C1], bias=b, k=C1)
-            if x2 is not None:
-                sk = ops.gemm(x2.view(-1, C2), w[:, C1:], res=sk, k=C2, out=sk)
+            if x2 is not None and ops.wide_tile_ok(w.shape[0], C1 + C2) and C1 % 64 == 0:
+                # `skip_connection(torch.cat([h, skip], 1))` (:274 after pfd.py:356) as ONE contraction over two sources
+                sk = ops.gemm(x.view(-1, C1), w, bias=b, a2=x2.view(-1, C2), k=C1 + C2)
+            else:
+                sk = ops.gemm(x.view(-1, C1), w[:, :C1], bias=b, k=C1)
+                if x2 is not None:
+                    sk = ops.gemm(x2.view(-1, C2), w[:, C1:], res=sk, k=C2, out=sk)
             sk = sk.view(B, H, W_, -1)
         else:
             assert x2 is None
