@@ -83,7 +83,6 @@ struct G160Params {
   const half_t* A2;        // channels >= gn_c1 of the virtual concat (GroupNorm prologue) / columns >= k_split (linear)
   long lda2;
   int gn_c1, gn_act;
-  int pf;                  // patch kernel, 3-stage form: A fragments of the next tap requested before its barrier
   int k_split;             // linear kernels: K tiles at k >= k_split come from A2 (== K when there is no second source)
   int zero_rows;           // linear kernels: operand rows below this are all zero and are never read (PfdGemmDesc.zero_rows)
 };
@@ -1366,10 +1365,8 @@ __global__ __launch_bounds__(768) void conv3x3_patch_ws_kernel(const G160Params 
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap) {
           if (more) {
-            // tap 8: only W(first tap of the next block) may stay in flight, i.e. the patch pieces of taps 5 / 6 have
-            // landed too -- the consumers prefetch their first A fragments of the next block behind THIS barrier
-            if (tap == 0 || tap == 8) __builtin_amdgcn_s_waitcnt(0x0F70 | 5);
-            else if (tap == 1) __builtin_amdgcn_s_waitcnt(0x0F70 | 7);
+            if (tap == 0) __builtin_amdgcn_s_waitcnt(0x0F70 | 5);
+            else if (tap == 1 || tap == 8) __builtin_amdgcn_s_waitcnt(0x0F70 | 7);
             else __builtin_amdgcn_s_waitcnt(0x0F70 | 9);
           } else {
             if (tap <= 7) __builtin_amdgcn_s_waitcnt(0x0F70 | 5);
@@ -1485,55 +1482,6 @@ __global__ __launch_bounds__(768) void conv3x3_patch_ws_kernel(const G160Params 
         }
       }
       if (!g1) block_barrier();                 // (B)
-    } else if (NWS == 3 && p.pf) {
-      // The patch of a channel block is complete in LDS for all nine taps; only the weight tile changes per tap.  So
-      // the A fragments of the NEXT tap's first half step do not depend on its barrier: they are requested behind the
-      // MFMAs of the current tap (16 spare registers in this loop) and the five weight fragments are the only LDS
-      // reads between a barrier and the first MFMA (was: 8 reads x 8 waves = 64 KB in front of every tap).  Across a
-      // channel-block boundary the next patch has landed one barrier early (loader wait at tap 8 above).
-      int stage = 0, tap = 0, ci = 0, toff = 0;
-      const char* patch = smem;
-      half8_t an[WMB];
-      for (int st = 0; st < nsteps; ++st) {
-        block_barrier();                        // (A)
-        const char* wt = smem + OFF_W + stage * WT_BYTES;
-        half8_t bf[5];
-#pragma unroll
-        for (int j = 0; j < 5; ++j) bf[j] = *reinterpret_cast<const half8_t*>(wt + boff0 + j * 16 * ROWB);
-        if (st == 0) {
-#pragma unroll
-          for (int i = 0; i < WMB; ++i) an[i] = *reinterpret_cast<const half8_t*>(patch + a_off(i, toff, 0));
-        }
-#pragma unroll
-        for (int i = 0; i < WMB; ++i)
-#pragma unroll
-          for (int j = 0; j < 5; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[j], an[i], acc[i][j], 0, 0, 0);
-        {
-          half8_t af[WMB], bg[5];
-#pragma unroll
-          for (int i = 0; i < WMB; ++i) af[i] = *reinterpret_cast<const half8_t*>(patch + a_off(i, toff, 1));
-#pragma unroll
-          for (int j = 0; j < 5; ++j) bg[j] = *reinterpret_cast<const half8_t*>(wt + boff1 + j * 16 * ROWB);
-#pragma unroll
-          for (int i = 0; i < WMB; ++i)
-#pragma unroll
-            for (int j = 0; j < 5; ++j)
-              acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bg[j], af[i], acc[i][j], 0, 0, 0);
-        }
-        // state of the next step, then its first A fragments (the read past the last step hits valid LDS and is unused)
-        if (++stage == NWS) stage = 0;
-        ++toff;
-        if (++tap == 9) {
-          tap = 0; toff = 0; ++ci;
-          patch = smem + (ci & 1) * PATCH_BYTES;
-        } else if (tap == 3 || tap == 6) {
-          toff += PW - 3;
-        }
-#pragma unroll
-        for (int i = 0; i < WMB; ++i) an[i] = *reinterpret_cast<const half8_t*>(patch + a_off(i, toff, 0));
-      }
-      block_barrier();                          // (B)
     } else {
       int stage = 0;
       for (int ci = 0; ci < ncbs; ++ci) {
@@ -1669,11 +1617,9 @@ inline bool patch_ring_on() {
   static const bool on = !(getenv("PFD_PATCH_RING") && atoi(getenv("PFD_PATCH_RING")) == 0);
   return on;
 }
-// ... and its A-fragment prefetch across the tap barrier: PFD_PATCH_PF=0 reads all fragments behind the barrier
-inline bool patch_pf_on() {
-  static const bool on = !(getenv("PFD_PATCH_PF") && atoi(getenv("PFD_PATCH_PF")) == 0);
-  return on;
-}
+// (Also tried in round 4 and removed: requesting the next tap's A fragments before its barrier -- the patch is stable in
+//  LDS for all nine taps, so only the weight fragments have to sit behind the barrier.  No effect: 7.32 / 7.41 vs 7.42 / 7.38 ms
+//  per replayed pass, 507 vs 510 ms per batch; profiles/r04_patch_prefetch_ab.log.)
 // same for the loader-wave implicit-GEMM kernel (gemm160ws_kernel): PFD_WS_RING=0 keeps two stages
 inline bool ws_ring_on() {
   static const bool on = !(getenv("PFD_WS_RING") && atoi(getenv("PFD_WS_RING")) == 0);
@@ -1770,7 +1716,6 @@ int launch_patch(G160Params& p, hipStream_t s, int ws) {
   p.tiles_n = p.N / BN;
   p.nmajor = pick_nmajor(p);
   p.krot = krot_mode() == 2;
-  p.pf = patch_pf_on() ? 1 : 0;
   const int ncb = p.Cin / BK;
   p.kt_per_split = (ncb + p.splits - 1) / p.splits;   // channel blocks per split
   p.splits = (ncb + p.kt_per_split - 1) / p.kt_per_split;
@@ -1841,7 +1786,6 @@ int pfd_gemm160_try(const PfdGemmDesc* d, int variant, int splits, hipStream_t s
   p.tiles_m = p.tiles_n = 0;
   p.kt_per_split = 0;
   p.pt_w = p.pt_sh = 0;
-  p.pf = 0;
   p.gn_table = (const float*)d->gn_table; p.A2 = (const half_t*)d->A2; p.lda2 = d->lda2;
   p.gn_c1 = d->gn_c1; p.gn_act = d->gn_act;
   p.ln_in = (const float2*)d->ln_stats; p.ln_cs = (const float*)d->ln_colsum; p.ln_P = d->ln_parts; p.ln_eps = d->ln_eps;

@@ -872,6 +872,210 @@ static void bench_ln(const char* label, int M, int C) {
   fflush(stdout);
 }
 
+// ------------------------------------------------------------------------------------------------
+// --winograd: Winograd F(2x2, 3x3) PROTOTYPE (selftest only; nothing here is linked into libpfd_hip.so).
+// the one exact-in-real-arithmetic lever on the 3x3 convolutions (2.25x fewer MACs).  Built the
+// way a product version would have to start: input transform V = B^T d B (4x4 tiles with stride 2, zero padding; one
+// pass, fp32 math, fp16 out), 16 GEMMs M_k = V_k U_k^T on the library's own wide-tile kernels (U = G g G^T transformed in
+// fp64 on the host and rounded to fp16), inverse transform Y = A^T M A (+ bias) -- measured against the patch kernel on
+// the same operands, with the error of both against an fp64 direct convolution at a shape the CPU can check.
+// ------------------------------------------------------------------------------------------------
+typedef _Float16 h16x8 __attribute__((ext_vector_type(8)));
+
+// x [B,H,W,C] f16 -> V [16][T][C] f16, T = B * (H/2) * (W/2); one thread = one tile x 8 channels
+__global__ void wino_input_kernel(const h16* __restrict__ x, h16* __restrict__ V, int B, int H, int W, int C) {
+  const int cv = C / 8;
+  const long T = (long)B * (H / 2) * (W / 2);
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= T * cv) return;
+  const long t = i / cv;
+  const int c0 = (int)(i - t * cv) * 8;
+  const int tw = W / 2, th = H / 2;
+  const int b = (int)(t / (th * tw));
+  const int ty = (int)((t / tw) % th), tx = (int)(t % tw);
+  float d[4][4][8];
+#pragma unroll
+  for (int r = 0; r < 4; ++r)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int y = 2 * ty - 1 + r, xx = 2 * tx - 1 + q;
+      h16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+      if (y >= 0 && y < H && xx >= 0 && xx < W) v = *reinterpret_cast<const h16x8*>(x + (((long)b * H + y) * W + xx) * C + c0);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) d[r][q][e] = (float)v[e];
+    }
+  // B^T d B, B^T = [1 0 -1 0; 0 1 1 0; 0 -1 1 0; 0 1 0 -1]
+  float tmp[4][4][8];
+#pragma unroll
+  for (int q = 0; q < 4; ++q)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      tmp[0][q][e] = d[0][q][e] - d[2][q][e];
+      tmp[1][q][e] = d[1][q][e] + d[2][q][e];
+      tmp[2][q][e] = d[2][q][e] - d[1][q][e];
+      tmp[3][q][e] = d[1][q][e] - d[3][q][e];
+    }
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    h16x8 o[4];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      o[0][e] = (h16)(tmp[r][0][e] - tmp[r][2][e]);
+      o[1][e] = (h16)(tmp[r][1][e] + tmp[r][2][e]);
+      o[2][e] = (h16)(tmp[r][2][e] - tmp[r][1][e]);
+      o[3][e] = (h16)(tmp[r][1][e] - tmp[r][3][e]);
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) *reinterpret_cast<h16x8*>(V + ((long)(r * 4 + q) * T + t) * C + c0) = o[q];
+  }
+}
+
+// Mk [16][T][N] f16 -> y [B,H,W,N] f16 (+ bias); one thread = one tile x 8 channels.  A^T = [1 1 1 0; 0 1 -1 -1]
+__global__ void wino_output_kernel(const h16* __restrict__ Mk, const h16* __restrict__ bias, h16* __restrict__ y, int B, int H,
+                                   int W, int N) {
+  const int nv = N / 8;
+  const long T = (long)B * (H / 2) * (W / 2);
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= T * nv) return;
+  const long t = i / nv;
+  const int n0 = (int)(i - t * nv) * 8;
+  const int tw = W / 2, th = H / 2;
+  const int b = (int)(t / (th * tw));
+  const int ty = (int)((t / tw) % th), tx = (int)(t % tw);
+  float m[4][4][8];
+#pragma unroll
+  for (int k = 0; k < 16; ++k) {
+    const h16x8 v = *reinterpret_cast<const h16x8*>(Mk + ((long)k * T + t) * N + n0);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) m[k >> 2][k & 3][e] = (float)v[e];
+  }
+  const h16x8 bv = *reinterpret_cast<const h16x8*>(bias + n0);
+  float tmp[2][4][8];
+#pragma unroll
+  for (int q = 0; q < 4; ++q)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      tmp[0][q][e] = m[0][q][e] + m[1][q][e] + m[2][q][e];
+      tmp[1][q][e] = m[1][q][e] - m[2][q][e] - m[3][q][e];
+    }
+#pragma unroll
+  for (int r = 0; r < 2; ++r) {
+    h16x8 o0, o1;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      o0[e] = (h16)(tmp[r][0][e] + tmp[r][1][e] + tmp[r][2][e] + (float)bv[e]);
+      o1[e] = (h16)(tmp[r][1][e] - tmp[r][2][e] - tmp[r][3][e] + (float)bv[e]);
+    }
+    h16* row = y + (((long)b * H + 2 * ty + r) * W + 2 * tx) * N + n0;
+    *reinterpret_cast<h16x8*>(row) = o0;
+    *reinterpret_cast<h16x8*>(row + N) = o1;
+  }
+}
+
+// one shape: times (and, if check, verifies against fp64) the direct patch-kernel convolution and the Winograd pipeline
+static void winograd_case(const char* label, int B, int H, int Cin, int N, bool check) {
+  const int W = H, M = B * H * W, K = 9 * Cin;
+  const long T = (long)B * (H / 2) * (W / 2);
+  auto x = rand_h((size_t)M * Cin), wt = rand_h((size_t)N * K, 1.7f / sqrtf((float)K)), bias = rand_h(N, 0.5f);
+  // U_k[n][c] = (G g G^T)[k], G = [1 0 0; .5 .5 .5; .5 -.5 .5; 0 0 1]; direct weight layout is [N][ky][kx][Cin]
+  std::vector<h16> U((size_t)16 * N * Cin);
+  static const double G[4][3] = {{1, 0, 0}, {0.5, 0.5, 0.5}, {0.5, -0.5, 0.5}, {0, 0, 1}};
+  for (int n = 0; n < N; ++n)
+    for (int c = 0; c < Cin; ++c) {
+      double g[3][3], t1[4][3];
+      for (int a = 0; a < 3; ++a)
+        for (int b2 = 0; b2 < 3; ++b2) g[a][b2] = (double)wt[(size_t)n * K + (a * 3 + b2) * Cin + c];
+      for (int a = 0; a < 4; ++a)
+        for (int b2 = 0; b2 < 3; ++b2) t1[a][b2] = G[a][0] * g[0][b2] + G[a][1] * g[1][b2] + G[a][2] * g[2][b2];
+      for (int a = 0; a < 4; ++a)
+        for (int b2 = 0; b2 < 4; ++b2)
+          U[((size_t)(a * 4 + b2) * N + n) * Cin + c] = (h16)(t1[a][0] * G[b2][0] + t1[a][1] * G[b2][1] + t1[a][2] * G[b2][2]);
+    }
+  Dev<h16> dx(x), dw(wt), db(bias), dU(U), dV((size_t)16 * T * Cin), dM((size_t)16 * T * N), dy((size_t)M * N), dyw((size_t)M * N);
+  Dev<float> dWS((size_t)24 << 20);
+  PfdGemmDesc d;
+  memset(&d, 0, sizeof(d));
+  d.A = dx.p; d.W = dw.p; d.bias = db.p; d.C = dy.p; d.lda = Cin; d.ldw = K; d.ldc = N; d.M = M; d.N = N; d.K = K; d.rows_per_rv = 1;
+  d.ksize = 3; d.stride = 1; d.pad = 1; d.B = B; d.H = H; d.Wd = W; d.Cin = Cin; d.Ho = H; d.Wo = W;
+  d.ws = dWS.p; d.ws_bytes = (size_t)96 << 20;
+  int rc = 0;
+  const float t_direct = time_ms([&] { rc |= pfd_gemm_f16(&d, nullptr); }, 20) * 1e3f;
+  PfdGemmDesc g;
+  memset(&g, 0, sizeof(g));
+  g.lda = Cin; g.ldw = Cin; g.ldc = N; g.M = (int)T; g.N = N; g.K = Cin; g.rows_per_rv = 1; g.ws = dWS.p; g.ws_bytes = (size_t)96 << 20;
+  const unsigned gi = (unsigned)((T * (Cin / 8) + 255) / 256), go = (unsigned)((T * (N / 8) + 255) / 256);
+  auto in_t = [&] { hipLaunchKernelGGL(wino_input_kernel, dim3(gi), dim3(256), 0, nullptr, dx.p, dV.p, B, H, W, Cin); };
+  auto gemms = [&] {
+    for (int k = 0; k < 16; ++k) {
+      g.A = dV.p + (size_t)k * T * Cin; g.W = dU.p + (size_t)k * N * Cin; g.C = dM.p + (size_t)k * T * N;
+      rc |= pfd_gemm_f16(&g, nullptr);
+    }
+  };
+  auto out_t = [&] { hipLaunchKernelGGL(wino_output_kernel, dim3(go), dim3(256), 0, nullptr, dM.p, db.p, dyw.p, B, H, W, N); };
+  const float t_in = time_ms(in_t, 20) * 1e3f, t_g = time_ms(gemms, 10) * 1e3f, t_out = time_ms(out_t, 20) * 1e3f;
+  const float t_all = time_ms([&] { in_t(); gemms(); out_t(); }, 10) * 1e3f;
+  // optimistic bound for a batched / fused product kernel: the same MACs and activation traffic as ONE launch (16 T rows
+  // against one weight matrix: 1/16 of the weight traffic, no launch boundaries between the 16 GEMMs)
+  PfdGemmDesc o = g;
+  o.A = dV.p; o.W = dU.p; o.C = dM.p; o.M = (int)(16 * T);
+  const float t_one = time_ms([&] { rc |= pfd_gemm_f16(&o, nullptr); }, 10) * 1e3f;
+  printf("winograd %-26s M%-6d N%-5d K%-6d rc=%d | direct %7.1f us (%6.1f TF/s) | F(2x2,3x3): transform %6.1f + 16 GEMMs %7.1f "
+         "+ inverse %6.1f = %7.1f us (x%.2f of direct); 16 GEMMs as one launch %7.1f us -> lower bound %7.1f us (x%.2f)\n",
+         label, M, N, K, rc, t_direct, 2.0 * M * N * K / t_direct * 1e-6, t_in, t_g, t_out, t_all, t_all / t_direct, t_one,
+         t_in + t_one + t_out, (t_in + t_one + t_out) / t_direct);
+  // the two results must agree with each other at the shape being timed (fp16 noise)
+  {
+    in_t(); gemms(); out_t();
+    rc |= pfd_gemm_f16(&d, nullptr);
+    auto a = dy.get(), b2 = dyw.get();
+    double worst = 0, rms = 0;
+    for (size_t i = 0; i < a.size(); ++i) { const double e = fabs((double)a[i] - (double)b2[i]); worst = std::max(worst, e); rms += e * e; }
+    printf("         winograd vs direct on the GPU: max |diff| %.3e, rms %.3e\n", worst, sqrt(rms / a.size()));
+  }
+  if (check) {   // fp64 direct convolution on the host
+    std::vector<double> ref((size_t)M * N);
+    for (int m = 0; m < M; ++m) {
+      const int b = m / (H * W), oy = (m / W) % H, ox = m % W;
+      for (int n = 0; n < N; ++n) {
+        double sacc = (double)bias[n];
+        for (int ky = 0; ky < 3; ++ky)
+          for (int kx = 0; kx < 3; ++kx) {
+            const int iy = oy + ky - 1, ix = ox + kx - 1;
+            if (iy < 0 || iy >= H || ix < 0 || ix >= W) continue;
+            const h16* ap = &x[(((size_t)b * H + iy) * W + ix) * Cin];
+            const h16* wp = &wt[(size_t)n * K + (ky * 3 + kx) * Cin];
+            for (int c = 0; c < Cin; ++c) sacc += (double)ap[c] * (double)wp[c];
+          }
+        ref[(size_t)m * N + n] = sacc;
+      }
+    }
+    auto a = dy.get(), b2 = dyw.get();
+    double ed = 0, ew = 0, rd = 0, rw = 0, rr = 0;
+    for (size_t i = 0; i < ref.size(); ++i) {
+      const double e1 = fabs((double)a[i] - ref[i]), e2 = fabs((double)b2[i] - ref[i]);
+      ed = std::max(ed, e1); ew = std::max(ew, e2); rd += e1 * e1; rw += e2 * e2; rr += ref[i] * ref[i];
+    }
+    printf("         error vs fp64 direct convolution (output rms %.3f): direct max %.3e rel-L2 %.3e | winograd max %.3e rel-L2 %.3e "
+           "(x%.1f)\n", sqrt(rr / ref.size()), ed, sqrt(rd / rr), ew, sqrt(rw / rr), sqrt(rw / rd));
+    ++g_total;
+    if (!(sqrt(rw / rr) < 1e-2)) { ++g_fail; printf("FAIL winograd prototype is not a convolution\n"); }
+  }
+  fflush(stdout);
+}
+
+static int winograd_main() {
+  // numerics at a shape the host can check (same K structure as the UNet's 320 -> 320 convolutions)
+  winograd_case("check 320->320 @16^2", 1, 16, 320, 320, true);
+  winograd_case("check 1280->1280 @8^2", 1, 8, 1280, 1280, true);
+  // the four dominant 3x3 shapes of a C2 UNet pass (UNet batch 8)
+  winograd_case("320->320 @64^2", 8, 64, 320, 320, false);
+  winograd_case("960->320 @64^2", 8, 64, 960, 320, false);
+  winograd_case("640->640 @32^2", 8, 32, 640, 640, false);
+  winograd_case("1280->1280 @16^2", 8, 16, 1280, 1280, false);
+  printf("%d checks, %d failed\n", g_total, g_fail);
+  return g_fail ? 1 : 0;
+}
+
 // Per-launch floor of the runtime: N dependent launches of a kernel with ~no work, in-stream and as one
 // hipGraph -- what every one of the ~500 launches of a UNet pass pays on top of its own duration.
 static void bench_launch_floor() {
@@ -1028,6 +1232,7 @@ static int replay(const char* path, bool timed = false, int force_tile = 0) {
 int main(int argc, char** argv) {
   if (argc > 2 && !strcmp(argv[1], "--replay")) return replay(argv[2]);
   if (argc > 1 && !strcmp(argv[1], "--launch-floor")) { bench_launch_floor(); return 0; }
+  if (argc > 1 && !strcmp(argv[1], "--winograd")) return winograd_main();
   if (argc > 1 && !strcmp(argv[1], "--bench-patch")) {   // one 3x3 conv per image width the patch kernel serves
     bench_gemm("conv3x3 320->320 @64^2", 0, 320, 0, 3, 8, 64, 320, 0);
     bench_gemm("conv3x3 640->640 @32^2", 0, 640, 0, 3, 8, 32, 640, 0);

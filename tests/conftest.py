@@ -18,6 +18,58 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+class _OracleJobs:
+    """The long fp32 CPU-oracle trajectories (tests/oracle_worker.py: C2 50 steps, C5 31 steps, C3 10 steps) run as
+    CPU-only subprocesses from the start of a GPU session, next to the rest of the suite; a trajectory test asks for its
+    case and waits for it.  Same oracle code, same inputs, same comparison -- only the wall-clock overlaps (the suite was
+    21 minutes with the three runs in line, 18 of them oracle time)."""
+
+    def __init__(self, cases):
+        import subprocess
+        import tempfile
+        self.dir = tempfile.mkdtemp(prefix="pfd_oracle_")
+        ncpu = os.cpu_count() or 1
+        threads = max(1, min(64, ncpu // max(1, len(cases) + 1)))
+        env = dict(os.environ, HIP_VISIBLE_DEVICES="", CUDA_VISIBLE_DEVICES="", OMP_NUM_THREADS=str(threads))
+        self.procs = {}
+        for c in cases:
+            out = os.path.join(self.dir, c + ".pt")
+            log = open(os.path.join(self.dir, c + ".log"), "w")
+            self.procs[c] = (subprocess.Popen([sys.executable, os.path.join(REPO, "tests", "oracle_worker.py"), c, out,
+                                               str(threads)], stdout=log, stderr=subprocess.STDOUT, env=env), out, log)
+
+    def get(self, case, timeout=3000):
+        if case not in self.procs:     # not started at session begin: start it now
+            self.procs.update(_OracleJobs([case]).procs)
+        proc, out, log = self.procs[case]
+        rc = proc.wait(timeout=timeout)
+        log.close()
+        if rc != 0 or not os.path.exists(out):
+            raise RuntimeError(f"oracle job {case} failed (rc {rc}):\n" + open(log.name).read()[-3000:])
+        return torch.load(out)
+
+    def close(self):
+        for proc, _, log in self.procs.values():
+            if proc.poll() is None:
+                proc.kill()
+            if not log.closed:
+                log.close()
+
+
+@pytest.fixture(scope="session", autouse=True)
+def oracle_jobs(request):
+    """started at session begin iff trajectory tests are among the selected items (a `-m gpu` run)"""
+    want = []
+    for item in request.session.items:
+        for case, name in (("c5", "test_config_c5_trajectory_all_31_steps"), ("c2", "test_config_c2_trajectory_vs_oracle"),
+                           ("c3", "test_config_c3_trajectory_vs_oracle")):
+            if item.name == name and case not in want:
+                want.append(case)
+    jobs = _OracleJobs(want) if (want and torch.cuda.is_available()) else _OracleJobs([])
+    yield jobs
+    jobs.close()
+
+
 @pytest.fixture(scope="session")
 def golden():
     return dict(np.load(os.path.join(REPO, "tests", "golden", "golden.npz"), allow_pickle=False))
