@@ -162,6 +162,17 @@ typedef struct PfdGemmDesc {
    *   178-201) in ONE launch with the conditional half, statistics (ln_out) included.  Not with ln_stats. */
   int32_t k_split;
   int32_t zero_rows;
+  /* GroupNorm statistics of the OUTPUT from the launch that stores it (ABI 8; `GroupNorm32 -> SiLU -> conv` /
+   * SpatialTransformer.norm read what a convolution or out-projection just wrote: openaimodel.py:200-226, 254-274,
+   * attention.py:83-84, 352-371): with gn_out != NULL the store pass (or the split-K reduction) also writes, for every
+   * slab of 64 consecutive output rows and every group of N / 32 output channels, (sum x, sum x^2) of the f16 values it
+   * stored:  gn_out[(slab * (N / 160) + n / 160) * 16 + (n % 160) / (N / 32)]  (float2; slab = m / 64; 16 slots per
+   * 160-column tile of which 160 / (N / 32) are used).  pfd_groupnorm_pstats_f16 normalises from these sums: the
+   * statistics pass over the tensor (a third of the two-launch GroupNorm) disappears.  Fixed summation order
+   * (deterministic); per-sample as long as a slab does not straddle two samples (rows per sample % 64 == 0).
+   * Wide-tile kernels only: N % 160 == 0, N / 32 >= 8 and a divisor of 160 (N = 320 | 640 | 1280), M % 64 == 0,
+   * act != GEGLU, no Ct / ln_out / bias_per_row; anything else is PFD_ESHAPE. */
+  void* gn_out;
 } PfdGemmDesc;
 int pfd_gemm_f16(const PfdGemmDesc* d, pfd_stream_t stream);
 /* Same, with the kernel variant forced (tests and tuning only); 0 = the library's heuristic.
@@ -241,6 +252,18 @@ int pfd_swin_window_attention_f16(const PfdSwinAttnDesc* d, pfd_stream_t stream)
  * C1, C2 % 8 == 0; (C1+C2) % G == 0.
  * ---------------------------------------------------------------------------------- */
 size_t pfd_groupnorm_ws_bytes(int32_t B, int32_t C, int32_t HW);
+/* GroupNorm(+SiLU) from the statistics its producers emitted (PfdGemmDesc.gn_out) -- ONE launch, no pass over the input
+ * for statistics.  x1 / x2 as in pfd_groupnorm_f16 (virtual channel concat); st1 / st2 are the gn_out arrays of the
+ * launches that wrote x1 / x2 (float2 [B * HW / 64][C_src / 160][16]; st2 NULL iff C2 == 0).  A group of this norm
+ * ((C1 + C2) / G channels) must be a whole number of producer groups (C_src / 32 channels) of ONE source and the shape must
+ * be one pfd_groupnorm_f16 would serve with its two-launch form: pfd_groupnorm_takes_pstats says so (1 / 0); otherwise
+ * PFD_ESHAPE and callers run pfd_groupnorm_f16.  Same normalisation arithmetic as pfd_groupnorm_f16; the statistics are
+ * sums in a different (fixed) order, i.e. equal up to fp32 rounding. */
+int32_t pfd_groupnorm_takes_pstats(int32_t B, int32_t C1, int32_t C2, int32_t HW, int32_t G);
+int pfd_groupnorm_pstats_f16(const void* x1, int32_t C1, int64_t ldx1, const void* st1, const void* x2, int32_t C2,
+                             int64_t ldx2, const void* st2, const void* gamma, const void* beta, void* y, int64_t ldy,
+                             int32_t B, int32_t HW, int32_t G, float eps, int32_t act, pfd_stream_t stream);
+
 /* GroupNorm statistics only: writes table[b][0][c] = rstd * gamma[c], table[b][1][c] = beta[c] - mean * rstd * gamma[c]
  * (f32 [B, 2, C1+C2], 16-byte aligned) for PfdGemmDesc.gn_table -- same arguments and workspace as pfd_groupnorm_f16 minus y / act. */
 int pfd_groupnorm_table_f16(const void* x1, int32_t C1, int64_t ldx1, const void* x2, int32_t C2, int64_t ldx2,

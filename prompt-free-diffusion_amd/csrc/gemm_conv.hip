@@ -342,6 +342,10 @@ extern "C" int pfd_gemm_f16_ex(const PfdGemmDesc* d, int32_t tile, pfd_stream_t 
     pfd_set_error("pfd_gemm_f16: the GroupNorm prologue is served by the 3x3 patch kernel only (see PfdGemmDesc.gn_table)");
     return PFD_ESHAPE;
   }
+  if (d->gn_out) {
+    pfd_set_error("pfd_gemm_f16: GroupNorm statistics of the output are emitted by the wide-tile kernels only (see PfdGemmDesc.gn_out)");
+    return PFD_ESHAPE;
+  }
   if (d->k_split > 0 || d->zero_rows > 0) {
     pfd_set_error("pfd_gemm_f16: k_split / zero_rows are served by the wide-tile linear kernels only (see PfdGemmDesc.k_split)");
     return PFD_ESHAPE;

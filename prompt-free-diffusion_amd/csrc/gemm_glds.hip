@@ -83,6 +83,7 @@ struct G160Params {
   const half_t* A2;        // channels >= gn_c1 of the virtual concat (GroupNorm prologue) / columns >= k_split (linear)
   long lda2;
   int gn_c1, gn_act;
+  float2* gn_out;          // GroupNorm statistics of the OUTPUT, per 64-row slab and group (PfdGemmDesc.gn_out); nullptr = none
   int k_split;             // linear kernels: K tiles at k >= k_split come from A2 (== K when there is no second source)
   int zero_rows;           // linear kernels: operand rows below this are all zero and are never read (PfdGemmDesc.zero_rows)
 };
@@ -97,6 +98,24 @@ __device__ __forceinline__ const half_t* w_row_ptr(const G160Params& p, int n, i
   if (p.w_tu == 0) return p.W + (long)n * p.ldw + c8;
   const int tn = n / p.w_tu;
   return p.W + ((long)tn * (p.K / BK) * p.w_tu + (n - tn * p.w_tu)) * BK + c8;
+}
+
+// Epilogue operands read LATE.  hipcc loads every kernel-argument field a kernel uses with one batch of s_load at the entry
+// and keeps it in SGPRs until its last use: the ~25 scalars only the epilogue needs (bias / row-vector / residual / output
+// pointers and strides, statistics pointers, M, N ...) then sit on top of the main loop's own scalars for the whole launch,
+// and the 12-wave patch kernel -- whose loader setup is at the 102-SGPR limit -- spills.  The epilogue of that kernel
+// reads its copy of the argument block through an opaque pointer instead: the loads are issued where the copy is made.
+__device__ __forceinline__ G160Params reload_params() {
+  typedef __attribute__((address_space(4))) const unsigned* KArgPtr;
+  KArgPtr k = (KArgPtr)__builtin_amdgcn_kernarg_segment_ptr();   // the G160Params block is the kernel's only argument (offset 0)
+  asm volatile("" : "+s"(k)::"memory");                          // loads below cannot be hoisted above this point
+  static_assert(sizeof(G160Params) % 4 == 0, "argument block read as dwords");
+  unsigned w[sizeof(G160Params) / 4];
+#pragma unroll
+  for (unsigned i = 0; i < sizeof(G160Params) / 4; ++i) w[i] = k[i];
+  G160Params q;
+  __builtin_memcpy(&q, w, sizeof(q));
+  return q;
 }
 
 // output row (index into M) of row `row` of the tile that starts at m0 (see G160Params.pt_w)
@@ -320,15 +339,132 @@ __device__ __forceinline__ bool epilogue_stage(float4_t (&acc)[WMB][NT], const G
   return true;
 }
 
+// ---- GroupNorm statistics from the producer (PfdGemmDesc.gn_out, round 4) ------------------------------------------
+// Every GroupNorm input of the UNet is written by one of these store passes (or by the split-K reduce below), so the
+// statistics pass of the two-launch GroupNorm (a full extra read of the tensor: 14.8 ms of a 532 ms batch) is replaced by
+// partial sums the producer forms from the f16 values it stores: per slab of 64 consecutive rows of a tile and per group
+// of cpg = N / 32 output channels, (sum x, sum x^2) -> gn_out[(slab * (N / 160) + n0 / 160) * 16 + local group].  The slab
+// height is 64 whatever the tile height, so the layout (and the consumer, pfd_groupnorm_pstats_f16) does not depend on
+// the tile variant the heuristic picked.  Fixed summation order: deterministic.
+// Thread mapping: a wave covers 3 rows x 20 chunks of 16 bytes (lanes 60-63 idle), the block sweeps 3 W rows at a time;
+// a lane keeps 8 column sums + 8 sums of squares per slab.  Reduction: the three lanes of a wave that own the same chunk
+// (2 bpermutes per value), then across waves and over a group's columns through the slab's own, now dead, image region.
+constexpr int GN_SLAB = 64;
+
+// cs / cq: this lane's partial column sums of its chunk of ITS slab (wave w works on slab w / WPS, WPS = waves per slab,
+// so a lane carries 16 sums whatever the tile height).  red_base(s): scratch of slab s (>= (WPS + 1) * 1280 bytes).
+template <int NSLAB, int NTHREADS, class RedBase>
+__device__ __forceinline__ void gn_slab_reduce(float (&cs)[8], float (&cq)[8], int tid, int cpg, int slab0, int nslab_total,
+                                               int tiles_n, int tile_n, float2* __restrict__ out, RedBase red_base) {
+  constexpr int W = NTHREADS / 64, WPS = W / NSLAB;
+  static_assert(W % NSLAB == 0, "whole waves per slab");
+  const int lane = tid & 63, w = tid >> 6;
+  const int cc = lane % 20;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    cs[e] += __shfl(cs[e], (lane + 20) & 63, 64) + __shfl(cs[e], (lane + 40) & 63, 64);
+    cq[e] += __shfl(cq[e], (lane + 20) & 63, 64) + __shfl(cq[e], (lane + 40) & 63, 64);
+  }
+  __syncthreads();   // every row of the staged image has been read: its slabs become scratch
+  if (lane < 20) {
+    float4_t* dst = reinterpret_cast<float4_t*>(red_base(w / WPS) + ((w % WPS) * 20 + cc) * 16);
+    dst[0] = (float4_t){cs[0], cs[1], cs[2], cs[3]};
+    dst[1] = (float4_t){cs[4], cs[5], cs[6], cs[7]};
+    dst[2] = (float4_t){cq[0], cq[1], cq[2], cq[3]};
+    dst[3] = (float4_t){cq[4], cq[5], cq[6], cq[7]};
+  }
+  __syncthreads();
+  for (int idx = tid; idx < NSLAB * 320; idx += NTHREADS) {   // (slab, chunk, element): sum over the slab's waves, first wave first
+    const int s = idx / 320, j = idx - s * 320;
+    const float* r = red_base(s) + j;
+    float a = 0.f;
+#pragma unroll
+    for (int ww = 0; ww < WPS; ++ww) a += r[ww * 320];
+    red_base(s)[WPS * 320 + j] = a;
+  }
+  __syncthreads();
+  const int ngl = 160 / cpg;
+  for (int idx = tid; idx < NSLAB * ngl; idx += NTHREADS) {   // (slab, local group): its cpg columns in ascending order
+    const int s = idx / ngl, gl = idx - s * ngl;
+    const float* fin = red_base(s) + WPS * 320;
+    float a = 0.f, q = 0.f;
+    for (int c = gl * cpg; c < (gl + 1) * cpg; ++c) {
+      a += fin[(c >> 3) * 16 + (c & 7)];
+      q += fin[(c >> 3) * 16 + 8 + (c & 7)];
+    }
+    if (slab0 + s < nslab_total)   // (a tile past M holds slabs that do not exist)
+      out[((long)(slab0 + s) * tiles_n + tile_n) * 16 + gl] = make_float2(a, q);
+  }
+}
+
+template <int BM, int NTHREADS, bool PT>
+__device__ __forceinline__ void epilogue_store_gn(const G160Params& p, int m0, int n0, int slab0, char* smem, int tid) {
+  constexpr int RS = stage_row_bytes(160);
+  constexpr int NSLAB = BM / GN_SLAB, W = NTHREADS / 64, WPS = W / NSLAB, SWEEP = 3 * WPS;
+  constexpr int ITERS = (GN_SLAB + SWEEP - 1) / SWEEP;
+  // residual chunks in flight together (the 12-wave kernels sit at their 168-register limit: two)
+  constexpr int UB = NTHREADS >= 768 ? 2 : (ITERS < 4 ? ITERS : 4);
+  static_assert(BM % GN_SLAB == 0 && W % NSLAB == 0 && (WPS + 1) * 1280 <= GN_SLAB * RS, "a slab's image region holds its scratch");
+  const int lane = tid & 63, w = tid >> 6;
+  const bool active = lane < 60;
+  const int rsub = lane / 20, cc = lane % 20;          // (idle lanes: rsub 3, masked below)
+  const int s = w / WPS;                               // this wave's slab
+  const int row0 = s * GN_SLAB + (w % WPS) * 3 + rsub;
+  const bool has_r = p.R != nullptr;
+  float cs[8], cq[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) cs[e] = cq[e] = 0.f;
+  for (int it0 = 0; it0 < ITERS; it0 += UB) {
+    Pack16 r[UB];
+    // the residual chunks of this group first, unconditional (clamped row): see store_pass below
+    if (has_r) {
+#pragma unroll
+      for (int u = 0; u < UB; ++u) {
+        const int row = min(row0 + (it0 + u) * SWEEP, (s + 1) * GN_SLAB - 1);
+        r[u].u = *reinterpret_cast<const uint4*>(p.R + (long)min(tile_row_m<PT>(p, m0, row), p.M - 1) * p.ldr + n0 + cc * 8);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < UB; ++u) {
+      const int row_u = row0 + (it0 + u) * SWEEP;
+      const int row = min(row_u, (s + 1) * GN_SLAB - 1);
+      const int m = tile_row_m<PT>(p, m0, row);
+      const bool ok = active && it0 + u < ITERS && row_u < (s + 1) * GN_SLAB && m < p.M;
+      Pack16 v;
+      v.u = *reinterpret_cast<const uint4*>(smem + row * RS + cc * 16);
+      if (has_r) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v.e[e] = (half_t)((float)v.e[e] + (float)r[u].e[e]);
+      }
+      if (ok) *reinterpret_cast<uint4*>(p.C + (long)m * p.ldc + n0 + cc * 8) = v.u;
+      const float mk = ok ? 1.f : 0.f;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float f = (float)v.e[e] * mk;
+        cs[e] += f;
+        cq[e] = fmaf(f, f, cq[e]);
+      }
+    }
+  }
+  gn_slab_reduce<NSLAB, NTHREADS>(cs, cq, tid, p.N / 32, slab0, p.M / GN_SLAB, p.N / 160, n0 / 160, p.gn_out,
+                                  [&](int sl) { return reinterpret_cast<float*>(smem + sl * GN_SLAB * RS); });
+}
+
 // pass 2 (every thread of the block, after a barrier): + residual, 16-byte chunks of contiguous row segments
 // LNOUT: compile the statistics-emitting store pass (linear kernels only: convolutions never feed a LayerNorm, and the
 // loader-wave kernels have no registers to spare for it)
 template <int BM, int NT, int NTHREADS, bool LNOUT = false, bool PT = false>
-__device__ __forceinline__ void epilogue_store(const G160Params& p, int m0, int n0, const char* smem, int tid) {
+__device__ __forceinline__ void epilogue_store(const G160Params& p, int m0, int n0, char* smem, int tid, int slab0 = 0) {
   constexpr int BN = 32 * NT;
   constexpr bool GEGLU_ONLY = NT == 10;
   if (!GEGLU_ONLY && (p.splits > 1 || (p.Ct && n0 >= p.n_split))) return;   // written directly by pass 1 (tile-uniform)
   const bool geglu = GEGLU_ONLY || p.act == PFD_ACT_GEGLU;
+  if constexpr (NT == 5) {
+    if (p.gn_out) {   // the store pass that also forms the GroupNorm statistics of what it stores (host: act != GEGLU, no Ct)
+      epilogue_store_gn<BM, NTHREADS, PT>(p, m0, n0, slab0, smem, tid);
+      return;
+    }
+  }
   if constexpr (LNOUT && !GEGLU_ONLY && (BN / 8) % 4 == 0) {
     if (p.ln_out) {
       // This launch's output feeds a LayerNorm that is folded into ITS consumer GEMM: emit the partial row sums
@@ -419,10 +555,10 @@ __device__ __forceinline__ void epilogue_store(const G160Params& p, int m0, int 
 template <int WMB, int NT, int NTHREADS, bool LNOUT = false, bool PT = false>
 __device__ __forceinline__ void epilogue160(float4_t (&acc)[WMB][NT], const G160Params& p, int lane, int m0,
                                             int n0, int wm, int wn, int split, char* smem, int tid,
-                                            const float2* lnstat = nullptr) {
+                                            const float2* lnstat = nullptr, int slab0 = 0) {
   epilogue_stage<WMB, NT, PT>(acc, p, lane, m0, n0, wm, wn, split, smem, lnstat);
   __syncthreads();
-  epilogue_store<(NTHREADS / 128) * WMB * 16, NT, NTHREADS, LNOUT, PT>(p, m0, n0, smem, tid);
+  epilogue_store<(NTHREADS / 128) * WMB * 16, NT, NTHREADS, LNOUT, PT>(p, m0, n0, smem, tid, slab0);
 }
 
 template <int WAVES_M, int WMB, bool CONV, int NBUF, int NT>
@@ -686,7 +822,7 @@ __global__ __launch_bounds__(WAVES_M * 128) void gemm160_kernel(const G160Params
   }
 
   epilogue160<WMB, NT, WAVES_M * 128, !CONV>(acc, p, lane, m0, n0, wm, wn, split, smem, tid,
-                                             (!CONV && p.ln_in) ? lnstat : nullptr);
+                                             (!CONV && p.ln_in) ? lnstat : nullptr, tile_m * (BM / GN_SLAB));
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -950,7 +1086,7 @@ __global__ __launch_bounds__(768) void gemm160ws_kernel(const G160Params p) {
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     block_barrier();                          // (C)
   }
-  epilogue_store<BM, NT, 768>(p, m0, n0, smem, tid);
+  epilogue_store<BM, NT, 768>(p, m0, n0, smem, tid, tile_m * (BM / GN_SLAB));
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1114,7 +1250,7 @@ __global__ __launch_bounds__(512) void conv3x3_patch_kernel(const G160Params p) 
       }
     }
   }
-  epilogue160<WMB, 5, 512, false, true>(acc, p, lane, m0, n0, wm, wn, split, smem, tid);
+  epilogue160<WMB, 5, 512, false, true>(acc, p, lane, m0, n0, wm, wn, split, smem, tid, nullptr, tile_m * (256 / GN_SLAB));
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1164,13 +1300,9 @@ __global__ __launch_bounds__(768) void conv3x3_patch_ws_kernel(const G160Params 
   const int m0 = b * hw + y0 * W + x0;          // first output pixel of the tile (see tile_row_m)
   const int ncbs = max(0, cb_end - cb_begin);
   const int nsteps = ncbs * 9;
-  // channel blocks are walked in rotated order (k_rotation): the i-th block of this tile is cbv(i)
-  const int cb_rot = k_rotation(p.krot, tile_m, p.tiles_m, ncbs);
-  auto cbv = [&](int i) -> int {
-    int c = i + cb_rot;
-    if (c >= ncbs) c -= ncbs;
-    return cb_begin + c;
-  };
+  // (the rotated K walk of the linear kernels -- k_rotation -- measured 2-3 % slower here and is not compiled in: the
+  //  loader setup of this kernel is at its scalar-register limit)
+  auto cbv = [&](int i) -> int { return cb_begin + i; };
 
   auto block_barrier = [&]() {
     __builtin_amdgcn_sched_barrier(0);
@@ -1516,11 +1648,15 @@ __global__ __launch_bounds__(768) void conv3x3_patch_ws_kernel(const G160Params 
       }
       block_barrier();                          // (B)
     }
-    epilogue_stage<WMB, 5, true>(acc, p, lane, m0, n0, wm, wn, split, smem);
+    {
+      const G160Params pe = reload_params();
+      epilogue_stage<WMB, 5, true>(acc, pe, lane, m0, n0, wm, wn, split, smem);
+    }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     block_barrier();                          // (C)
   }
-  epilogue_store<256, 5, 768, false, true>(p, m0, n0, smem, tid);
+  const G160Params pe = reload_params();
+  epilogue_store<256, 5, 768, false, true>(pe, m0, n0, smem, tid, tile_m * (256 / GN_SLAB));
 }
 
 // sum the split-K slabs and apply the epilogue (bias, row vector, activation, residual)
@@ -1588,6 +1724,80 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const G160Params p) 
     }
     *reinterpret_cast<uint4*>(p.C + (long)m * p.ldc + n) = o.u;
   }
+}
+
+// The same reduction for a launch whose output feeds a GroupNorm (PfdGemmDesc.gn_out): one block per 64-row slab x 160-column
+// tile, the store-pass mapping of epilogue_store_gn (a wave = 3 rows x 20 chunks), statistics through gn_slab_reduce.
+__global__ __launch_bounds__(256) void splitk_reduce_gn_kernel(const G160Params p) {
+  __shared__ __attribute__((aligned(16))) float red[5 * 320];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int tiles_n = p.N / 160;
+  const int slab = blockIdx.x / tiles_n, tile_n = blockIdx.x - slab * tiles_n;
+  const int n = tile_n * 160 + (lane % 20) * 8;
+  const bool active = lane < 60;
+  const int rsub = lane / 20;
+  float cs[8], cq[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) cs[e] = cq[e] = 0.f;
+  Pack16 bb;
+  bb.u = *reinterpret_cast<const uint4*>(p.bias ? p.bias + n : g_zero_page);
+  for (int it = 0; it < (GN_SLAB + 11) / 12; ++it) {
+    const int row_u = w * 3 + rsub + it * 12;
+    const int m = min(slab * GN_SLAB + min(row_u, GN_SLAB - 1), p.M - 1);
+    const bool ok = active && row_u < GN_SLAB && slab * GN_SLAB + row_u < p.M;
+    Pack16 rv, rr;
+    rv.u = *reinterpret_cast<const uint4*>(p.rowvec ? p.rowvec + (long)(m / p.rows_per_rv) * p.ldrv + n : g_zero_page);
+    rr.u = *reinterpret_cast<const uint4*>(p.R ? p.R + (long)m * p.ldr + n : g_zero_page);
+    float v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int s0 = 0; s0 < p.splits; s0 += 4) {   // same order of the slabs as splitk_reduce_kernel
+      float4_t a[4], b[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const float* src = p.ws + ((long)min(s0 + u, p.splits - 1) * p.M + m) * p.N + n;
+        a[u] = *reinterpret_cast<const float4_t*>(src);
+        b[u] = *reinterpret_cast<const float4_t*>(src + 4);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const float wgt = s0 + u < p.splits ? 1.f : 0.f;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          v[e] += a[u][e] * wgt;
+          v[4 + e] += b[u][e] * wgt;
+        }
+      }
+    }
+    Pack16 o;
+    const float mk = ok ? 1.f : 0.f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      float x = v[e] + (float)bb.e[e];
+      x += (float)rv.e[e];
+      if (p.act == PFD_ACT_GELU) x = pfd_gelu(x);
+      else if (p.act == PFD_ACT_RELU) x = fmaxf(x, 0.f);
+      else if (p.act == PFD_ACT_SILU) x = pfd_silu(x);
+      o.e[e] = (half_t)(x + (float)rr.e[e]);
+      const float f = (float)o.e[e] * mk;
+      cs[e] += f;
+      cq[e] = fmaf(f, f, cq[e]);
+    }
+    if (ok) *reinterpret_cast<uint4*>(p.C + (long)m * p.ldc + n) = o.u;
+  }
+  gn_slab_reduce<1, 256>(cs, cq, tid, p.N / 32, slab, p.M / GN_SLAB, tiles_n, tile_n, p.gn_out, [&](int) { return red; });
+}
+
+// launches the reduction of a split-K launch (plain, or the statistics-emitting form) and the LayerNorm fallback statistics
+inline void launch_splitk_reduce(const G160Params& p, hipStream_t s) {
+  if (p.gn_out) {
+    hipLaunchKernelGGL(splitk_reduce_gn_kernel, dim3((p.M / GN_SLAB) * (p.N / 160)), dim3(256), 0, s, p);
+  } else {
+    const long nvec = (long)p.M * (p.N / 8);
+    int g = (int)((nvec + 255) / 256);
+    if (g > 2048) g = 2048;
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(g), dim3(256), 0, s, p);
+  }
+  // a split-K output that feeds a folded LayerNorm: its row statistics by the stand-alone kernel
+  if (p.ln_out) pfd_ln_rowstats_launch(p.C, p.ldc, p.M, p.N, reinterpret_cast<float*>(p.ln_out), s, false);   // inside this launch's event pair
 }
 
 // Rotated K walk (k_rotation), measured on the cold replay of the sampler's launch list (profiles/r03_krot_pp_replay.log):
@@ -1660,14 +1870,7 @@ int launch160(G160Params& p, int bucket, hipStream_t s) {
     hipLaunchKernelGGL((gemm160_kernel<WAVES_M, WMB, true, NBUF, NT>), grid, dim3(WAVES_M * 128), 0, s, p);
   else
     hipLaunchKernelGGL((gemm160_kernel<WAVES_M, WMB, false, NBUF, NT>), grid, dim3(WAVES_M * 128), 0, s, p);
-  if (p.splits > 1) {
-    const long nvec = (long)p.M * (p.N / 8);
-    int g = (int)((nvec + 255) / 256);
-    if (g > 2048) g = 2048;
-    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(g), dim3(256), 0, s, p);
-    // a split-K output that feeds a folded LayerNorm: its row statistics by the stand-alone kernel
-    if (p.ln_out) pfd_ln_rowstats_launch(p.C, p.ldc, p.M, p.N, reinterpret_cast<float*>(p.ln_out), s, false);   // inside this launch's event pair
-  }
+  if (p.splits > 1) launch_splitk_reduce(p, s);
   if (prof) pfd_prof_end(s);
   return pfd_check_launch("pfd_gemm_f16(wide)");
 }
@@ -1698,14 +1901,7 @@ int launch160ws(G160Params& p, int bucket, hipStream_t s, int pp) {
     else if (pp == 2) hipLaunchKernelGGL((gemm160ws_kernel<false, NT, false, 3>), grid, dim3(768), 0, s, p);
     else hipLaunchKernelGGL((gemm160ws_kernel<false, NT, false>), grid, dim3(768), 0, s, p);
   }
-  if (p.splits > 1) {
-    const long nvec = (long)p.M * (p.N / 8);
-    int g = (int)((nvec + 255) / 256);
-    if (g > 2048) g = 2048;
-    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(g), dim3(256), 0, s, p);
-    // a split-K output that feeds a folded LayerNorm: its row statistics by the stand-alone kernel
-    if (p.ln_out) pfd_ln_rowstats_launch(p.C, p.ldc, p.M, p.N, reinterpret_cast<float*>(p.ln_out), s, false);   // inside this launch's event pair
-  }
+  if (p.splits > 1) launch_splitk_reduce(p, s);
   if (prof) pfd_prof_end(s);
   return pfd_check_launch("pfd_gemm_f16(wave-specialised)");
 }
@@ -1730,14 +1926,7 @@ int launch_patch(G160Params& p, hipStream_t s, int ws) {
   else if (ws == 2) hipLaunchKernelGGL((conv3x3_patch_ws_kernel<0, true>), grid, dim3(768), 0, s, p);
   else if (ws) hipLaunchKernelGGL((conv3x3_patch_ws_kernel<0, false>), grid, dim3(768), 0, s, p);
   else hipLaunchKernelGGL(conv3x3_patch_kernel, grid, dim3(512), 0, s, p);
-  if (p.splits > 1) {
-    const long nvec = (long)p.M * (p.N / 8);
-    int g = (int)((nvec + 255) / 256);
-    if (g > 2048) g = 2048;
-    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(g), dim3(256), 0, s, p);
-    // a split-K output that feeds a folded LayerNorm: its row statistics by the stand-alone kernel
-    if (p.ln_out) pfd_ln_rowstats_launch(p.C, p.ldc, p.M, p.N, reinterpret_cast<float*>(p.ln_out), s, false);   // inside this launch's event pair
-  }
+  if (p.splits > 1) launch_splitk_reduce(p, s);
   if (prof) pfd_prof_end(s);
   return pfd_check_launch("pfd_gemm_f16(conv3x3 patch)");
 }
@@ -1790,6 +1979,14 @@ int pfd_gemm160_try(const PfdGemmDesc* d, int variant, int splits, hipStream_t s
   p.gn_c1 = d->gn_c1; p.gn_act = d->gn_act;
   p.ln_in = (const float2*)d->ln_stats; p.ln_cs = (const float*)d->ln_colsum; p.ln_P = d->ln_parts; p.ln_eps = d->ln_eps;
   p.ln_out = (float2*)d->ln_out;
+  // GroupNorm statistics of the output (ABI 8): 160-wide tiles, whole 64-row slabs, groups that do not straddle a tile
+  p.gn_out = (float2*)d->gn_out;
+  if (p.gn_out) {
+    if (bn != 160 || (d->N % 32) || d->N / 32 < 8 || (160 % (d->N / 32)) || (d->M % GN_SLAB) || d->act == PFD_ACT_GEGLU || d->Ct ||
+        d->ln_out || d->bias_per_row || (reinterpret_cast<uintptr_t>(p.gn_out) & 7))
+      return 1;
+    if (d->ksize > 0 && ((long)d->Ho * d->Wo) % GN_SLAB) return 1;   // a slab must not straddle two samples
+  }
   // two-source contraction / zero rows (ABI 8): the 8-wave / 4-wave linear kernels only
   p.k_split = d->K; p.zero_rows = 0;
   if (d->k_split > 0 || d->zero_rows > 0) {

@@ -189,6 +189,107 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(GnSrc s, const half_t* __
   }
 }
 
+// ---- GroupNorm apply with the statistics of the PRODUCERS (pfd_groupnorm_pstats_f16, round 4) ----
+// The tensors were written by launches that emitted, per 64-row slab and per group of C_src / 32 channels, the sums of the
+// f16 values they stored (PfdGemmDesc.gn_out: st[(slab * (C_src / 160) + tile) * 16 + local group], slab = row / 64 over
+// the whole batch).  A group of THIS GroupNorm (cpg = (C1 + C2) / G channels of the virtual concat) is a whole number of
+// producer groups of one source (checked by the host), so its statistics are sums of producer partials: no pass over the
+// tensor.  Same apply loop as gn_apply_kernel.
+struct GnPStats {
+  const float2* st1;
+  const float2* st2;
+  int tn1, tn2;      // C_src / 160
+  int cpp1, cpp2;    // channels per producer group (C_src / 32)
+};
+
+__global__ __launch_bounds__(256) void gn_apply_pstats_kernel(GnSrc s, GnPStats ps, const half_t* __restrict__ gamma,
+                                                              const half_t* __restrict__ beta, half_t* __restrict__ y,
+                                                              long ldy, int HW, int G, int rows_per_chunk, int act,
+                                                              float count, float eps) {
+  __shared__ float sc[4096], sh[4096];
+  __shared__ float ra[256], rq[256], gmean[GN_MAX_G], grstd[GN_MAX_G];
+  const int C = s.C1 + s.C2;
+  const int nvec = C / 8;
+  const int cpg = C / G;
+  const int b = blockIdx.y, chunk = blockIdx.x, tid = threadIdx.x;
+  {
+    const int nslab = HW / 64;
+    const int P = 256 / G;
+    const int g = tid % G, part = tid / G;
+    float a = 0.f, q = 0.f;
+    if (part < P) {
+      const int c0 = g * cpg;
+      const bool first = c0 < s.C1;
+      const float2* st = first ? ps.st1 : ps.st2;
+      const int tn = first ? ps.tn1 : ps.tn2, cpp = first ? ps.cpp1 : ps.cpp2;
+      const int cl = first ? c0 : c0 - s.C1;
+      const int npg = cpg / cpp;                       // producer groups per group of this norm
+      for (int k = part; k < nslab; k += P) {
+        const float2* row = st + ((long)(b * nslab + k) * tn) * 16;
+        for (int j = 0; j < npg; ++j) {
+          const int c = cl + j * cpp;
+          const float2 v = row[(c / 160) * 16 + (c % 160) / cpp];
+          a += v.x;
+          q += v.y;
+        }
+      }
+    }
+    ra[tid] = a;
+    rq[tid] = q;
+    __syncthreads();
+    if (tid < G) {
+      for (int k = 1; k < P; ++k) {
+        a += ra[k * G + tid];
+        q += rq[k * G + tid];
+      }
+      const float mean = a / count;
+      gmean[tid] = mean;
+      grstd[tid] = rsqrtf(fmaxf(q / count - mean * mean, 0.f) + eps);
+    }
+    __syncthreads();
+  }
+  for (int c = tid; c < C; c += 256) {
+    const int g = c / cpg;
+    const float w = grstd[g] * (float)gamma[c];
+    sc[c] = w;
+    sh[c] = (float)beta[c] - gmean[g] * w;
+  }
+  __syncthreads();
+  const int VT = nvec < 256 ? nvec : 256;
+  const int RT = 256 / VT;
+  const int v0 = tid % VT, rt = tid / VT;
+  if (rt >= RT) return;
+  const int r_beg = chunk * rows_per_chunk;
+  const int r_end = min(HW, r_beg + rows_per_chunk);
+  for (int v = v0; v < nvec; v += 256) {
+    float w[8], o[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      w[e] = sc[v * 8 + e];
+      o[e] = sh[v * 8 + e];
+    }
+    for (int r = r_beg + rt; r < r_end; r += 4 * RT) {
+      Pack16 p[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        if (r + u * RT < r_end) p[u].u = gn_load(s, (long)b * HW + r + u * RT, v);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        if (r + u * RT >= r_end) break;
+        const long row = (long)b * HW + r + u * RT;
+        Pack16 qv;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          float t = (float)p[u].e[e] * w[e] + o[e];
+          if (act == PFD_ACT_SILU) t = pfd_silu(t);
+          qv.e[e] = (half_t)t;
+        }
+        *reinterpret_cast<uint4*>(y + row * ldy + v * 8) = qv.u;
+      }
+    }
+  }
+}
+
 // GroupNorm folded into the consumer (pfd_groupnorm_table_f16): instead of writing the normalised tensor, write the
 // per-(sample, channel) affine map  y = x * scale + shift  as two planes [B][2][C]  (scale = rstd * gamma, shift = beta - mean * scale; the
 // same fp32 expressions, reduced in the same order, as gn_apply_kernel) -- the 3x3 patch convolution applies it
@@ -558,6 +659,12 @@ static void gn_chunks(int B, int C, int HW, int* nchunks_out, int* rpc_out) {
   *rpc_out = rpc;
 }
 
+// 1 when pfd_groupnorm_f16 would take the single-launch small-slab form (which needs no separate statistics)
+static bool gn_is_small(int B, int C, int HW, int G) {
+  const int cpg = C / G;
+  return cpg % 4 == 0 && cpg >= 32 && (long)HW * (cpg / 4) <= 256 * GNS_MAX && (long)B * G >= 128;
+}
+
 extern "C" size_t pfd_groupnorm_ws_bytes(int32_t B, int32_t C, int32_t HW) {
   (void)C;
   (void)HW;
@@ -579,8 +686,7 @@ extern "C" int pfd_groupnorm_f16(const void* x1, int32_t C1, int64_t ldx1, const
   hipStream_t s = (hipStream_t)stream;
   GnSrc src{(const half_t*)x1, (const half_t*)x2, ldx1, ldx2, C1, C2};
   const bool prof = pfd_prof_on();
-  const int cpg = C / G;
-  if (cpg % 4 == 0 && cpg >= 32 && (long)HW * (cpg / 4) <= 256 * GNS_MAX && (long)B * G >= 128) {  // narrower groups: 40-byte row segments, the two-launch form wins (640 @ 32^2: 15 vs 17 us)
+  if (gn_is_small(B, C, HW, G)) {  // narrower groups: 40-byte row segments, the two-launch form wins (640 @ 32^2: 15 vs 17 us)
     if (prof) pfd_prof_begin(10, 8.0 * B * HW * C, 4.0 * B * HW * C, s);  // 2B read + 2B write
     hipLaunchKernelGGL(gn_small_kernel, dim3(G, B), dim3(256), 0, s, src, (const half_t*)gamma, (const half_t*)beta,
                        (half_t*)y, (long)ldy, HW, G, act, eps);
@@ -597,6 +703,39 @@ extern "C" int pfd_groupnorm_f16(const void* x1, int32_t C1, int64_t ldx1, const
                      (float)HW * (float)(C / G), eps);
   if (prof) pfd_prof_end(s);
   return pfd_check_launch("pfd_groupnorm_f16");
+}
+
+extern "C" int32_t pfd_groupnorm_takes_pstats(int32_t B, int32_t C1, int32_t C2, int32_t HW, int32_t G) {
+  if (B <= 0 || C1 <= 0 || C2 < 0 || HW <= 0 || G <= 0 || G > GN_MAX_G) return 0;
+  const int C = C1 + C2;
+  if ((C % G) || C > 4096 || (HW % 64) || (C1 % 160) || (C2 % 160) || (C1 % 32) || (C2 % 32)) return 0;
+  if (gn_is_small(B, C, HW, G)) return 0;
+  const int cpg = C / G, cpp1 = C1 / 32, cpp2 = C2 ? C2 / 32 : cpp1;
+  if (cpp1 < 8 || (160 % cpp1) || (cpg % cpp1) || (C1 % cpg)) return 0;       // groups of this norm = whole producer groups
+  if (C2 && (cpp2 < 8 || (160 % cpp2) || (cpg % cpp2))) return 0;
+  return 1;
+}
+
+extern "C" int pfd_groupnorm_pstats_f16(const void* x1, int32_t C1, int64_t ldx1, const void* st1, const void* x2,
+                                        int32_t C2, int64_t ldx2, const void* st2, const void* gamma, const void* beta,
+                                        void* y, int64_t ldy, int32_t B, int32_t HW, int32_t G, float eps, int32_t act,
+                                        pfd_stream_t stream) {
+  if (!x1 || !st1 || !gamma || !beta || !y) return PFD_EINVAL;
+  if (C2 > 0 && (!x2 || !st2)) return PFD_EINVAL;
+  if (act != PFD_ACT_NONE && act != PFD_ACT_SILU) return PFD_EINVAL;
+  if ((ldx1 & 7) || (ldx2 & 7) || (ldy & 7) || (reinterpret_cast<uintptr_t>(st1) & 7) || (reinterpret_cast<uintptr_t>(st2) & 7))
+    return PFD_EINVAL;
+  if (!pfd_groupnorm_takes_pstats(B, C1, C2, HW, G)) return PFD_ESHAPE;
+  hipStream_t s = (hipStream_t)stream;
+  const int C = C1 + C2;
+  GnSrc src{(const half_t*)x1, (const half_t*)x2, ldx1, ldx2, C1, C2};
+  GnPStats ps{(const float2*)st1, (const float2*)st2, C1 / 160, C2 ? C2 / 160 : 0, C1 / 32, C2 ? C2 / 32 : C1 / 32};
+  int nchunks, rpc;
+  gn_chunks(B, C, HW, &nchunks, &rpc);
+  PfdProfScope prof_scope(10, 8.0 * B * HW * C, 4.0 * B * HW * C, s);   // 2 B read + 2 B write
+  hipLaunchKernelGGL(gn_apply_pstats_kernel, dim3(nchunks, B), dim3(256), 0, s, src, ps, (const half_t*)gamma,
+                     (const half_t*)beta, (half_t*)y, (long)ldy, HW, G, rpc, act, (float)HW * (float)(C / G), eps);
+  return pfd_check_launch("pfd_groupnorm_pstats_f16");
 }
 
 extern "C" int pfd_groupnorm_table_f16(const void* x1, int32_t C1, int64_t ldx1, const void* x2, int32_t C2,

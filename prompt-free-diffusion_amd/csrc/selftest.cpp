@@ -112,6 +112,7 @@ struct GemmCase {
   int w_tiled = 0;  // 1: the weight is uploaded K-tile-contiguous (PfdGemmDesc.w_tiled)
   int k_split = 0;  // > 0: columns >= k_split of the operand come from a second buffer (PfdGemmDesc.k_split)
   int zero_rows = 0;  // > 0: the first rows of the operand are all zero and not stored (PfdGemmDesc.zero_rows)
+  int gn_out = 0;     // 1: the launch also emits the GroupNorm statistics of its output (PfdGemmDesc.gn_out)
 };
 
 static void run_gemm_case(const GemmCase& c) {
@@ -172,10 +173,15 @@ static void run_gemm_case(const GemmCase& c) {
   d.w_tiled = c.w_tiled;
   if (c.k_split) { d.A2 = dA2.p; d.lda2 = lda2; d.k_split = c.k_split; }
   d.zero_rows = c.zero_rows;
+  Dev<float> dGn(c.gn_out ? (size_t)(M / 64) * (N / 160) * 32 : 2);
+  if (c.gn_out) {
+    HIP_OK(hipMemset(dGn.p, 0xFF, dGn.n * sizeof(float)));   // NaN pattern: every used slot must be written
+    d.gn_out = dGn.p;
+  }
   const int rc = pfd_gemm_f16_ex(&d, c.tile, nullptr);
   char name[256];
-  snprintf(name, sizeof(name), "gemm M%d N%d K%d act%d b%d r%d rv%d br%d tile%d%s ks%d zr%d ld+%d %s", M, N, K, c.act,
-           c.bias, c.res, c.rowvec, c.bias_row, c.tile, c.w_tiled ? "T" : "", c.k_split, c.zero_rows, c.extra_ld,
+  snprintf(name, sizeof(name), "gemm M%d N%d K%d act%d b%d r%d rv%d br%d tile%d%s ks%d zr%d%s ld+%d %s", M, N, K, c.act,
+           c.bias, c.res, c.rowvec, c.bias_row, c.tile, c.w_tiled ? "T" : "", c.k_split, c.zero_rows, c.gn_out ? " gn" : "", c.extra_ld,
            conv ? (std::string("conv k") + std::to_string(c.ksize) + " s" + std::to_string(c.stride) + " p" +
                    std::to_string(c.pad) + " u" + std::to_string(c.ups))
                       .c_str()
@@ -240,6 +246,25 @@ static void run_gemm_case(const GemmCase& c) {
   for (int m = 0; m < M; ++m)
     for (long n = c.n_split > 0 ? c.n_split : Nout; n < ldc; ++n) gotc[(size_t)m * ldc + n] = got[(size_t)m * ldc + n];
   report(name, gotc, ref, 4e-3, 3e-3);
+  if (c.gn_out) {   // the statistics must be the sums of the f16 values the launch stored, per 64-row slab and group of N / 32
+    auto st = dGn.get();
+    const int cpg = N / 32, tn = N / 160, ngl = 160 / cpg;
+    std::vector<double> sref((size_t)(M / 64) * tn * 32, 0.0);
+    std::vector<float> sgot(sref.size(), 0.f);
+    for (int sl = 0; sl < M / 64; ++sl)
+      for (int t = 0; t < tn; ++t)
+        for (int gl = 0; gl < ngl; ++gl) {
+          double a = 0, q = 0;
+          for (int r = 0; r < 64; ++r)
+            for (int cc = 0; cc < cpg; ++cc) {
+              const double v = (double)got[(size_t)(sl * 64 + r) * ldc + t * 160 + gl * cpg + cc];
+              a += v; q += v * v;
+            }
+          const size_t o = (((size_t)sl * tn + t) * 16 + gl) * 2;
+          sref[o] = a; sref[o + 1] = q; sgot[o] = st[o]; sgot[o + 1] = st[o + 1];
+        }
+    report((std::string(name) + " [gn_out]").c_str(), sgot, sref, 2e-2, 1e-4);
+  }
 }
 
 // K-tile-contiguous weights (PfdGemmDesc.w_tiled): every wide-tile kernel family, both tile widths, conv K walks, split-K
@@ -559,6 +584,49 @@ static void run_gn_case(int B, int HW, int C1, int C2, int G, int act, float eps
 // conv3x3(act(GroupNorm([x1 | x2]))) two ways: pfd_groupnorm_f16 + plain patch conv vs pfd_groupnorm_table_f16 + the
 // conv's GroupNorm prologue.  Same statistics code, same fp32 affine map, same kernel behind it: the outputs must be
 // identical, not merely close.
+// pfd_groupnorm_pstats_f16: statistics handed over in the producers' layout (host-computed here) vs a plain fp64 GroupNorm
+static void run_gn_pstats_case(int B, int HW, int C1, int C2, int act, float eps) {
+  const int C = C1 + C2, G = 32, cpg = C / G;
+  auto x1 = rand_h((size_t)B * HW * C1), x2 = rand_h((size_t)B * HW * std::max(C2, 8)), gm = rand_h(C), bt = rand_h(C);
+  for (auto& v : x1) v = (h16)((float)v * 1.5f + 0.3f);
+  auto mk_stats = [&](const std::vector<h16>& x, int Cs) {
+    const int cpp = Cs / 32, tn = Cs / 160;
+    std::vector<float> st((size_t)(B * HW / 64) * tn * 32, 0.f);
+    for (int sl = 0; sl < B * HW / 64; ++sl)
+      for (int c = 0; c < Cs; ++c) {
+        double a = 0, q = 0;
+        for (int r = 0; r < 64; ++r) { const double v = (double)x[(size_t)(sl * 64 + r) * Cs + c]; a += v; q += v * v; }
+        const size_t o = (((size_t)sl * tn + c / 160) * 16 + (c % 160) / cpp) * 2;
+        st[o] += (float)a; st[o + 1] += (float)q;
+      }
+    return st;
+  };
+  auto s1 = mk_stats(x1, C1);
+  std::vector<float> s2 = C2 ? mk_stats(x2, C2) : std::vector<float>(2, 0.f);
+  Dev<h16> d1(x1), d2(x2), dg(gm), db(bt), dy((size_t)B * HW * C);
+  Dev<float> ds1(s1), ds2(s2);
+  char name[160];
+  snprintf(name, sizeof(name), "groupnorm pstats B%d HW%d C%d+%d act%d", B, HW, C1, C2, act);
+  if (!pfd_groupnorm_takes_pstats(B, C1, C2, HW, G)) { ++g_total; ++g_fail; printf("FAIL %s: shape refused\n", name); return; }
+  const int rc = pfd_groupnorm_pstats_f16(d1.p, C1, C1, ds1.p, C2 ? d2.p : nullptr, C2, C2, C2 ? ds2.p : nullptr, dg.p, db.p, dy.p, C,
+                                          B, HW, G, eps, act, nullptr);
+  if (rc != 0) { ++g_total; ++g_fail; printf("FAIL %s rc=%d (%s)\n", name, rc, pfd_last_error()); return; }
+  auto got = dy.get();
+  std::vector<double> ref((size_t)B * HW * C);
+  auto at = [&](int b, int r, int c) { return c < C1 ? (double)x1[((size_t)b * HW + r) * C1 + c] : (double)x2[((size_t)b * HW + r) * C2 + c - C1]; };
+  for (int b = 0; b < B; ++b)
+    for (int g = 0; g < G; ++g) {
+      double a = 0, q = 0;
+      for (int r = 0; r < HW; ++r)
+        for (int c = g * cpg; c < (g + 1) * cpg; ++c) { const double v = at(b, r, c); a += v; q += v * v; }
+      const double n = (double)HW * cpg, mean = a / n, rstd = 1.0 / sqrt(std::max(q / n - mean * mean, 0.0) + eps);
+      for (int r = 0; r < HW; ++r)
+        for (int c = g * cpg; c < (g + 1) * cpg; ++c)
+          ref[((size_t)b * HW + r) * C + c] = act_ref((at(b, r, c) - mean) * rstd * (double)gm[c] + (double)bt[c], act);
+    }
+  report(name, got, ref, 6e-3, 4e-3);
+}
+
 static void run_gn_conv_case(int B, int H, int W, int C1, int C2, int N, int act, bool with_res) {
   const int C = C1 + C2, HW = H * W, G = 32, M = B * HW, K = 9 * C;
   const float eps = 1e-5f;
@@ -1295,6 +1363,23 @@ int main(int argc, char** argv) {
       { GemmCase c{600, 160, 256, PFD_ACT_SILU, true, true, true, false, v}; c.zero_rows = 300; c.k_split = 64; run_gemm_case(c); }
     }
     { GemmCase c{520, 256, 512, 0, true, true, false, false, 0}; c.k_split = 128; c.zero_rows = 256; run_gemm_case(c); }   // 128-wide tiles
+    // GroupNorm statistics from the producer (gn_out): every store pass that can feed a GroupNorm, and the split-K reduce
+    for (int v : {0, 3200, 3400, 5400, 5100, 9200, 9300, 5800, 5700, 3202, 9202}) {
+      { GemmCase c{768, 320, 512, 0, true, true, true, false, v}; c.gn_out = 1; run_gemm_case(c); }              // cpg 10
+      { GemmCase c{512, 640, 256, PFD_ACT_SILU, true, false, false, false, v}; c.gn_out = 1; run_gemm_case(c); } // cpg 20
+    }
+    { GemmCase c{256, 1280, 128, 0, true, true, false, false, 0}; c.gn_out = 1; run_gemm_case(c); }             // cpg 40
+    for (int v : {0, 10600, 10800, 10900, 10602, 5700, 5800, 5400}) {
+      { GemmCase c{0, 320, 0, 0, true, true, true, false, v, 0, 3, 1, 1, 0, 2, 16, 16, 128}; c.gn_out = 1; run_gemm_case(c); }   // 16^2
+      { GemmCase c{0, 640, 0, 0, true, false, true, false, v, 0, 3, 1, 1, 0, 1, 32, 32, 64}; c.gn_out = 1; run_gemm_case(c); }   // 32^2
+    }
+    { GemmCase c{0, 320, 0, 0, true, true, true, false, 0, 0, 3, 1, 1, 0, 1, 16, 96, 64}; c.gn_out = 1; run_gemm_case(c); }      // 2-D patch tiles
+    { GemmCase c{0, 320, 0, 0, true, false, false, false, 0, 0, 3, 2, 1, 0, 2, 32, 32, 128}; c.gn_out = 1; run_gemm_case(c); }   // stride 2
+    { GemmCase c{0, 320, 0, 0, true, false, false, false, 0, 0, 3, 1, 1, 1, 1, 8, 8, 128}; c.gn_out = 1; run_gemm_case(c); }     // upsample
+    run_gn_pstats_case(2, 256, 320, 0, PFD_ACT_SILU, 1e-5f);
+    run_gn_pstats_case(2, 1024, 640, 0, PFD_ACT_NONE, 1e-6f);
+    run_gn_pstats_case(3, 256, 320, 320, PFD_ACT_SILU, 1e-5f);     // aligned skip concat: a group = two producer groups
+    run_gn_pstats_case(2, 256, 640, 640, PFD_ACT_SILU, 1e-5f);
     printf("SELFTEST %d/%d passed, %d failed\n", g_total - g_fail, g_total, g_fail);
     return g_fail;
   }

@@ -33,7 +33,7 @@ class PfdGemmDesc(C.Structure):
         ("Ct", _vp), ("ldct", _i64), ("n_split", _i32), ("w_tiled", _i32),
         ("gn_table", _vp), ("A2", _vp), ("lda2", _i64), ("gn_c1", _i32), ("gn_act", _i32),
         ("ln_stats", _vp), ("ln_colsum", _vp), ("ln_parts", _i32), ("ln_eps", _f32), ("ln_out", _vp),
-        ("k_split", _i32), ("zero_rows", _i32),
+        ("k_split", _i32), ("zero_rows", _i32), ("gn_out", _vp),
     ]
 
 
@@ -69,6 +69,9 @@ SIGNATURES = {
                                        _vp]),
     "pfd_groupnorm_f16": (_i32, [_vp, _i32, _i64, _vp, _i32, _i64, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _f32,
                                  _i32, _vp, _sz, _vp]),
+    "pfd_groupnorm_takes_pstats": (_i32, [_i32, _i32, _i32, _i32, _i32]),
+    "pfd_groupnorm_pstats_f16": (_i32, [_vp, _i32, _i64, _vp, _vp, _i32, _i64, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32,
+                                        _f32, _i32, _vp]),
     "pfd_layernorm_f16": (_i32, [_vp, _i64, _vp, _vp, _vp, _i64, _i32, _i32, _f32, _i32, _i32, _i32, _i32, _vp]),
     "pfd_ln_rowstats_f16": (_i32, [_vp, _i64, _i32, _i32, _vp, _vp]),
     "pfd_softmax_rows_f16": (_i32, [_vp, _i64, _vp, _i64, _i32, _i32, _f32, _vp]),

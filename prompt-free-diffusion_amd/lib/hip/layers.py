@@ -121,8 +121,10 @@ class Conv2d(nn.Conv2d, _Packed):
         return self._packed("w", lambda: (pack_conv_weight(self.weight), pack_vec(self.bias)), self.weight, self.bias)
 
     def hip(self, x, *, ups=False, rowvec=None, res=None, act=ACT_NONE, out=None, out_hw=None, rows_per_rv=None,
-            gn=None, ln_out=None):
-        """ln_out (1x1 convolutions only): also return the partial row sums of the output, see ops.gemm"""
+            gn=None, ln_out=None, gn_out=False):
+        """ln_out (1x1 convolutions only): also return the partial row sums of the output, see ops.gemm.
+        gn_out=True: this output will be read by a GroupNorm -- where that norm takes the two-launch form the launch also
+        emits its statistics (PfdGemmDesc.gn_out); they ride on the returned tensor (ops.get_gn_stats)"""
         w, b = self._pk()
         k, s, p = self.kernel_size[0], self.stride[0], self.padding[0]
         cin = self.in_channels
@@ -134,22 +136,27 @@ class Conv2d(nn.Conv2d, _Packed):
                 B, H, W_, _ = x.shape
                 o2 = None if out is None else out.view(-1, out.shape[-1])
                 r2 = None if res is None else res.reshape(-1, res.shape[-1])
+                want = bool(gn_out) and (ln_out is None or ln_out is False) and act != ACT_GEGLU and \
+                    ops.gn_stats_wanted(B, H * W_, self.out_channels) and ops.wide_tile_ok(self.out_channels, cin)
                 y = ops.gemm(x.reshape(-1, cin), w, bias=b, rowvec=rowvec,
                              rows_per_rv=H * W_ if rows_per_rv is None else rows_per_rv, res=r2, act=act,
-                             out=o2, ln_out=ln_out)
+                             out=o2, ln_out=ln_out, gn_out=want)
                 if ln_out is not None and ln_out is not False:
                     return y[0].view(B, H, W_, self.out_channels), y[1]
-                return y.view(B, H, W_, self.out_channels)
+                v = y.view(B, H, W_, self.out_channels)
+                if want:
+                    ops.set_gn_stats(v, ops.get_gn_stats(y))
+                return v
             if ln_out is not None and ln_out is not False:
                 raise ValueError("ln_out is for 1x1 convolutions (token-wise linears)")
             return ops.conv(x, w, k, stride=s, pad=p, ups=ups, bias=b, rowvec=rowvec, res=res, act=act, out=out,
-                            out_hw=out_hw, rows_per_rv=rows_per_rv)
+                            out_hw=out_hw, rows_per_rv=rows_per_rv, gn_out=gn_out)
         if ups:
             raise NotImplementedError("narrow-channel conv with fused upsample")
         r2 = None if res is None else res.reshape(-1, res.shape[-1])
         ho, wo = out_hw if out_hw is not None else (None, None)
         return ops.conv_narrow(x, w, k, stride=s, pad=p, bias=b, rowvec=rowvec, res=r2, act=act, ho=ho, wo=wo,
-                               out=out)
+                               out=out, gn_out=gn_out)
 
     def forward(self, x):
         return _io_wrap_nchw(self, x, self.hip)

@@ -142,6 +142,47 @@ def ln_rowstats(x, out=None):
     return out
 
 
+# GroupNorm statistics from the producers (PfdGemmDesc.gn_out / pfd_groupnorm_pstats_f16); PFD_GN_PSTATS=0: every
+# two-launch GroupNorm reads its input for statistics again (A/B runs)
+GN_PSTATS = os.environ.get("PFD_GN_PSTATS", "1") != "0"
+
+
+def gn_stats_wanted(B, HW, N, M=None):
+    """should the launch that writes a [B, HW, N] tensor also emit GroupNorm(32) statistics of it?  Yes where a GroupNorm
+    over these channels (alone or as one source of a skip concat) takes the two-launch form and the wide-tile kernels
+    can form them (N = 320 | 640 | 1280, whole 64-row slabs per sample)."""
+    if not GN_PSTATS or N not in (320, 640, 1280) or HW % 64 or (M is not None and M != B * HW):
+        return False
+    return bool(_lib().pfd_groupnorm_takes_pstats(B, N, 0, HW, 32))
+
+
+def _new_gn_stats(M, N, device):
+    return torch.empty((M // 64, N // 160, 16, 2), dtype=torch.float32, device=device)
+
+
+def set_gn_stats(t, stats):
+    """attach the producer's statistics to the tensor OBJECT that holds its output (views / copies do not inherit them)"""
+    t._pfd_gn = (stats, t.data_ptr(), tuple(t.shape))
+    return t
+
+
+def get_gn_stats(t):
+    """the statistics the producer of `t` emitted, or None (also when the object was re-pointed since)"""
+    ent = getattr(t, "_pfd_gn", None)
+    if ent is None or ent[1] != t.data_ptr() or ent[2] != tuple(t.shape):
+        return None
+    return ent[0]
+
+
+def cat_pair(t):
+    """torch.cat([t, t]) of a CFG pair, statistics included (per-sample slabs: the copy's are the original's)"""
+    out = torch.cat([t, t])
+    st = get_gn_stats(t)
+    if st is not None:
+        set_gn_stats(out, torch.cat([st, st]))
+    return out
+
+
 # ABI 8 forms (PfdGemmDesc.k_split / zero_rows); PFD_GEMM_FUSE=0 keeps the two-launch forms (A/B runs)
 GEMM_FUSE = os.environ.get("PFD_GEMM_FUSE", "1") != "0"
 
@@ -153,11 +194,13 @@ def wide_tile_ok(N, K):
 
 def gemm(a, w, *, bias=None, rowvec=None, rows_per_rv=1, res=None, act=ACT_NONE, out=None,
          bias_per_row=False, n=None, k=None, tile=0, out_t=None, n_split=None, ln=None, ln_out=None,
-         a2=None, zero_rows=0):
+         a2=None, zero_rows=0, gn_out=False):
     """out[M, N] = epi(a[M, K] @ w[N, K]^T); see pfd_gemm_f16 in include/pfd_hip.h.
     a2: second source of the contraction -- the operand is the virtual column concat [a | a2] (K = Ka + Ka2; the
     1x1 skip convolution over a skip concat).  zero_rows: that many all-zero operand rows come in front of a's rows
     (M = zero_rows + rows of a); their result is epi(0).  Both: wide-tile kernels only (wide_tile_ok).
+    gn_out: the launch also emits the GroupNorm statistics of its output (PfdGemmDesc.gn_out); they ride on the returned
+    tensor (get_gn_stats).
     out_t / n_split: columns >= n_split go, transposed, to out_t[N - n_split, M] (wide-tile path only).
     ln = (stats, colsum, eps): LayerNorm of `a` folded into the contraction (w is the gamma-scaled weight, bias is b';
     PfdGemmDesc.ln_stats).  ln_out: True (allocate) or a float32 [M, N/160, 2] tensor -> the partial row sums of the
@@ -226,11 +269,17 @@ def gemm(a, w, *, bias=None, rowvec=None, rows_per_rv=1, res=None, act=ACT_NONE,
             if stats.dtype != torch.float32 or not stats.is_contiguous() or stats.numel() != M * (N // 160) * 2:
                 raise ValueError("gemm: ln_out must be a contiguous float32 [M, N/160, 2]")
         d.ln_out = stats.data_ptr()
+    gst = None
+    if gn_out:
+        gst = _new_gn_stats(M, N, a.device)
+        d.gn_out = gst.data_ptr()
     if _TRACE:
         _trace(d)
     lib = _lib()
     rc = lib.pfd_gemm_f16_ex(_byref(d), tile, _stream()) if tile else lib.pfd_gemm_f16(_byref(d), _stream())
     _b.check(rc, f"pfd_gemm_f16 M{M} N{N} K{K}")
+    if gst is not None:
+        set_gn_stats(out, gst)
     return out if stats is None else (out, stats)
 
 
@@ -242,7 +291,7 @@ def conv_gn_fusable(B, H, W_, C1, C2, N, ksize=3, stride=1, pad=1):
 
 
 def conv(x, w, ksize, *, stride=1, pad=None, ups=False, bias=None, rowvec=None, res=None, act=ACT_NONE,
-         out=None, tile=0, out_hw=None, rows_per_rv=None, gn=None):
+         out=None, tile=0, out_hw=None, rows_per_rv=None, gn=None, gn_out=False):
     """Implicit-GEMM convolution of an NHWC image x[B,H,W,Cin] (Cin % 64 == 0) with packed
     weights w[N, ksize*ksize*Cin]; returns [B,Ho,Wo,N].  rowvec: [B, N] per-sample vector.
     gn = (table, x2, silu): GroupNorm(+SiLU) of the virtual concat [x | x2] applied while the input is staged
@@ -302,11 +351,17 @@ def conv(x, w, ksize, *, stride=1, pad=None, ups=False, bias=None, rowvec=None, 
         d.gn_table, d.gn_c1, d.gn_act = table.data_ptr(), C1, ACT_SILU if gn_silu else ACT_NONE
         if x2 is not None:
             d.A2, d.lda2 = x2.data_ptr(), x2.stride(2)
+    gst = None
+    if gn_out and gn is None and gn_stats_wanted(B, Ho * Wo, N) and Cin % 64 == 0:   # (True = "where a GroupNorm will use them")
+        gst = _new_gn_stats(M, N, x.device)
+        d.gn_out = gst.data_ptr()
     if _TRACE:
         _trace(d)
     lib = _lib()
     rc = lib.pfd_gemm_f16_ex(_byref(d), tile, _stream()) if tile else lib.pfd_gemm_f16(_byref(d), _stream())
     _b.check(rc, f"pfd_gemm_f16(conv) M{M} N{N} K{K}" + (" with GroupNorm prologue" if gn is not None else ""))
+    if gst is not None:
+        set_gn_stats(out, gst)
     return out
 
 
@@ -324,7 +379,7 @@ def im2col(x, ksize, stride, pad, kpad, ho=None, wo=None):
 
 
 def conv_narrow(x, w, ksize, *, stride=1, pad=None, bias=None, rowvec=None, res=None, act=ACT_NONE,
-                ho=None, wo=None, out=None):
+                ho=None, wo=None, out=None, gn_out=False):
     """Convolution whose Cin is not a multiple of 64: im2col + GEMM.  w: [N, kpad] packed."""
     if pad is None:
         pad = ksize // 2
@@ -332,8 +387,12 @@ def conv_narrow(x, w, ksize, *, stride=1, pad=None, bias=None, rowvec=None, res=
     col, Ho, Wo = im2col(x, ksize, stride, pad, w.shape[1], ho, wo)
     N = w.shape[0]
     o2 = None if out is None else out.view(-1, out.shape[-1])
-    y = gemm(col, w, bias=bias, rowvec=rowvec, rows_per_rv=Ho * Wo, res=res, act=act, out=o2)
-    return y.view(B, Ho, Wo, N) if out is None else out
+    gn_out = bool(gn_out) and gn_stats_wanted(B, Ho * Wo, N) and wide_tile_ok(N, w.shape[1])
+    y = gemm(col, w, bias=bias, rowvec=rowvec, rows_per_rv=Ho * Wo, res=res, act=act, out=o2, gn_out=gn_out)
+    r = y.view(B, Ho, Wo, N) if out is None else out
+    if gn_out:
+        set_gn_stats(r, get_gn_stats(y))
+    return r
 
 
 # ----------------------------------------------------------------------------------------------
@@ -368,7 +427,9 @@ def swin_window_attention(qkv, qkv_bias, rpb, B, H, W_, Cdim, nH, ws, shift, sca
 # normalisation
 # ----------------------------------------------------------------------------------------------
 def groupnorm(x, gamma, beta, groups, eps, *, x2=None, silu=False, out=None):
-    """GroupNorm(+SiLU) of NHWC x[B,H,W,C1] (optionally virtually concatenated with x2[B,H,W,C2])."""
+    """GroupNorm(+SiLU) of NHWC x[B,H,W,C1] (optionally virtually concatenated with x2[B,H,W,C2]).  When the launches
+    that wrote x (and x2) emitted their statistics (gemm / conv gn_out=True) and the shape qualifies, the normalisation is
+    ONE launch from those sums (pfd_groupnorm_pstats_f16); otherwise statistics + apply (or the small-slab kernel)."""
     _chk16(x, "groupnorm x")
     B = x.shape[0]
     C1 = x.shape[-1]
@@ -377,6 +438,16 @@ def groupnorm(x, gamma, beta, groups, eps, *, x2=None, silu=False, out=None):
     if out is None:
         out = torch.empty(tuple(x.shape[:-1]) + (C1 + C2,), dtype=torch.float16, device=x.device)
     lib = _lib()
+    st1 = get_gn_stats(x) if GN_PSTATS else None
+    st2 = get_gn_stats(x2) if (GN_PSTATS and x2 is not None) else None
+    if st1 is not None and (x2 is None or st2 is not None) and groups == 32 and \
+            lib.pfd_groupnorm_takes_pstats(B, C1, C2, HW, groups):
+        rc = lib.pfd_groupnorm_pstats_f16(x.data_ptr(), C1, x.stride(-2), st1.data_ptr(), _ptr(x2), C2,
+                                          0 if x2 is None else x2.stride(-2), _ptr(st2), gamma.data_ptr(), beta.data_ptr(),
+                                          out.data_ptr(), out.stride(-2), B, HW, groups, eps,
+                                          ACT_SILU if silu else ACT_NONE, _stream())
+        _b.check(rc, f"pfd_groupnorm_pstats_f16 B{B} HW{HW} C{C1}+{C2}")
+        return out
     wsb = lib.pfd_groupnorm_ws_bytes(B, C1 + C2, HW)
     ws = torch.empty(wsb, dtype=torch.uint8, device=x.device)
     rc = lib.pfd_groupnorm_f16(x.data_ptr(), C1, x.stride(-2), _ptr(x2), C2, 0 if x2 is None else x2.stride(-2),

@@ -398,7 +398,9 @@ class SpatialTransformer(nn.Module):
         for blk in blocks:
             h = blk.hip(h, B, N, context, hs)
             hs = None
-        return self.proj_out.hip(h.view(B, H, W_, -1), res=x)
+        if self.use_linear:
+            return self.proj_out.hip(h.view(B, H, W_, -1), res=x)
+        return self.proj_out.hip(h.view(B, H, W_, -1), res=x, gn_out=True)   # read next by a GroupNorm (ResBlock / head)
 
     def forward(self, x, context=None):
         y = self.hip(ops.to_nhwc(x), as_context_kv(context))

@@ -59,6 +59,8 @@ class TimestepEmbedSequential(nn.Sequential, TimestepBlock):
                 x = layer[2].hip(layer[0].hip(x, silu=True))
             elif isinstance(layer, nn.SiLU):
                 x = ops.activation(x, ops.ACT_SILU)
+            elif isinstance(layer, L.Conv2d):       # stem convolution: its output is the first GroupNorm's input and a skip
+                x = layer.hip(x, gn_out=True)
             else:
                 x = layer.hip(x)
         return x
@@ -85,7 +87,7 @@ class Upsample(nn.Module):
         assert x.shape[-1] == self.channels
         if not self.use_conv:
             raise NotImplementedError("Upsample without conv is not on the hot path")
-        return self.conv.hip(x, ups=True)
+        return self.conv.hip(x, ups=True, gn_out=True)     # read next by a ResBlock's GroupNorm (skip concat)
 
     def forward(self, x):
         return ops.to_nchw(self.hip(ops.to_nhwc(x)), x.dtype)
@@ -102,7 +104,7 @@ class Downsample(nn.Module):
 
     def hip(self, x):
         assert x.shape[-1] == self.channels
-        return self.op.hip(x)
+        return self.op.hip(x, gn_out=True)                   # read next by a ResBlock's GroupNorm, and kept as a skip
 
     def forward(self, x):
         return ops.to_nchw(self.hip(ops.to_nhwc(x)), x.dtype)
@@ -171,7 +173,8 @@ class ResBlock(TimestepBlock):
                                       gn=(self.in_layers[0].hip_table(x, x2), x2, True))
         else:
             hn = self.in_layers[0].hip(x, x2, silu=True)                   # [B,H,W,C1+C2]
-            h = self.in_layers[2].hip(hn, rowvec=e, rows_per_rv=rows_per_rv)   # conv + bias + emb
+            # conv + bias + emb; its output is read by GroupNorm 2 only: the statistics come with it (ops.gemm gn_out)
+            h = self.in_layers[2].hip(hn, rowvec=e, rows_per_rv=rows_per_rv, gn_out=not fuse_out)
         skip = self.skip_connection
         if isinstance(skip, nn.Identity):
             assert x2 is None
@@ -192,7 +195,9 @@ class ResBlock(TimestepBlock):
             sk = skip.hip(x)
         if fuse_out:
             return self.out_layers[3].hip(h, res=sk, gn=(self.out_layers[0].hip_table(h), None, True))
-        return self.out_layers[3].hip(self.out_layers[0].hip(h, silu=True), res=sk)
+        # (the block's output feeds the next GroupNorm -- a ResBlock's, a SpatialTransformer's, the head's -- possibly
+        #  later, as a skip: statistics with the store)
+        return self.out_layers[3].hip(self.out_layers[0].hip(h, silu=True), res=sk, gn_out=True)
 
     def forward(self, x, emb):
         semb = ops.activation(emb.to(torch.float16).contiguous(), ops.ACT_SILU)
@@ -398,7 +403,7 @@ class UNetModel2D_Next(nn.Module, L._Packed):
             elif ltype == 'c':
                 h = ctx_layer(h)
             else:
-                hs.append(torch.cat([h, h]) if pair[0] else h)   # a skip saved before the doubling: stored doubled
+                hs.append(ops.cat_pair(h) if pair[0] else h)   # a skip saved before the doubling: stored doubled
         if pair[0]:
             raise ValueError("cfg_pair: no context layer in the input half of this UNet")
         for ltype in self.m_order:

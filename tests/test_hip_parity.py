@@ -562,3 +562,44 @@ def test_sampler_lanes_match_the_single_graph(net):
     rel = float((outs[2] - outs[1]).norm() / outs[1].norm())
     print(f"[parity] sampler lanes 2 vs 1 (256x256, 4 steps, batch 4): latent rel-L2 {rel:.3e}")
     assert rel <= 5e-3
+
+
+def test_groupnorm_statistics_from_the_producers(net, monkeypatch):
+    """GroupNorm statistics emitted by the launches that write the tensor (PfdGemmDesc.gn_out -> pfd_groupnorm_pstats_f16,
+    round 4) against the same layers with a statistics pass per GroupNorm (PFD_GN_PSTATS=0): a ResBlock chain + a
+    SpatialTransformer at 32x32 / 64x64 with a skip concat whose groups are whole producer groups (640 = 320 + 320) and one
+    whose groups straddle the sources (960 = 640 + 320: falls back to the statistics pass).  The producers' sums are the
+    sums of the stored f16 values in another (fixed) order: equal up to fp32 rounding of the statistics."""
+    from lib.hip import ops
+    unet = net.diffuser['image']
+    g = torch.Generator().manual_seed(23)
+    B = 2
+    semb = (torch.randn((B, 1280), generator=g) * 0.5).half().cuda()
+
+    assert ops.GN_PSTATS
+    rb1, rb2 = unet.data_blocks[1], unet.data_blocks[2]            # 320 -> 320 at the first level
+    st1 = unet.context_blocks[0][0]
+    x0 = torch.randn((B, 64, 64, 320), generator=g).half().cuda()
+    c = torch.randn((B, 148, 768), generator=g).half().cuda()
+    ctx = net.prepare_context(c)
+
+    def chain():
+        h = rb1[0].hip(x0, semb)
+        carried = ops.get_gn_stats(h) is not None
+        h = st1.hip(h, ctx)
+        carried = carried and ops.get_gn_stats(h) is not None
+        h2 = rb2[0].hip(h, semb)
+        up = unet.data_blocks[-2][0]                               # output-half ResBlock 640 = 320 + 320 -> 320
+        assert up.channels == 640 and up.out_channels == 320
+        return up.hip(h2, semb, x2=h), carried
+    y_ps, carried = chain()
+    assert carried, "the producers did not hand their statistics on"
+    monkeypatch.setattr(ops, "GN_PSTATS", False)
+    y_ref, carried_off = chain()
+    monkeypatch.setattr(ops, "GN_PSTATS", True)
+    assert not carried_off
+    check("producer GroupNorm statistics vs statistics pass (ResBlock / SpatialTransformer / skip concat at 64x64)",
+          y_ps, y_ref.float().cpu(), 5e-3)
+    # determinism of the producer sums
+    y_again, _ = chain()
+    assert torch.equal(y_ps, y_again)
