@@ -184,12 +184,24 @@ __device__ __forceinline__ bool epilogue_stage(float4_t (&acc)[WMB][NT], const G
   if (lnstat && p.splits == 1) {
     // LN(x) W^T = rstd_m (x (W o gamma)^T)[m, n] - rstd_m mean_m s_n (+ b'_n, the `bias` of this launch): the affine map
     // goes onto the accumulators, everything behind it (bias, activation / GEGLU, transposed tail) is unchanged
+    // The row statistics first, with their own wait, far in front of their first use.  (Round 4: with the LDS reads issued
+    // right in front of the packed-f32 multiplies that consume them -- `ds_read2_b64 ...; s_waitcnt vmcnt(9) lgkmcnt(0);
+    // v_pk_mul_f32` -- lanes 48-63 of the FIRST product after the wait occasionally saw the previous contents of the
+    // destination registers: one accumulator register of one 16-row tile per ~10^7 elements differed between two launches
+    // of the same problem.  Which launches did so changed with the placement of the kernel in the code object, i.e. with
+    // unrelated edits; tools/determinism_gemm.py repeats single launches and compares bits.  Read early + explicit wait:
+    // 40 / 40 identical in every configuration, profiles/r04_ln_fold_determinism.log.)
+    float2 abv[WMB];
+#pragma unroll
+    for (int i = 0; i < WMB; ++i) abv[i] = lnstat[wm * WMB * 16 + i * 16 + l15];
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
     float4_t cs[NT];
 #pragma unroll
     for (int j = 0; j < NT; ++j) cs[j] = *reinterpret_cast<const float4_t*>(p.ln_cs + nw + j * 16);
 #pragma unroll
     for (int i = 0; i < WMB; ++i) {
-      const float2 ab = lnstat[wm * WMB * 16 + i * 16 + l15];
+      const float2 ab = abv[i];
 #pragma unroll
       for (int j = 0; j < NT; ++j)
 #pragma unroll

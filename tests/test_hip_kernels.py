@@ -300,3 +300,44 @@ def test_operand_validation_is_loud():
     y = conv.hip(x, out=out)
     assert y.data_ptr() == out.data_ptr() and float(out.abs().max()) > 0
     close(out, conv.hip(x))
+
+
+def test_repeated_launches_give_the_same_bits():
+    """Forty launches of the same problem must return the same bits (round 4: the LayerNorm-folded GEMMs did not --
+    lanes 48-63 of the first accumulator the fold touched occasionally saw stale row statistics, depending on where the
+    kernel happened to sit in the code object; profiles/r04_ln_fold_determinism.log).  Every epilogue family: plain,
+    LayerNorm fold in (GEGLU / fused q|k|v with transposed tail / plain), statistics out (LayerNorm, GroupNorm), zero rows,
+    two sources, split-K, and a 3x3 patch convolution with GroupNorm statistics."""
+    from lib.hip import ops
+    g = torch.Generator().manual_seed(1)
+    M, K = 8192, 320
+    x = torch.randn((M, K), generator=g).half().cuda()
+    x2 = torch.randn((M, 320), generator=g).half().cuda()
+    r = torch.randn((M, 320), generator=g).half().cuda()
+    st = ops.ln_rowstats(x)
+
+    def W(n, k=K):
+        return (torch.randn((n, k), generator=g) * 0.05).half().cuda()
+    w320, w960, w2560, w640k = W(320), W(960), W(2560), W(320, 640)
+    b320, b960, b2560 = (torch.randn((n,), generator=g).half().cuda() for n in (320, 960, 2560))
+    cs = {n: w.float().sum(1).contiguous() for n, w in ((320, w320), (960, w960), (2560, w2560))}
+    img = torch.randn((2, 32, 32, 320), generator=g).half().cuda()
+    wc = W(320, 9 * 320)
+    cases = {
+        "plain": lambda: ops.gemm(x, w320, bias=b320, res=r),
+        "ln fold": lambda: ops.gemm(x, w320, bias=b320, ln=(st, cs[320], 1e-5)),
+        "ln fold GEGLU": lambda: ops.gemm(x, w2560, bias=b2560, act=ops.ACT_GEGLU, ln=(st, cs[2560], 1e-5)),
+        "ln fold q|k|v + transposed tail": lambda: ops.gemm(x, w960, bias=b960, ln=(st, cs[960], 1e-5), n_split=640,
+                                                            out_t=torch.empty((320, M), dtype=torch.float16, device='cuda')),
+        "ln statistics out": lambda: ops.gemm(x, w320, bias=b320, res=r, ln_out=True)[0],
+        "GroupNorm statistics out": lambda: ops.gemm(x, w320, bias=b320, res=r, gn_out=True),
+        "zero rows": lambda: ops.gemm(x[: M // 2], w320, bias=b320, res=r, zero_rows=M // 2),
+        "two sources": lambda: ops.gemm(x, w640k, bias=b320, a2=x2),
+        "split-K": lambda: ops.gemm(x[:512], w320, bias=b320, tile=1000 + 2200 + 2),
+        "3x3 patch conv + GroupNorm statistics": lambda: ops.conv(img, wc, 3, bias=b320, gn_out=True),
+    }
+    for name, fn in cases.items():
+        outs = [fn().clone() for _ in range(40)]
+        torch.cuda.synchronize()
+        same = sum(int(torch.equal(o, outs[0])) for o in outs)
+        assert same == 40, f"{name}: only {same}/40 launches returned the same bits"
