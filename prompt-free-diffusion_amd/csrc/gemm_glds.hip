@@ -118,6 +118,29 @@ __device__ __forceinline__ G160Params reload_params() {
   return q;
 }
 
+// Global-memory accesses of the epilogues, with the address space spelled out at the access: a pointer that came out of
+// reload_params() is generic to the compiler (flat_load / flat_store, which also tick lgkmcnt and order against the LDS reads of
+// the store pass); through these they are global_load / global_store whatever the pointer's provenance.
+template <int BYTES> struct GRaw;
+template <> struct GRaw<2>  { typedef unsigned short type; };
+template <> struct GRaw<8>  { typedef unsigned int type __attribute__((ext_vector_type(2))); };
+template <> struct GRaw<16> { typedef unsigned int type __attribute__((ext_vector_type(4))); };
+template <class T>
+__device__ __forceinline__ T gld(const void* ptr) {
+  typedef typename GRaw<sizeof(T)>::type V;
+  const V v = *reinterpret_cast<const __attribute__((address_space(1))) V*>((unsigned long)ptr);
+  T out;
+  __builtin_memcpy(&out, &v, sizeof(T));
+  return out;
+}
+template <class T>
+__device__ __forceinline__ void gst(void* ptr, T val) {
+  typedef typename GRaw<sizeof(T)>::type V;
+  V v;
+  __builtin_memcpy(&v, &val, sizeof(T));
+  *reinterpret_cast<__attribute__((address_space(1))) V*>((unsigned long)ptr) = v;
+}
+
 // output row (index into M) of row `row` of the tile that starts at m0 (see G160Params.pt_w)
 // PT = false (every kernel but the 3x3 patch kernels): rows are consecutive, the mapping folds away
 template <bool PT>
@@ -216,7 +239,7 @@ __device__ __forceinline__ bool epilogue_stage(float4_t (&acc)[WMB][NT], const G
       if (m >= p.M) continue;
 #pragma unroll
       for (int j = 0; j < NT; ++j)
-        *reinterpret_cast<float4_t*>(p.ws + ((long)split * p.M + m) * p.N + nw + j * 16) = acc[i][j];
+        gst<float4_t>(p.ws + ((long)split * p.M + m) * p.N + nw + j * 16, acc[i][j]);
     }
     return false;
   }
@@ -228,7 +251,7 @@ __device__ __forceinline__ bool epilogue_stage(float4_t (&acc)[WMB][NT], const G
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
       Pack8 b;
-      b.u = *reinterpret_cast<const uint2*>(bp + j * bstep);
+      b.u = gld<uint2>(bp + j * bstep);
 #pragma unroll
       for (int r = 0; r < 4; ++r) bv[j][r] = (float)b.e[r];
     }
@@ -240,7 +263,7 @@ __device__ __forceinline__ bool epilogue_stage(float4_t (&acc)[WMB][NT], const G
       for (int j = 0; j < NT; ++j)
 #pragma unroll
         for (int r = 0; r < 4; ++r)   // 16 lanes = 16 consecutive m: 32-byte segments per output row
-          p.Ct[(long)(nw + j * 16 + r - p.n_split) * p.ldct + m] = (half_t)(acc[i][j][r] + bv[j][r]);
+          gst<half_t>(p.Ct + (long)(nw + j * 16 + r - p.n_split) * p.ldct + m, (half_t)(acc[i][j][r] + bv[j][r]));
     }
     return false;
   }
@@ -261,7 +284,7 @@ __device__ __forceinline__ bool epilogue_stage(float4_t (&acc)[WMB][NT], const G
   const int bstep = p.bias ? 16 : 0;
   Pack8 bq[NT];
 #pragma unroll
-  for (int j = 0; j < NT; ++j) bq[j].u = *reinterpret_cast<const uint2*>(bp + j * bstep);
+  for (int j = 0; j < NT; ++j) bq[j].u = gld<uint2>(bp + j * bstep);
   // (the bias stays packed f16 and is widened where it is added: 10 registers instead of 20 through the staging pass of
   //  the loader-wave kernels, which sit at their 168-register limit)
   if (geglu) {
@@ -305,7 +328,7 @@ __device__ __forceinline__ bool epilogue_stage(float4_t (&acc)[WMB][NT], const G
     auto load_rv = [&](Pack8(&rv)[NT], int m) __attribute__((always_inline)) {   // row vector of output row m (clamped)
       const half_t* rvp = p.rowvec + (long)(min(m, p.M - 1) / p.rows_per_rv) * p.ldrv + nw;
 #pragma unroll
-      for (int j = 0; j < NT; ++j) rv[j].u = *reinterpret_cast<const uint2*>(rvp + j * 16);
+      for (int j = 0; j < NT; ++j) rv[j].u = gld<uint2>(rvp + j * 16);
     };
     auto for_rows = [&](auto&& f) __attribute__((always_inline)) {
       f(std::integral_constant<int, 0>{});
@@ -405,7 +428,7 @@ __device__ __forceinline__ void gn_slab_reduce(float (&cs)[8], float (&cq)[8], i
       q += fin[(c >> 3) * 16 + 8 + (c & 7)];
     }
     if (slab0 + s < nslab_total)   // (a tile past M holds slabs that do not exist)
-      out[((long)(slab0 + s) * tiles_n + tile_n) * 16 + gl] = make_float2(a, q);
+      gst<float2>(out + ((long)(slab0 + s) * tiles_n + tile_n) * 16 + gl, make_float2(a, q));
   }
 }
 
@@ -433,7 +456,7 @@ __device__ __forceinline__ void epilogue_store_gn(const G160Params& p, int m0, i
 #pragma unroll
       for (int u = 0; u < UB; ++u) {
         const int row = min(row0 + (it0 + u) * SWEEP, (s + 1) * GN_SLAB - 1);
-        r[u].u = *reinterpret_cast<const uint4*>(p.R + (long)min(tile_row_m<PT>(p, m0, row), p.M - 1) * p.ldr + n0 + cc * 8);
+        r[u].u = gld<uint4>(p.R + (long)min(tile_row_m<PT>(p, m0, row), p.M - 1) * p.ldr + n0 + cc * 8);
       }
     }
 #pragma unroll
@@ -448,7 +471,7 @@ __device__ __forceinline__ void epilogue_store_gn(const G160Params& p, int m0, i
 #pragma unroll
         for (int e = 0; e < 8; ++e) v.e[e] = (half_t)((float)v.e[e] + (float)r[u].e[e]);
       }
-      if (ok) *reinterpret_cast<uint4*>(p.C + (long)m * p.ldc + n0 + cc * 8) = v.u;
+      if (ok) gst<uint4>(p.C + (long)m * p.ldc + n0 + cc * 8, v.u);
       const float mk = ok ? 1.f : 0.f;
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
@@ -498,7 +521,7 @@ __device__ __forceinline__ void epilogue_store(const G160Params& p, int m0, int 
         if (has_r) {
 #pragma unroll
           for (int j = 0; j < CPL; ++j)
-            r[j].u = *reinterpret_cast<const uint4*>(p.R + (long)min(m0 + rowc, p.M - 1) * p.ldr + n0 + (k + 4 * j) * 8);
+            r[j].u = gld<uint4>(p.R + (long)min(m0 + rowc, p.M - 1) * p.ldr + n0 + (k + 4 * j) * 8);
         }
         float sum = 0.f, sq = 0.f;
 #pragma unroll
@@ -512,13 +535,13 @@ __device__ __forceinline__ void epilogue_store(const G160Params& p, int m0, int 
             sum += f;
             sq = fmaf(f, f, sq);
           }
-          if (ok) *reinterpret_cast<uint4*>(p.C + (long)m * p.ldc + n0 + (k + 4 * j) * 8) = v.u;
+          if (ok) gst<uint4>(p.C + (long)m * p.ldc + n0 + (k + 4 * j) * 8, v.u);
         }
         sum += __shfl_xor(sum, 1, 64);
         sq += __shfl_xor(sq, 1, 64);
         sum += __shfl_xor(sum, 2, 64);
         sq += __shfl_xor(sq, 2, 64);
-        if (ok && k == 0) p.ln_out[(long)m * tiles_n + tile_n] = make_float2(sum, sq);
+        if (ok && k == 0) gst<float2>(p.ln_out + (long)m * tiles_n + tile_n, make_float2(sum, sq));
       }
       return;
     }
@@ -541,7 +564,7 @@ __device__ __forceinline__ void epilogue_store(const G160Params& p, int m0, int 
         for (int u = 0; u < U; ++u) {
           const int c = min(tid + (it0 + u) * NTHREADS, TOTAL - 1);
           const int row = c / CPR, cc = c - row * CPR;
-          r[u].u = *reinterpret_cast<const uint4*>(p.R + (long)min(tile_row_m<PT>(p, m0, row), p.M - 1) * p.ldr + nc0 + cc * 8);
+          r[u].u = gld<uint4>(p.R + (long)min(tile_row_m<PT>(p, m0, row), p.M - 1) * p.ldr + nc0 + cc * 8);
         }
       }
 #pragma unroll
@@ -556,7 +579,7 @@ __device__ __forceinline__ void epilogue_store(const G160Params& p, int m0, int 
 #pragma unroll
           for (int e = 0; e < 8; ++e) v.e[e] = (half_t)((float)v.e[e] + (float)r[u].e[e]);
         }
-        *reinterpret_cast<uint4*>(p.C + (long)m * p.ldc + nc0 + cc * 8) = v.u;
+        gst<uint4>(p.C + (long)m * p.ldc + nc0 + cc * 8, v.u);
       }
     }
   };
