@@ -1204,12 +1204,14 @@ __global__ void count_mismatch_kernel(const unsigned short* a, const unsigned sh
 static int replay(const char* path, bool timed = false, int force_tile = 0) {
   FILE* f = fopen(path, "r");
   if (!f) { printf("cannot open %s\n", path); return 1; }
-  std::vector<std::array<long, 19>> rows;
-  std::array<long, 19> r;
-  while (true) {
-    int n = 0;
-    for (int i = 0; i < 19; ++i) n += fscanf(f, "%ld", &r[i]) == 1;
-    if (n != 19) break;
+  // one launch per line: 19 fields (rounds 1-3) or 22 (+ k_split, zero_rows, gn_out != NULL)
+  std::vector<std::array<long, 22>> rows;
+  char line[512];
+  while (fgets(line, sizeof(line), f)) {
+    std::array<long, 22> r{};
+    int n = 0, off = 0, adv = 0;
+    while (n < 22 && sscanf(line + off, "%ld%n", &r[n], &adv) == 1) { ++n; off += adv; }
+    if (n != 19 && n != 22) break;
     rows.push_back(r);
   }
   fclose(f);
@@ -1224,6 +1226,7 @@ static int replay(const char* path, bool timed = false, int force_tile = 0) {
   Dev<float> dWS((size_t)24 << 20);
   size_t maxM = 1;
   for (auto& q : rows) maxM = std::max(maxM, (size_t)q[0]);
+  Dev<float> dGnO((maxM / 64 + 1) * 8 * 16 * 2);   // PfdGemmDesc.gn_out: [M / 64][N / 160 <= 8][16] float2
   Dev<float> dLnS(rand_f(maxM * 16, 1.0f)), dLnC(rand_f(16384, 1.0f)), dLnO(maxM * 16);   // [M][<= 8][2] statistics, column sums
   {  // plausible statistics: sum ~ 0, sum of squares ~ K (so that rstd is finite)
     std::vector<float> st(maxM * 16);
@@ -1259,6 +1262,9 @@ static int replay(const char* path, bool timed = false, int force_tile = 0) {
       const long nout = d.act == PFD_ACT_GEGLU ? d.N / 2 : d.N;
       d.lda = d.ksize > 0 ? d.Cin : d.K; d.ldw = d.K; d.ldc = nout; d.ldr = nout; d.ldrv = d.N;
       d.ws = dWS.p; d.ws_bytes = (size_t)96 << 20;
+      if (q[19] > 0) { d.k_split = (int)q[19]; d.A2 = dA.p + (size_t)d.M * d.k_split; d.lda = d.k_split; d.lda2 = d.K - d.k_split; }
+      d.zero_rows = (int)q[20];
+      if (q[21]) d.gn_out = dGnO.p;
       if (timed) {
         const size_t wn = ((size_t)d.N * d.K + 4095) & ~(size_t)4095;
         if (pool_off + wn > pool_elems) pool_off = 0;
@@ -1312,7 +1318,7 @@ static int replay(const char* path, bool timed = false, int force_tile = 0) {
   HIP_OK(hipDeviceSynchronize());
   printf("replayed %zu launches x%d, %d errors\n", rows.size(), reps, bad);
   if (timed) {
-    struct Agg { std::array<long, 19> q; int n; double ms; };
+    struct Agg { std::array<long, 22> q; int n; double ms; };
     std::vector<Agg> aggs;
     for (size_t i = 0; i < rows.size(); ++i) {
       bool found = false;
@@ -1321,19 +1327,20 @@ static int replay(const char* path, bool timed = false, int force_tile = 0) {
     }
     std::sort(aggs.begin(), aggs.end(), [](const Agg& a, const Agg& b) { return a.ms > b.ms; });
     double tot = 0, tot_ideal = 0;
-    printf("%7s %6s %6s k s u act rv R | %3s %9s %8s %8s %8s %8s\n", "M", "N", "K", "n", "us/launch", "TF/s", "GB/s", "ideal_us", "sum_ms");
+    printf("%7s %6s %6s k s u act rv R ks zrows gn | %3s %9s %8s %8s %8s %8s\n", "M", "N", "K", "n", "us/launch", "TF/s", "GB/s", "ideal_us", "sum_ms");
     for (auto& a : aggs) {
       const auto& q = a.q;
       const double M = q[0], N = q[1], K = q[2];
       const double nout = q[3] == PFD_ACT_GEGLU ? N / 2 : N;
-      const double abytes = q[8] > 0 ? 2.0 * q[12] * q[13] * q[14] * q[15] : 2.0 * M * K;
+      const double Mz = M - q[20];   // rows with a non-zero operand (PfdGemmDesc.zero_rows)
+      const double abytes = q[8] > 0 ? 2.0 * q[12] * q[13] * q[14] * q[15] : 2.0 * Mz * K;
       const double bytes = abytes + 2.0 * N * K + 2.0 * M * nout + (q[6] ? 2.0 * M * nout : 0) + (q[5] ? 2.0 * M * N / std::max<double>(1, std::min<long>(q[18], M)) : 0);
-      const double flops = 2.0 * M * N * K;
+      const double flops = 2.0 * Mz * N * K;
       const double us = a.ms / a.n * 1e3;
       const double ideal = std::max(flops / 2.5e15, bytes / 8e12) * 1e6;
       tot += a.ms; tot_ideal += ideal * a.n * 1e-3;
-      printf("%7ld %6ld %6ld %ld %ld %ld %3ld %2ld %ld | %3d %9.1f %8.1f %8.1f %8.1f %8.2f\n", q[0], q[1], q[2], q[8], q[9], q[11], q[3], q[5], q[6],
-             a.n, us, flops / us * 1e-6, bytes / us * 1e-3, ideal, a.ms);
+      printf("%7ld %6ld %6ld %ld %ld %ld %3ld %2ld %ld %4ld %5ld %ld | %3d %9.1f %8.1f %8.1f %8.1f %8.2f\n", q[0], q[1], q[2], q[8], q[9], q[11], q[3], q[5], q[6],
+             q[19], q[20], q[21], a.n, us, flops / us * 1e-6, bytes / us * 1e-3, ideal, a.ms);
     }
     printf("total %.2f ms per UNet pass (GEMM/conv only); roofline-ideal %.2f ms\n", tot, tot_ideal);
   }

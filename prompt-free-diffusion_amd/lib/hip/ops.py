@@ -92,7 +92,8 @@ def _trace(d):
     with open(_TRACE, "a") as f:
         f.write(" ".join(str(int(v)) for v in (
             d.M, d.N, d.K, d.act, d.bias is not None, d.rowvec is not None, d.R is not None, d.bias_per_row,
-            d.ksize, d.stride, d.pad, d.ups, d.B, d.H, d.Wd, d.Cin, d.Ho, d.Wo, d.rows_per_rv)) + "\n")
+            d.ksize, d.stride, d.pad, d.ups, d.B, d.H, d.Wd, d.Cin, d.Ho, d.Wo, d.rows_per_rv,
+            d.k_split, d.zero_rows, bool(d.gn_out))) + "\n")
 
 
 def _chk16(t, what):

@@ -17,11 +17,11 @@ for w in attn gn; do
   rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $OUT/pmc_write_$w -o w -- $S --bench-$w > $OUT/pmc_write_$w.log 2>&1
 done
 # kernel stats of the other BASELINE configs (C3 ControlNet + SeeCoder-PA, C5 768^2)
-for c in c3 c5; do
+for c in ${PFD_PROFILE_CONFIGS-c3 c5}; do
   rocprofv3 --kernel-trace --stats -d $OUT/kt_$c -o kt -- python $REPO/bench.py --config $c --steps 2 --warmup 1 --no-cpu-baseline --no-prof > $OUT/kt_bench_$c.json 2> $OUT/kt_$c.log
 done
 cd $REPO
-for c in c3 c5; do
+for c in ${PFD_PROFILE_CONFIGS-c3 c5}; do
   python tools/rocpd_stats.py $(find $OUT/kt_$c -name '*results.db' | head -1) $OUT/${TAG}_rocprof_kernel_stats_$c.md > /dev/null 2>&1
 done
 python tools/rocpd_stats.py $(find $OUT/kt -name '*results.db' | head -1) $OUT/${TAG}_rocprof_kernel_stats.md > /dev/null 2>&1
