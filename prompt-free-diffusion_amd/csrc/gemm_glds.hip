@@ -2192,6 +2192,11 @@ int pfd_gemm160_try(const PfdGemmDesc* d, int variant, int splits, hipStream_t s
     // deep operand rings (counted vmcnt): K tiles in flight ahead of the MFMAs = 3 (64-row tile) / 2 (128-row tile)
     case 23: return launch160<2, 2, 4>(p, 14 + 4 * conv, s) < 0 ? PFD_ELAUNCH : 0;
     case 25: return launch160<2, 4, 3>(p, 13 + 4 * conv, s) < 0 ? PFD_ELAUNCH : 0;
+    // round-5 candidates, forced only (no heuristic picks them): the 64-row tiles on a 5-stage ring = 4 K tiles (112 KB of
+    // a CU's 160 KB) in flight.  The K loop of the chip-filling-once problems is a latency chain -- nk / DEPTH round trips
+    // of ~1.9 us each -- so 4 in flight instead of 3 is worth up to a quarter of it if the deeper ring costs nothing else
+    case 26: return launch160<2, 2, 5>(p, 14 + 4 * conv, s) < 0 ? PFD_ELAUNCH : 0;
+    case 46: return launch160<4, 1, 5>(p, 14 + 4 * conv, s) < 0 ? PFD_ELAUNCH : 0;
     // round 3 experiments: the same tiles on 8 waves (4 x 2 wave layout, wave tile 16 x 80 / 32 x 80): twice the waves
     // issuing LDS-DMA pieces per CU and two waves per SIMD on the problems whose one 4-wave block per CU is bound by the
     // piece issue rate (64-row tiles: 41 two stages, 43 four-stage ring; 128-row tiles: 82 two stages, 83 three)

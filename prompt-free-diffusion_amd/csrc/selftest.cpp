@@ -1384,6 +1384,23 @@ int main(int argc, char** argv) {
     printf("SELFTEST %d/%d passed, %d failed\n", g_total - g_fail, g_total, g_fail);
     return g_fail;
   }
+  if (argc > 1 && !strcmp(argv[1], "--r5")) {   // round-5 candidates (forced variants only): 64-row tiles on a 5-stage operand ring
+    for (int v : {3600, 5600}) {
+      run_gemm_case({300, 320, 64, 0, true, true, false, false, v});                                        // ONE K step (ring deeper than the loop)
+      run_gemm_case({300, 320, 192, PFD_ACT_SILU, true, true, true, false, v});                             // three K steps
+      run_gemm_case({1100, 320, 1024, 0, true, true, true, false, v});
+      run_gemm_case({2048, 1280, 1280, 0, true, false, true, false, v});                                    // the 16^2 out-projection class
+      run_gemm_case({512, 1280, 1280, PFD_ACT_GELU, true, true, false, false, v + 2});                      // split-K 2
+      run_gemm_case({0, 320, 0, 0, true, true, true, false, v, 0, 3, 1, 1, 0, 2, 16, 16, 128});               // 3x3 s1 as implicit GEMM
+      run_gemm_case({0, 160, 0, 0, true, false, false, false, v, 0, 3, 2, 1, 0, 2, 16, 16, 128});             // stride 2
+      run_gemm_case({0, 1280, 0, 0, true, true, true, false, v + 4, 0, 3, 1, 1, 0, 8, 8, 8, 1280});           // the 8^2 conv class, split-K 4
+      { GemmCase c{700, 320, 1024, 0, true, true, true, false, v}; c.k_split = 384; run_gemm_case(c); }
+      { GemmCase c{1100, 320, 512, 0, true, true, false, false, v}; c.zero_rows = 512; run_gemm_case(c); }
+      { GemmCase c{768, 320, 512, 0, true, true, true, false, v}; c.gn_out = 1; run_gemm_case(c); }
+    }
+    printf("%d checks, %d failed\n", g_total, g_fail);
+    return g_fail;
+  }
   if (argc > 1 && !strcmp(argv[1], "--r4")) {   // round-4 kernels: 3-stage weight ring of the patch kernel (96), 3-stage loader-wave GEMM (47)
     for (int v : {10600, 10800}) {
       run_gemm_case({0, 320, 0, 0, true, true, true, false, v, 0, 3, 1, 1, 0, 2, 16, 16, 320});               // 16^2, 5 channel blocks

@@ -39,8 +39,9 @@ def _shard_xT(n, h, w, seed):
     return torch.randn([n, 4, h // 8, w // 8], generator=g)
 
 
-def trajectory(eps_fn, cond, uncond, xT, steps, scale=2.0):
-    """`steps` CFG DDIM steps of the CPU oracle from xT (ddim.py:107-172 restated by oracle.ddim_step)"""
+def trajectory(eps_fn, cond, uncond, xT, steps, scale=2.0, stop_after=None):
+    """`steps` CFG DDIM steps of the CPU oracle from xT (ddim.py:107-172 restated by oracle.ddim_step);
+    stop_after=k returns after the first k steps of that schedule (the fixture pin of tests/test_oracle_golden.py)"""
     import pfd_oracle as O
     acp = O.schedule_buffers()["alphas_cumprod"]
     ts, a, ap, sg = O.ddim_tables(acp, steps, 0.0)
@@ -52,17 +53,21 @@ def trajectory(eps_fn, cond, uncond, xT, steps, scale=2.0):
         x, _ = O.ddim_step(eps_fn, x, t, cond, uncond, scale, float(a[idx]), float(ap[idx]), float(sg[idx]))
         if i == 0:
             first = x.clone()
+        if stop_after is not None and i + 1 >= stop_after:
+            break
     return x, first, len(ts)
 
 
-def case_c2(shapes):
+def case_c2(shapes, stop_after=None):
     import pfd_oracle as O
     img = torch.rand((1, 3, 512, 512), generator=torch.Generator().manual_seed(1234))
     sd_u, sd_c, sd_v = _sd(shapes, "diffuser.image."), _sd(shapes, "ctx.image."), _sd(shapes, "vae.image.")
     cond = O.seecoder_encode(sd_c, "ctx.image.", img)
     eps_fn = lambda xx, tt, cc: O.unet_apply(sd_u, "diffuser.image.", xx, tt, cc)  # noqa: E731
-    x, _, n = trajectory(eps_fn, cond, torch.zeros_like(cond), _shard_xT(4, 512, 512, 20)[:1], 50)
-    return {"latent": x, "image": O.vae_decode(sd_v, "vae.image.", x), "steps": n}
+    x, x1, n = trajectory(eps_fn, cond, torch.zeros_like(cond), _shard_xT(4, 512, 512, 20)[:1], 50, stop_after=stop_after)
+    if stop_after is not None:
+        return {"first_step": x1, "steps": n}
+    return {"latent": x, "first_step": x1, "image": O.vae_decode(sd_v, "vae.image.", x), "steps": n}
 
 
 def c5_uncond():
@@ -72,14 +77,16 @@ def c5_uncond():
     return ug.half().float()                                 # the fp16 values the GPU path is handed
 
 
-def case_c5(shapes):
+def case_c5(shapes, stop_after=None):
     import pfd_oracle as O
     img = torch.rand((1, 3, 768, 768), generator=torch.Generator().manual_seed(77))
     sd_u = _sd(shapes, "diffuser.image.")
     cond = O.seecoder_encode(_sd(shapes, "ctx.image."), "ctx.image.", img)
     eps_fn = lambda xx, tt, cc: O.unet_apply(sd_u, "diffuser.image.", xx, tt, cc)  # noqa: E731
-    x, _, n = trajectory(eps_fn, cond, c5_uncond(), _shard_xT(2, 768, 768, 31)[:1], 30)
-    return {"latent": x, "steps": n}
+    x, x1, n = trajectory(eps_fn, cond, c5_uncond(), _shard_xT(2, 768, 768, 31)[:1], 30, stop_after=stop_after)
+    if stop_after is not None:
+        return {"first_step": x1, "steps": n}
+    return {"latent": x, "first_step": x1, "steps": n}
 
 
 def c3_pe_state():
@@ -88,7 +95,7 @@ def c3_pe_state():
     return {k: seeded_tensor(k, s, 0) for k, s in spec.items()}
 
 
-def case_c3(shapes):
+def case_c3(shapes, stop_after=None):
     import pfd_oracle as O
     img = torch.rand((1, 3, 512, 512), generator=torch.Generator().manual_seed(1234))
     hint16 = torch.rand((1, 3, 512, 512), generator=torch.Generator().manual_seed(4321)).half().float()
@@ -101,7 +108,9 @@ def case_c3(shapes):
         res = O.controlnet_apply(sd_ctl, "ctl.", xx, hint16, tt, cc)
         return O.unet_apply(sd_u, "diffuser.image.", xx, tt, cc, control=res)
     xT = _shard_xT(4, 512, 512, 20)[:1]
-    x, x1, n = trajectory(eps_fn, cond, torch.zeros_like(cond), xT, 10)
+    x, x1, n = trajectory(eps_fn, cond, torch.zeros_like(cond), xT, 10, stop_after=stop_after)
+    if stop_after is not None:
+        return {"first_step": x1, "steps": n}
     plain = lambda xx, tt, cc: O.unet_apply(sd_u, "diffuser.image.", xx, tt, cc)  # noqa: E731
     acp = O.schedule_buffers()["alphas_cumprod"]
     ts, a, ap, sg = O.ddim_tables(acp, 10, 0.0)

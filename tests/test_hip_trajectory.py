@@ -7,12 +7,16 @@ on identical seeds/inputs within fp16 tol 1e-2 on latents".  tests/test_hip_kern
 weights, reference image and x_T:
 
   * C2 (headline): 512x512, 50 DDIM steps, CFG 2.0, batch 4 on the GPU; the oracle runs sample 0 (samples are
-    independent) for the same 50 steps on the host -- about five minutes of CPU time, the long pole of the suite;
+    independent) for the same 50 steps on the host -- about five minutes of CPU time;
   * C5: 768x768 (96x96 latent, 9216-token self-attention), batch 2, NON-ZERO unconditional context (the
     SeeCoder-Anime case, app.py:238-241: no zero-context shortcut), all 31 real DDIM steps of the "30-step" schedule;
   * C3: ControlNet + SeeCoder-PA + a control hint, 512x512, batch 4, 10 DDIM steps;
   * SeeCoder-PA (position-aware MLP attached like app.py:166-177) at 512x512;
   * the C4 per-rank shape (8 images per GPU -> UNet batch 16): determinism and batch invariance against the batch-4 run.
+
+The three oracle trajectories (18 minutes of host time) are read from tests/golden/trajectories.npz -- written by
+oracle/make_trajectory_golden.py from tests/oracle_worker.py's cases, pinned to the oracle on the CPU by
+tests/test_oracle_golden.py::test_trajectory_fixture_first_step; PFD_ORACLE_LIVE=1 recomputes them during the session.
 
 Errors are printed both scaled (relative L2 / max-abs over max(1, max|ref|)) and as the plain max-abs.
 """
@@ -39,7 +43,7 @@ def _report(name, a, ref):
 
 def test_config_c2_trajectory_vs_oracle(net, oracle_jobs):
     """BASELINE configs[1] end to end: 512x512, 50 real DDIM steps, CFG 2.0, fp16, batch 4.  Sample 0's latent after
-    the loop and its decoded image against the fp32 CPU oracle (tests/oracle_worker.py case c2, started at session begin):
+    the loop and its decoded image against the fp32 CPU oracle (tests/oracle_worker.py case c2):
     latent rel-L2 <= 1e-2, image <= 2e-2."""
     from lib.pipeline import PromptFreePipeline
     img = torch.rand((1, 3, 512, 512), generator=torch.Generator().manual_seed(1234))
@@ -48,7 +52,7 @@ def test_config_c2_trajectory_vs_oracle(net, oracle_jobs):
     ref = oracle_jobs.get("c2")
     assert ref["steps"] == 50
     print(f"[trajectory] C2 oracle: 50 CFG steps + encode + decode in {ref['seconds']:.0f} s on {ref['threads']} host "
-          f"threads (background job); latent std {float(ref['latent'].std()):.2f}")
+          f"threads ({ref['source']}); latent std {float(ref['latent'].std()):.2f}")
     rel, _ = _report("C2 (512x512, 50 steps, batch 4) latent of sample 0 vs oracle", lat[:1], ref["latent"])
     assert rel <= 1e-2
     _, mx = _report("C2 decoded image of sample 0 vs oracle", im[:1], ref["image"])
@@ -60,7 +64,7 @@ def test_config_c5_trajectory_all_31_steps(net, oracle_jobs):
     patch kernel does not take), batch 2, a NON-ZERO unconditional context (SeeCoder-Anime, app.py:238-241: the
     zero-context shortcut must not trigger), "30" DDIM steps = the 31 real steps of make_ddim_timesteps
     (diffusion_utils.py:32-46: 1000 // 30 = 33 -> range(0, 1000, 33)), sample 0 vs the oracle for the same 31 steps
-    (tests/oracle_worker.py case c5: ~10 minutes of host time, started at session begin)."""
+    (tests/oracle_worker.py case c5: ~10 minutes of host time)."""
     from lib.pipeline import PromptFreePipeline
     from oracle_worker import c5_uncond
     img = torch.rand((1, 3, 768, 768), generator=torch.Generator().manual_seed(77))
@@ -72,7 +76,7 @@ def test_config_c5_trajectory_all_31_steps(net, oracle_jobs):
     assert len(pipe.sampler.ddim_timesteps) == 31
     ref = oracle_jobs.get("c5")
     assert ref["steps"] == 31
-    print(f"[trajectory] C5 oracle: 31 CFG steps at 96x96 in {ref['seconds']:.0f} s on {ref['threads']} host threads (background job)")
+    print(f"[trajectory] C5 oracle: 31 CFG steps at 96x96 in {ref['seconds']:.0f} s on {ref['threads']} host threads ({ref['source']})")
     rel, _ = _report("C5 (768x768, non-zero uncond, 31 real steps, batch 2) latent of sample 0 vs oracle", lat[:1], ref["latent"])
     assert rel <= 1e-2
 
@@ -103,7 +107,7 @@ def test_config_c3_trajectory_vs_oracle(net, oracle_jobs):
     assert ref["steps"] == 10
     # the control must matter: one controlled vs one uncontrolled oracle step from the same x_T
     assert float((ref["first_step"] - ref["first_step_uncontrolled"]).abs().max()) > 1e-2
-    print(f"[trajectory] C3 oracle: SeeCoder-PA + 10 ControlNet-guided CFG steps in {ref['seconds']:.0f} s (background job); "
+    print(f"[trajectory] C3 oracle: SeeCoder-PA + 10 ControlNet-guided CFG steps in {ref['seconds']:.0f} s ({ref['source']}); "
           f"latent std {float(ref['latent'].std()):.2f}")
     rel, _ = _report("C3 (ControlNet + SeeCoder-PA, 512x512, 10 steps, batch 4) latent of sample 0 vs oracle", lat[:1], ref["latent"])
     assert rel <= 1e-2

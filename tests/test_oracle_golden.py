@@ -2,6 +2,7 @@
 modules (oracle/make_golden.py).  This is what pins the oracle; GPU parity tests then compare the
 HIP path with the oracle and with the same fixtures."""
 import json
+import os
 
 import numpy as np
 import pytest
@@ -148,3 +149,25 @@ def test_multicontext_sampling(golden, param_shapes):
         x, _ = O.ddim_step_multicontext(sd, "diffuser.image.", x, t, conds, unconds, list(golden["mc.ratios"]), 2.0,
                                         float(a[idx]), float(ap[idx]), float(sg[idx]))
     assert rel_err(x, golden["mc.out"]) < 1e-3
+
+
+@pytest.mark.parametrize("case", ["c2", "c3", "c5"])
+def test_trajectory_fixture_first_step(case):
+    """tests/golden/trajectories.npz (the oracle trajectories the GPU suite compares whole DDIM runs with at the BASELINE
+    shapes, oracle/make_trajectory_golden.py) is what THIS oracle computes: the first DDIM step of every case -- context
+    encode (SeeCoder / SeeCoder-PA at 512x512 / 768x768), one CFG UNet evaluation (64x64 / 96x96 latent; with the
+    ControlNet residuals for c3), the DDIM update -- is recomputed here from the same seeds and compared.  (The remaining
+    steps repeat the same code on the result; PFD_ORACLE_LIVE=1 in a GPU session recomputes them all.)"""
+    import oracle_worker as OW
+    fx = dict(np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "trajectories.npz"), allow_pickle=False))
+    meta = json.loads(str(fx["meta"]))
+    want_steps = {"c2": 50, "c3": 10, "c5": 31}[case]
+    assert meta["cases"][case]["steps"] == want_steps
+    with torch.no_grad():
+        got = OW.CASES[case](OW._param_shapes(), stop_after=1)
+    assert got["steps"] == want_steps
+    ref = T(fx[f"{case}.first_step"])
+    assert got["first_step"].shape == ref.shape == fx[f"{case}.latent"].shape
+    # same arithmetic on another host / thread count: summation-order noise only
+    assert rel_err(got["first_step"], ref) < 1e-4
+    assert np.isfinite(fx[f"{case}.latent"]).all() and float(np.abs(fx[f"{case}.latent"]).max()) > 1.0
