@@ -5,11 +5,14 @@ set -u
 O=gpurun_out/r04_ab; mkdir -p $O
 B="--steps 6 --warmup 2 --no-cpu-baseline --no-prof"
 T0=$(date +%s)
-for i in 1 2; do
-  timeout 150 python bench.py $B > $O/r04_$i.json 2> $O/r04_$i.err
-  ( cd variants/r03_tree && timeout 120 python bench.py $B > ../../$O/r03_$i.json 2> ../../$O/r03_$i.err )
-  echo "pair $i done after $(( $(date +%s) - T0 )) s"
-done
+pair() {
+  timeout 150 python bench.py $B > $O/r04_$1.json 2> $O/r04_$1.err
+  ( cd variants/r03_tree && timeout 120 python bench.py $B > ../../$O/r03_$1.json 2> ../../$O/r03_$1.err )
+  echo "pair $1 done after $(( $(date +%s) - T0 )) s"
+}
+pair 1
+timeout 160 python -m pytest tests/test_hip_trajectory.py -m gpu -q -s -x > $O/pytest_trajectory.log 2>&1; echo "pytest trajectory rc=$? after $(( $(date +%s) - T0 )) s"; grep "trajectory\]" $O/pytest_trajectory.log | cut -c1-230; tail -2 $O/pytest_trajectory.log
+pair 2
 for f in r04_1 r03_1 r04_2 r03_2; do python - <<P
 import json
 try:
@@ -18,4 +21,3 @@ except Exception as e:
     print("$f", "no result:", e)
 P
 done
-timeout 170 python -m pytest tests/test_hip_trajectory.py -m gpu -q -s -x > $O/pytest_trajectory.log 2>&1; echo "pytest trajectory rc=$? after $(( $(date +%s) - T0 )) s"; grep "trajectory\]" $O/pytest_trajectory.log | cut -c1-230; tail -2 $O/pytest_trajectory.log
