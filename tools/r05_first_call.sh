@@ -1,0 +1,17 @@
+#!/bin/bash
+# First GPU call of the next round (prepared at the end of round 4, never run): correctness of the forced-only 5-stage ring
+# variants (26 = 64x160 on 4 waves, 46 = on 8 waves), then their per-problem A/B on the cold replay of the C2 launch list
+# (tile code 1000 + 100 * variant: a launch the forced variant does not serve falls back to the automatic choice).
+#   usage (on the GPU box): bash tools/r05_first_call.sh   -> gpurun_out/r05_ring5/
+set -u
+O=gpurun_out/r05_ring5; mkdir -p $O
+S=prompt-free-diffusion_amd/csrc/build/selftest
+L=profiles/unet_c2_gemm_shapes.txt
+timeout 120 $S --r5 > $O/selftest_r5.log 2>&1; echo "selftest --r5 rc=$?"; tail -1 $O/selftest_r5.log; grep FAIL $O/selftest_r5.log | head
+for rep in 1 2; do
+  for t in 0 3300 3600 5300 5600; do     # 0 = automatic, 33 / 53 = today's 4-stage rings (variants 23 / 43), 36 / 56 = 5 stages
+    timeout 60 $S --replay-time $L $t > $O/replay_t${t}_$rep.log 2>&1; echo "tile $t run $rep: $(tail -1 $O/replay_t${t}_$rep.log)"
+  done
+done
+for t in 0 3300 3600 5300 5600; do cp $O/replay_t${t}_2.log $O/replay_t$t.log; done
+python tools/replay_merge.py $O 0 3300 3600 5300 5600 > $O/merge.log 2>&1; tail -25 $O/merge.log
