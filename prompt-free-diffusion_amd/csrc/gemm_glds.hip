@@ -1694,6 +1694,228 @@ __global__ __launch_bounds__(768) void conv3x3_patch_ws_kernel(const G160Params 
   epilogue_store<256, 5, 768, false, true>(pe, m0, n0, smem, tid, tile_m * (256 / GN_SLAB));
 }
 
+// ------------------------------------------------------------------------------------------------
+// Round-5 candidate, forced only (variant 95; never the automatic choice, not yet run on hardware): the wave-specialised
+// patch kernel WITHOUT the block-wide barrier per tap.  conv3x3_patch_ws_kernel passes 12 waves through one s_barrier
+// per tap: all eight consumers start their fragment reads together and drain the MFMA pipe together (wait share 0.50,
+// in-loop rate 0.67 of the instruction's ceiling).  Here the two sides hand over through two counters in LDS:
+//   ready  += 1 by every loader wave when ITS pieces of tap T (and, at a block's tap 0, of the patch) have landed
+//             (its own s_waitcnt vmcnt(0));  a consumer starts tap T when ready >= 4 (T + 1)
+//   done   += 1 by every consumer wave when its fragment reads of tap T have returned (lgkmcnt(0));  a loader refills the
+//             weight stage of tap T - 1 with tap T + 1 -- and writes the next block's patch pieces into the buffer block
+//             ci - 1 used -- when done >= 8 T
+// so waves drift up to one tap apart and the two MFMA waves of a SIMD stop waiting at the same instant.  Two weight
+// stages (the 3-stage ring fills all 160 KiB; the counters need 8 bytes), same LDS images, swizzles, DMA pieces,
+// summation order and epilogue as the <0, false, 2> instantiation: results must be bit-identical to it.  Every poll is
+// bounded (FL_SPIN_CAP): a protocol error gives wrong numbers in selftest, not a hung GPU.
+// ------------------------------------------------------------------------------------------------
+constexpr int FL_SPIN_CAP = 1 << 20;
+typedef __attribute__((address_space(3))) unsigned lds_u32_t;
+__device__ __forceinline__ void fl_wait(const char* flag, unsigned target) {
+  const volatile lds_u32_t* f = (const volatile lds_u32_t*)flag;   // ds_read_b32, not a flat load through the aperture
+#pragma nounroll
+  for (int spin = 0; spin < FL_SPIN_CAP; ++spin) {
+    const unsigned v = __builtin_amdgcn_readfirstlane(*f);
+    if (v >= target) break;
+    __builtin_amdgcn_s_sleep(1);
+  }
+  asm volatile("" ::: "memory");
+}
+__device__ __forceinline__ void fl_signal(char* flag, int lane) {
+  asm volatile("" ::: "memory");
+  if (lane == 0) __hip_atomic_fetch_add((lds_u32_t*)flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  asm volatile("" ::: "memory");
+}
+
+__global__ __launch_bounds__(768) void conv3x3_patch_fl_kernel(const G160Params p) {
+  constexpr int NCW = 8, NLW = 4, WMB = 4;
+  constexpr int PATCH_BYTES = PATCH_ROWS * ROWB;  // 51200
+  constexpr int WT_BYTES = BN * ROWB;             // 20480
+  constexpr int OFF_W = 2 * PATCH_BYTES;
+  constexpr int OFF_FLAGS = OFF_W + 2 * WT_BYTES; // {ready, done}
+  constexpr int SMEM = OFF_FLAGS + 1024;
+  static_assert(SMEM <= 160 * 1024, "LDS");
+  constexpr int P_INSTR = PATCH_ROWS / 8;          // 50 DMA pieces per patch
+  __shared__ __attribute__((aligned(1024))) char smem[SMEM];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int nblk = p.tiles_m * p.tiles_n;
+  const int t = xcd_remap(blockIdx.x, nblk);
+  const int tile_m = p.nmajor ? t % p.tiles_m : t / p.tiles_n;
+  const int tile_n = p.nmajor ? t / p.tiles_m : t - tile_m * p.tiles_n;
+  const int n0 = tile_n * BN;
+  const int split = blockIdx.z;
+  const int ncb = p.Cin / BK;
+  const int cb_begin = split * p.kt_per_split;
+  const int cb_end = min(ncb, cb_begin + p.kt_per_split);
+  const int W = p.Wd, H = p.H;
+  const int TW = p.pt_w ? p.pt_w : W;
+  const int TH = 256 / TW, PW = TW + 2;
+  const int hw = H * W;
+  const int tpi = hw / 256, ntx = W / TW;
+  const int b = tile_m / tpi;
+  const int ti = tile_m - b * tpi;
+  const int y0 = (ti / ntx) * TH, x0 = (ti % ntx) * TW;
+  const int m0 = b * hw + y0 * W + x0;
+  const int ncbs = max(0, cb_end - cb_begin);
+  const int nsteps = ncbs * 9;
+  char* const f_ready = smem + OFF_FLAGS;
+  char* const f_done = smem + OFF_FLAGS + 4;
+
+  auto block_barrier = [&]() {
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  if (tid == 0) {
+    volatile lds_u32_t* f = (volatile lds_u32_t*)(smem + OFF_FLAGS);
+    f[0] = 0u;
+    f[1] = 0u;
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  block_barrier();                            // the counters are zero before anyone polls or adds
+
+  if (wave >= NCW) {
+    // ================================ loader waves ================================
+    const int lw = wave - NCW;
+    const int srow = lane >> 3, cpos = lane & 7;
+    const int prow_count = (TH + 2) * PW;
+    const half_t* img = p.A + (long)b * hw * p.lda;
+    auto piece_off = [&](int q) -> int {
+      const int r = q * 8 + srow;
+      const int py = r / PW, px = r - py * PW;
+      const int y = y0 - 1 + py, x = x0 - 1 + px;
+      const int c = (cpos - (r & ~1)) & 7;   // rotation swizzle of the patch rows
+      const bool ok = q < P_INSTR && r < prow_count && y >= 0 && y < H && x >= 0 && x < W;
+      return ok ? (int)((y * W + x) * p.lda + c * 8) : -1;
+    };
+    int off_a[9], off_b[9];
+#pragma unroll
+    for (int tp = 0; tp < 9; ++tp) {
+      off_a[tp] = piece_off(6 * tp + lw);
+      off_b[tp] = piece_off(6 * tp + 4 + lw);
+    }
+    auto issue_patch = [&](int buf, int cb, int q, int off) {
+      glds16(off >= 0 ? (const void*)(img + off + cb * BK) : (const void*)g_zero_page,
+             smem + buf * PATCH_BYTES + q * 1024);
+    };
+    const half_t* wp[5];
+#pragma unroll
+    for (int j = 0; j < 5; ++j) {
+      const int r = (lw + NLW * j) * 8 + srow;
+      const int c = cpos ^ ((r >> 1) & 7);
+      wp[j] = w_row_ptr(p, n0 + r, c * 8);
+    }
+    auto issue_w = [&](int stage, int tap, int cb) {
+      const long k0 = (long)(tap * (p.Cin / BK) + cb) * p.w_kstep;
+#pragma unroll
+      for (int j = 0; j < 5; ++j) glds16(wp[j] + k0, smem + OFF_W + stage * WT_BYTES + (lw + NLW * j) * 1024);
+    };
+    if (nsteps > 0) {
+#pragma unroll
+      for (int tp = 0; tp < 9; ++tp) {     // the whole first patch
+        if (6 * tp + lw < P_INSTR) issue_patch(0, cb_begin, 6 * tp + lw, off_a[tp]);
+        if (lw < 2 && 6 * tp + 4 + lw < P_INSTR) issue_patch(0, cb_begin, 6 * tp + 4 + lw, off_b[tp]);
+      }
+      issue_w(0, 0, cb_begin);
+    }
+    int stage = 0;
+    unsigned T = 0;                           // taps handed over so far
+    for (int ci = 0; ci < ncbs; ++ci) {
+      const int cb = cb_begin + ci;
+      const int pbuf = ci & 1;
+      const bool more = ci + 1 < ncbs;
+      const int cb1 = more ? cb + 1 : cb;
+#pragma unroll
+      for (int tap = 0; tap < 9; ++tap) {
+        __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): this wave's pieces of tap T (and of the patch) are in LDS
+        fl_signal(f_ready, lane);
+        fl_wait(f_done, 8u * T);              // every consumer has read tap T - 1: its weight stage (and block ci - 1's patch) are free
+        if (tap < 8) issue_w(stage ^ 1, tap + 1, cb);
+        else if (more) issue_w(stage ^ 1, 0, cb1);
+        if (more) {
+          if (6 * tap + lw < P_INSTR) issue_patch(pbuf ^ 1, cb1, 6 * tap + lw, off_a[tap]);
+          if (lw < 2 && 6 * tap + 4 + lw < P_INSTR) issue_patch(pbuf ^ 1, cb1, 6 * tap + 4 + lw, off_b[tap]);
+        }
+        stage ^= 1;
+        ++T;
+      }
+    }
+    block_barrier();                          // (B) consumers finished the last tap: LDS is free
+    block_barrier();                          // (C) the staging image is written
+  } else {
+    // ================================ consumer waves ================================
+    const int wm = wave >> 1, wn = wave & 1;
+    const int l15 = lane & 15, g = lane >> 4;
+    int rbase[WMB];
+#pragma unroll
+    for (int i = 0; i < WMB; ++i) {
+      const int ql = wm * 64 + i * 16;
+      const int ty = ql / TW, tx = ql - ty * TW;
+      rbase[i] = ty * PW + tx + l15;
+    }
+    const int sw = (l15 >> 1) & 7;
+    const int boff0 = wn * 80 * ROWB + l15 * ROWB + (((0 + g) ^ sw) << 4);
+    const int boff1 = wn * 80 * ROWB + l15 * ROWB + (((4 + g) ^ sw) << 4);
+    float4_t acc[WMB][5];
+#pragma unroll
+    for (int i = 0; i < WMB; ++i)
+#pragma unroll
+      for (int j = 0; j < 5; ++j) acc[i][j] = (float4_t){0.f, 0.f, 0.f, 0.f};
+    auto a_off = [&](int i, int toff, int ks) -> int {   // byte offset of A fragment i in the patch (rotation swizzle)
+      const int r = rbase[i] + toff;
+      return r * ROWB + ((((ks * 4 + g) + (r & ~1)) & 7) << 4);
+    };
+    int stage = 0;
+    unsigned T = 0;
+    for (int ci = 0; ci < ncbs; ++ci) {
+      const char* patch = smem + (ci & 1) * PATCH_BYTES;
+      int toff = 0;
+#pragma nounroll
+      for (int ky = 0; ky < 3; ++ky) {
+#pragma nounroll
+        for (int kx = 0; kx < 3; ++kx) {
+          ++T;
+          fl_wait(f_ready, 4u * T);           // all four loaders' pieces of this tap have landed
+          const char* wt = smem + OFF_W + stage * WT_BYTES;
+#pragma unroll
+          for (int ks = 0; ks < 2; ++ks) {
+            half8_t af[WMB], bf[5];
+#pragma unroll
+            for (int i = 0; i < WMB; ++i) af[i] = *reinterpret_cast<const half8_t*>(patch + a_off(i, toff, ks));
+            const int bo = ks ? boff1 : boff0;
+#pragma unroll
+            for (int j = 0; j < 5; ++j) bf[j] = *reinterpret_cast<const half8_t*>(wt + bo + j * 16 * ROWB);
+#pragma unroll
+            for (int i = 0; i < WMB; ++i)
+#pragma unroll
+              for (int j = 0; j < 5; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[j], af[i], acc[i][j], 0, 0, 0);
+          }
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this tap's fragments are in registers
+          fl_signal(f_done, lane);
+          stage ^= 1;
+          toff += 1;
+        }
+        toff += PW - 3;
+      }
+    }
+    block_barrier();                          // (B)
+    {
+      const G160Params pe = reload_params();
+      epilogue_stage<WMB, 5, true>(acc, pe, lane, m0, n0, wm, wn, split, smem);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    block_barrier();                          // (C)
+  }
+  const G160Params pe = reload_params();
+  epilogue_store<256, 5, 768, false, true>(pe, m0, n0, smem, tid, tile_m * (256 / GN_SLAB));
+}
+
 // sum the split-K slabs and apply the epilogue (bias, row vector, activation, residual)
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const G160Params p) {
   const int nv = p.N / 8;
@@ -1941,7 +2163,8 @@ int launch160ws(G160Params& p, int bucket, hipStream_t s, int pp) {
   return pfd_check_launch("pfd_gemm_f16(wave-specialised)");
 }
 
-// ws: 0 = 8-wave kernel, 1 = + 4 loader waves, 2 = + ping-pong consumer groups, 3 = loader waves + 3-stage weight ring
+// ws: 0 = 8-wave kernel, 1 = + 4 loader waves, 2 = + ping-pong consumer groups, 3 = loader waves + 3-stage weight ring,
+//     4 = loader waves handing over through LDS counters instead of a barrier per tap (forced variant 95, round-5 candidate)
 int launch_patch(G160Params& p, hipStream_t s, int ws) {
   p.tiles_m = p.M / 256;
   p.tiles_n = p.N / BN;
@@ -1957,6 +2180,7 @@ int launch_patch(G160Params& p, hipStream_t s, int ws) {
                    2.0 * p.B * p.H * p.Wd * p.Cin + 2.0 * p.N * p.K + 2.0 * p.M * p.N * (p.R ? 2 : 1), s);
   if (p.gn_table && p.gn_act == PFD_ACT_SILU) hipLaunchKernelGGL((conv3x3_patch_ws_kernel<2, false>), grid, dim3(768), 0, s, p);
   else if (p.gn_table) hipLaunchKernelGGL((conv3x3_patch_ws_kernel<1, false>), grid, dim3(768), 0, s, p);
+  else if (ws == 4) hipLaunchKernelGGL(conv3x3_patch_fl_kernel, grid, dim3(768), 0, s, p);
   else if (ws == 3) hipLaunchKernelGGL((conv3x3_patch_ws_kernel<0, false, 3>), grid, dim3(768), 0, s, p);
   else if (ws == 2) hipLaunchKernelGGL((conv3x3_patch_ws_kernel<0, true>), grid, dim3(768), 0, s, p);
   else if (ws) hipLaunchKernelGGL((conv3x3_patch_ws_kernel<0, false>), grid, dim3(768), 0, s, p);
@@ -2064,7 +2288,7 @@ int pfd_gemm160_try(const PfdGemmDesc* d, int variant, int splits, hipStream_t s
     else if (p.Wd % 16 == 0 && p.H % 16 == 0) pt_w = 16;
   }
   const bool patch_w = p.Wd == 16 || p.Wd == 32 || p.Wd == 64 || (pt_w != 0 && r3tiles_on());
-  if (bn == 160 && (variant == 0 || variant == 99 || variant == 98 || variant == 97 || variant == 96) && p.ksize == 3 && p.stride == 1 && p.pad == 1 && !p.ups &&
+  if (bn == 160 && (variant == 0 || variant == 99 || variant == 98 || variant == 97 || variant == 96 || variant == 95) && p.ksize == 3 && p.stride == 1 && p.pad == 1 && !p.ups &&
       patch_w && p.Ho == p.H && p.Wo == p.Wd && (pt_w != 0 || p.H % (256 / p.Wd) == 0) &&
       p.M % 256 == 0 && ((long)p.H * p.Wd) % 256 == 0 && p.act != PFD_ACT_GEGLU) {
     p.pt_w = pt_w;
@@ -2089,10 +2313,11 @@ int pfd_gemm160_try(const PfdGemmDesc* d, int variant, int splits, hipStream_t s
     // on the long-K ones (32768 x 320 x 8640: 149 -> 131 us = 1435 TF; profiles/r02_patch_ws_ab.log), with ping-pong
     // consumer groups (round 3); 99 forces the 8-wave form, 98 loader waves + lock-step consumers, 97 ping-pong
     // 96 forces the 3-stage weight ring (two taps of weights in flight, counted vmcnt; round 4); PFD_PATCH_RING=0/1 picks the default
-    const int ws = variant == 99 ? 0 : variant == 98 ? 1 : variant == 97 ? 2 : variant == 96 ? 3 : (pp_on() ? 2 : patch_ring_on() ? 3 : 1);
+    const int ws = variant == 99 ? 0 : variant == 98 ? 1 : variant == 97 ? 2 : variant == 96 ? 3 : variant == 95 ? 4 : (pp_on() ? 2 : patch_ring_on() ? 3 : 1);
+    if (ws == 4 && p.gn_table) return 1;   // the GroupNorm prologue lives in conv3x3_patch_ws_kernel<1 / 2> only
     return launch_patch(p, s, ws) < 0 ? PFD_ELAUNCH : 0;
   }
-  if (variant == 99 || variant == 98 || variant == 97 || variant == 96 || p.gn_table) return 1;
+  if (variant == 99 || variant == 98 || variant == 97 || variant == 96 || variant == 95 || p.gn_table) return 1;
   const bool auto_variant = variant == 0;
   const int nk_all = p.K / BK;
   if (auto_variant) {

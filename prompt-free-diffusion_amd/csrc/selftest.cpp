@@ -404,6 +404,43 @@ static void run_ln_fold_case(int M, int C, int N, int act, int tile_prod, int ti
   }
 }
 
+// the same 3x3 / s1 / p1 convolution under two forced tile codes: the results must be the same bits, on every one of
+// `reps` launches of the second code (a hand-over protocol that races shows up as a launch that differs)
+static void run_conv_same_case(int B, int H, int W, int Cin, int N, int tile_a, int tile_b, bool res, int reps = 8) {
+  const long M = (long)B * H * W, K = 9L * Cin;
+  auto A = rand_h((size_t)M * Cin), Wt = rand_h((size_t)N * K, 1.7f / sqrtf((float)K)), Bv = rand_h(N), R = rand_h((size_t)M * N);
+  Dev<h16> dA(A), dW(Wt), dB(Bv), dR(R), dC1((size_t)M * N), dC2((size_t)M * N);
+  Dev<float> dWS((size_t)8 * M * N);
+  PfdGemmDesc d;
+  memset(&d, 0, sizeof(d));
+  d.M = (int)M; d.N = N; d.K = (int)K; d.A = dA.p; d.W = dW.p; d.bias = dB.p; d.R = res ? dR.p : nullptr;
+  d.lda = Cin; d.ldw = K; d.ldc = N; d.ldr = N; d.ldrv = N; d.rows_per_rv = 1;
+  d.ksize = 3; d.stride = 1; d.pad = 1; d.B = B; d.H = H; d.Wd = W; d.Cin = Cin; d.Ho = H; d.Wo = W;
+  d.ws = dWS.p; d.ws_bytes = (size_t)8 * M * N * sizeof(float);
+  char name[160];
+  snprintf(name, sizeof(name), "conv3x3 B%d %dx%d %d->%d tile %d == tile %d (bitwise, %d launches)%s", B, H, W, Cin, N, tile_a, tile_b, reps, res ? " +res" : "");
+  ++g_total;
+  d.C = dC1.p;
+  int rc = pfd_gemm_f16_ex(&d, tile_a, nullptr);
+  if (rc != 0) { ++g_fail; printf("FAIL %-58s rc=%d (%s)\n", name, rc, pfd_last_error()); return; }
+  auto y1 = dC1.get();
+  d.C = dC2.p;
+  for (int r = 0; r < reps; ++r) {
+    HIP_OK(hipMemset(dC2.p, 0xFF, (size_t)M * N * sizeof(h16)));
+    rc = pfd_gemm_f16_ex(&d, tile_b, nullptr);
+    if (rc != 0) { ++g_fail; printf("FAIL %-58s rc=%d (%s)\n", name, rc, pfd_last_error()); return; }
+    auto y2 = dC2.get();
+    if (memcmp(y1.data(), y2.data(), y1.size() * sizeof(h16))) {
+      size_t nd = 0;
+      for (size_t i = 0; i < y1.size(); ++i) nd += memcmp(&y1[i], &y2[i], sizeof(h16)) != 0;
+      ++g_fail;
+      printf("FAIL %-58s launch %d: %zu of %zu elements differ\n", name, r, nd, y1.size());
+      return;
+    }
+  }
+  printf("ok   %-58s\n", name);
+}
+
 // pfd_add_rowvec_lnstats_f16 == pfd_add_rowvec_f16 followed by pfd_ln_rowstats_f16, bit for bit (values and statistics)
 static void run_add_rowvec_lnstats_case(int R, int C) {
   auto X = rand_h((size_t)R * C, 3.0f), V = rand_h(C, 1.0f);
@@ -1397,6 +1434,24 @@ int main(int argc, char** argv) {
       { GemmCase c{700, 320, 1024, 0, true, true, true, false, v}; c.k_split = 384; run_gemm_case(c); }
       { GemmCase c{1100, 320, 512, 0, true, true, false, false, v}; c.zero_rows = 512; run_gemm_case(c); }
       { GemmCase c{768, 320, 512, 0, true, true, true, false, v}; c.gn_out = 1; run_gemm_case(c); }
+    }
+    // forced variant 95: the patch kernel that hands over through LDS counters instead of a barrier per tap
+    {
+      const int v = 10500;
+      run_gemm_case({0, 320, 0, 0, true, true, true, false, v, 0, 3, 1, 1, 0, 2, 16, 16, 320});               // 16^2, 5 channel blocks
+      run_gemm_case({0, 160, 0, PFD_ACT_SILU, true, true, true, false, v, 0, 3, 1, 1, 0, 1, 32, 32, 128});    // 32^2, 2 blocks
+      run_gemm_case({0, 320, 0, 0, true, false, true, false, v, 0, 3, 1, 1, 0, 1, 64, 64, 64});               // 64^2, ONE block (no successor)
+      run_gemm_case({0, 160, 0, 0, true, true, false, false, v, 0, 3, 1, 1, 0, 3, 16, 16, 192});              // several samples, 3 blocks
+      run_gemm_case({0, 160, 0, 0, true, true, true, false, v, 0, 3, 1, 1, 0, 1, 16, 48, 128});               // 2-D tiles (48-wide)
+      run_gemm_case({0, 160, 0, 0, true, true, true, false, v + 2, 0, 3, 1, 1, 0, 1, 16, 16, 256});           // split over channel blocks
+      run_gemm_case({0, 160, 0, 0, true, true, true, false, v + 3, 0, 3, 1, 1, 0, 1, 16, 16, 448});           // uneven split (3, 2, 2)
+      { GemmCase c{0, 320, 0, 0, true, true, true, false, v, 0, 3, 1, 1, 0, 2, 16, 16, 128}; c.gn_out = 1; run_gemm_case(c); }
+      // same bits as the barrier form with two weight stages (98), launch after launch: C2 shapes incl. the long-K ones
+      run_conv_same_case(2, 16, 16, 320, 320, 10800, 10500, true);
+      run_conv_same_case(8, 64, 64, 320, 320, 10800, 10500, true);
+      run_conv_same_case(8, 64, 64, 960, 320, 10800, 10500, false);
+      run_conv_same_case(8, 32, 32, 640, 640, 10800, 10500, true);
+      run_conv_same_case(8, 16, 16, 1280, 1280, 10800, 10500, false);
     }
     printf("%d checks, %d failed\n", g_total, g_fail);
     return g_fail;

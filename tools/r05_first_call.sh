@@ -1,6 +1,8 @@
 #!/bin/bash
-# First GPU call of the next round (prepared at the end of round 4, never run): correctness of the forced-only 5-stage ring
-# variants (26 = 64x160 on 4 waves, 46 = on 8 waves), then their per-problem A/B on the cold replay of the C2 launch list
+# First GPU call of the next round (prepared at the end of round 4, never run): correctness of the forced-only candidates --
+# 5-stage ring variants (26 = 64x160 on 4 waves, 46 = on 8 waves) and the patch kernel that hands over through LDS counters
+# instead of a barrier per tap (95; every poll is bounded, a protocol error shows as a FAIL, not a hang) -- under a short
+# timeout FIRST, then their per-problem A/B on the cold replay of the C2 launch list
 # (tile code 1000 + 100 * variant: a launch the forced variant does not serve falls back to the automatic choice).
 #   usage (on the GPU box): bash tools/r05_first_call.sh   -> gpurun_out/r05_ring5/
 set -u
@@ -13,5 +15,11 @@ for rep in 1 2; do
     timeout 60 $S --replay-time $L $t > $O/replay_t${t}_$rep.log 2>&1; echo "tile $t run $rep: $(tail -1 $O/replay_t${t}_$rep.log)"
   done
 done
-for t in 0 3300 3600 5300 5600; do cp $O/replay_t${t}_2.log $O/replay_t$t.log; done
+for rep in 1 2; do
+  for t in 10800 10500; do               # patch kernel: 98 = barrier per tap with two weight stages (the like-for-like base), 95 = LDS counters
+    timeout 60 $S --replay-time $L $t > $O/replay_t${t}_$rep.log 2>&1; echo "tile $t run $rep: $(tail -1 $O/replay_t${t}_$rep.log)"
+  done
+done
+for t in 0 3300 3600 5300 5600 10800 10500; do cp $O/replay_t${t}_2.log $O/replay_t$t.log; done
+python tools/replay_merge.py $O 0 10800 10500 > $O/merge_patch.log 2>&1; tail -12 $O/merge_patch.log
 python tools/replay_merge.py $O 0 3300 3600 5300 5600 > $O/merge.log 2>&1; tail -25 $O/merge.log
