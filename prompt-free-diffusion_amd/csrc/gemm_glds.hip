@@ -1709,7 +1709,7 @@ __global__ __launch_bounds__(768) void conv3x3_patch_ws_kernel(const G160Params 
 // summation order and epilogue as the <0, false, 2> instantiation: results must be bit-identical to it.  Every poll is
 // bounded (FL_SPIN_CAP): a protocol error gives wrong numbers in selftest, not a hung GPU.
 // ------------------------------------------------------------------------------------------------
-constexpr int FL_SPIN_CAP = 1 << 20;
+constexpr int FL_SPIN_CAP = 1 << 16;   // ~3 ms of polling: three orders of magnitude above a tap, far below a watchdog
 typedef __attribute__((address_space(3))) unsigned lds_u32_t;
 __device__ __forceinline__ void fl_wait(const char* flag, unsigned target) {
   const volatile lds_u32_t* f = (const volatile lds_u32_t*)flag;   // ds_read_b32, not a flat load through the aperture
