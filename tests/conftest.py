@@ -12,6 +12,10 @@ for p in (PKG, os.path.join(REPO, "oracle"), REPO):
     if p not in sys.path:
         sys.path.insert(0, p)
 os.environ.setdefault("PFD_QUIET", "1")
+# CPU references (the oracle, fp32 torch formulas): the GPU boxes report 256 host threads but a container gets about 64
+# threads' worth of CPU -- the real oracle UNet step takes 4.9 / 5.0 / 7.0 s on 16 / 32 / 64 threads (bench.py's sweep,
+# profiles/r04_bench_c2.json) and far longer on all 256
+torch.set_num_threads(max(1, min(32, os.cpu_count() or 1)))
 
 
 def pytest_configure(config):
