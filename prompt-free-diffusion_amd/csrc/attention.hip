@@ -327,7 +327,10 @@ __global__ __launch_bounds__(256, (D <= 40 ? 4 : 1)) void attention_kernel(const
 //    accumulator rescale -- sees the same rounded number, so the rounding cancels in O / l exactly like any other
 //    common factor.  The maximum is only RAISED when a row's tile maximum exceeds the folded one by more than 6 (P <= 64
 //    in f16; the guide's T13 deferred rescale), or on the first tile; that path subtracts the increment explicitly.
-template <int D, int NWAVES, bool PV16, bool FOLD = false>
+// PRIO (round-5 candidate, PFD_ATTN=7, never the default and not yet run on hardware): s_setprio(1) around the two MFMA
+// clusters of a tile (the guide's T5: +4-7 % on attention kernels whose waves are in different phases -- here the two
+// 8-wave blocks of a CU are not synchronised with each other, so a wave in its softmax competes with a wave in its MFMAs)
+template <int D, int NWAVES, bool PV16, bool FOLD = false, bool PRIO = false>
 __global__ __launch_bounds__(NWAVES * 64, (D <= 40 ? 4 : 1)) void attention2_kernel(const AttnParams p) {
   static_assert(!PV16 || D == 40, "the 16x16x32 PV path is laid out for d = 40 (48 padded rows, row 40 = ones)");
   static_assert(!FOLD || D == 40, "the folded maximum uses contraction slot 40 of the d = 40 build (DQK = 48)");
@@ -515,6 +518,7 @@ __global__ __launch_bounds__(NWAVES * 64, (D <= 40 ? 4 : 1)) void attention2_ker
     const half_t* Kt = Ks + stage * K_TILE_HALFS;
     const half_t* Vt = Vts + stage * V_TILE_HALFS;
     float16_t st[NU];
+    if constexpr (PRIO) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
     for (int u = 0; u < NU; ++u) {
 #pragma unroll
@@ -526,6 +530,7 @@ __global__ __launch_bounds__(NWAVES * 64, (D <= 40 ? 4 : 1)) void attention2_ker
         st[u] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[s], st[u], 0, 0, 0);
       }
     }
+    if constexpr (PRIO) __builtin_amdgcn_s_setprio(0);
     if (RAG) {
 #pragma unroll
       for (int u = 0; u < NU; ++u)
@@ -623,6 +628,7 @@ __global__ __launch_bounds__(NWAVES * 64, (D <= 40 ? 4 : 1)) void attention2_ker
         pb[u][0] = r0.h;
         pb[u][1] = r1.h;
       }
+      if constexpr (PRIO) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
       for (int i = 0; i < NDT; ++i)
 #pragma unroll
@@ -636,6 +642,7 @@ __global__ __launch_bounds__(NWAVES * 64, (D <= 40 ? 4 : 1)) void attention2_ker
           o16[i][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf, pb[u][0], o16[i][0], 0, 0, 0);
           o16[i][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf, pb[u][1], o16[i][1], 0, 0, 0);
         }
+      if constexpr (PRIO) __builtin_amdgcn_s_setprio(0);
     } else {
 #pragma unroll
       for (int i = 0; i < ND; ++i) {
@@ -927,7 +934,8 @@ static int launch512(const AttnParams& p, hipStream_t s) {
 
 // PFD_ATTN: 0 = round-2 kernel; 1 = peeled loop, 4 waves, PV on 32x32x16; 2 = + 8 waves per block (d = 40, big grids);
 // 3 = 4 waves + PV on 16x16x32 (d = 40); 4 = 8 waves + PV on 16x16x32 where 8-wave blocks apply, mode 1 elsewhere;
-// 5 = mode 2 + the maximum folded into the QK^T MFMA; 6 (default) = mode 4 + fold.
+// 5 = mode 2 + the maximum folded into the QK^T MFMA; 6 (default) = mode 4 + fold; 7 = mode 6 + s_setprio around the MFMA
+// clusters (round-5 candidate, unmeasured).
 // PFD_ATTN_FORCE8=1 takes the 8-wave form for every d = 40 problem (tests).
 static int attn_mode() {
   static const int m = getenv("PFD_ATTN") ? atoi(getenv("PFD_ATTN")) : 6;
@@ -947,14 +955,15 @@ int launch(const AttnParams& p, hipStream_t s) {
   const int mode = attn_mode();
   // 8-wave blocks pay when a block has many queries to amortise the staging over and the grid still fills the chip twice
   const bool big = p.Nq >= 1024 && (long)p.B * p.H * ((p.Nq + 255) / 256) >= 512;
-  const bool w8 = (mode == 2 || mode == 4 || mode == 5 || mode == 6) && D == 40 && (big || attn_force8());
+  const bool w8 = (mode == 2 || mode == 4 || mode == 5 || mode == 6 || mode == 7) && D == 40 && (big || attn_force8());
   const int qb = w8 ? 256 : 128;
   dim3 grid(((p.Nq + qb - 1) / qb) * p.H * p.B);
   if (mode == 0) {
     hipLaunchKernelGGL((attention_kernel<D, 64>), grid, dim3(256), 0, s, p);
   } else if constexpr (D == 40) {
-    const bool pv16 = mode == 3 || ((mode == 4 || mode == 6) && w8);   // (the 4-wave PV16 build spills 24 bytes at 128 VGPRs)
-    if (w8 && mode == 6) hipLaunchKernelGGL((attention2_kernel<D, 8, true, true>), grid, dim3(512), 0, s, p);
+    const bool pv16 = mode == 3 || ((mode == 4 || mode == 6 || mode == 7) && w8);   // (the 4-wave PV16 build spills 24 bytes at 128 VGPRs)
+    if (w8 && mode == 7) hipLaunchKernelGGL((attention2_kernel<D, 8, true, true, true>), grid, dim3(512), 0, s, p);
+    else if (w8 && mode == 6) hipLaunchKernelGGL((attention2_kernel<D, 8, true, true>), grid, dim3(512), 0, s, p);
     else if (w8 && mode == 5) hipLaunchKernelGGL((attention2_kernel<D, 8, false, true>), grid, dim3(512), 0, s, p);
     else if (w8 && pv16) hipLaunchKernelGGL((attention2_kernel<D, 8, true>), grid, dim3(512), 0, s, p);
     else if (w8) hipLaunchKernelGGL((attention2_kernel<D, 8, false>), grid, dim3(512), 0, s, p);
