@@ -861,6 +861,196 @@ __global__ __launch_bounds__(WAVES_M * 128) void gemm160_kernel(const G160Params
 }
 
 // ------------------------------------------------------------------------------------------------
+// Round-5 candidate, forced only (variants 27 / 45 / 85; never the automatic choice, not yet run on hardware): the ring
+// kernel of the linear layers with the ACTIVATION fragments loaded global -> VGPR and only the weights on the LDS ring.
+// Why: the chip-filling-once linears (16^2 / 8^2 levels, ff-out, cond-half projections) are a chain of K-tile round
+// trips (nk / DEPTH x ~1.9 us cold); K tiles in flight are capped by the 160 KiB of LDS -- 3 of 28 KB on the
+// 64-row tile (variant 23), 4 with the 5-stage ring (26).  A wave's own A fragments are exactly what the MFMA's B slot
+// wants -- lane (l15, g) holds halfs [32 ks + 8 g, + 8) of row l15 = one 16-byte load per fragment -- and only the two
+// waves of a row block share them, so they need not go through LDS at all: a stage is then the 20 KB weight tile alone,
+// 7 stages = 6 K tiles in flight in 140 KB, and the A fragments of those 6 tiles wait in registers (WMB x 2 x 4 VGPRs
+// per tile; a 4-wave block owns the CU's whole register file).  Same K walk, same fragment values, same MFMA order per
+// accumulator, same epilogue as gemm160_kernel<., ., false, ., 5>: results must be bit-identical to variants 23 / 43 / 83
+// (selftest --r5 compares them launch by launch).
+// The A loads are asm statements hipcc does not count (guide 5.7, form (iii)): written as plain loads, the waitcnt pass
+// merges the conditional issues of prologue and loop conservatively and drains the whole queue (vmcnt(0)) in front of the
+// MFMAs of slot 0, once per trip round the ring.  They are issued BEFORE the weight pieces of their K tile, so the
+// counted wait in front of the barrier -- the only VM wait of the loop -- covers them; an empty "+v" statement per
+// register behind the barrier keeps every consumer below it.
+// ------------------------------------------------------------------------------------------------
+typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ u32x4_t gld16_uncounted(const void* src) {
+  u32x4_t d;
+  asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(d) : "v"((const __attribute__((address_space(1))) void*)src) : "memory");
+  return d;
+}
+template <int WAVES_M, int WMB, int NBUF>
+__global__ __launch_bounds__(WAVES_M * 128) void gemm160ar_kernel(const G160Params p) {
+  constexpr int NT = 5;
+  constexpr int BN = 32 * NT;
+  constexpr int NW = WAVES_M * 2;
+  constexpr int BM = WAVES_M * WMB * 16;
+  constexpr int B_INSTR = BN / 8;                  // 20 weight pieces of 1 KiB per K tile
+  constexpr int B_PER_WAVE = (B_INSTR + NW - 1) / NW;
+  constexpr bool B_DUP = B_INSTR % NW != 0;        // surplus slots re-issue the piece NW below: same count in every wave
+  constexpr int STAGE = BN * ROWB;                 // weights only
+  constexpr int MAIN_BYTES = NBUF * STAGE;
+  constexpr int DEPTH = NBUF - 1;
+  static_assert(NBUF >= 3, "ring kernel");
+  static_assert(MAIN_BYTES + BM * 8 <= 160 * 1024, "weight ring exceeds the 160 KiB LDS");
+  static_assert(BM * stage_row_bytes(BN) <= MAIN_BYTES, "the epilogue's staging image reuses the weight ring");
+  static_assert(WAVES_M * 128 >= BM, "one thread per row forms the LayerNorm statistics");
+  __shared__ __attribute__((aligned(1024))) char smem[MAIN_BYTES + BM * 8];
+  float2* const lnstat = reinterpret_cast<float2*>(smem + MAIN_BYTES);
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int l15 = lane & 15, g = lane >> 4;
+
+  const int nblk = p.tiles_m * p.tiles_n;
+  const int t = xcd_remap(blockIdx.x, nblk);
+  const int tile_m = p.nmajor ? t % p.tiles_m : t / p.tiles_n;
+  const int tile_n = p.nmajor ? t / p.tiles_m : t - tile_m * p.tiles_n;
+  const int m0 = tile_m * BM;
+  const int n0 = tile_n * BN;
+  const int split = blockIdx.z;
+  const int kt_begin = split * p.kt_per_split;
+  const int nk_total = p.K / BK;
+  const int kt_end = min(nk_total, kt_begin + p.kt_per_split);
+
+  // A fragments: this lane's 16-byte chunk g of row (wm WMB + i) 16 + l15; rows past M / below zero_rows read the zero
+  // page (their K offset is held at 0: the page is 256 bytes)
+  const half_t* a_ptr[WMB];
+  const half_t* a2_ptr[WMB];
+  int a_adv[WMB];
+#pragma unroll
+  for (int i = 0; i < WMB; ++i) {
+    const int m = m0 + (wm * WMB + i) * 16 + l15;
+    const int mz = m - p.zero_rows;
+    const bool ok = m < p.M && mz >= 0;
+    a_ptr[i] = ok ? p.A + (long)mz * p.lda + g * 8 : g_zero_page + g * 8;
+    a2_ptr[i] = ok ? p.A2 + (long)mz * p.lda2 + g * 8 : g_zero_page + g * 8;
+    a_adv[i] = ok ? 1 : 0;
+  }
+  const int srow = lane >> 3;
+  const int cpos = lane & 7;
+  const half_t* b_ptr[B_PER_WAVE];
+#pragma unroll
+  for (int j = 0; j < B_PER_WAVE; ++j) {
+    int q = wave + NW * j;
+    if (q >= B_INSTR) q = B_DUP ? q - NW : 0;
+    const int r = q * 8 + srow;
+    const int c = cpos ^ ((r >> 1) & 7);
+    b_ptr[j] = w_row_ptr(p, n0 + r, c * 8);
+  }
+
+  const int nsteps = (m0 + BM <= p.zero_rows) ? 0 : kt_end - kt_begin;
+  int kt_issue = kt_begin + k_rotation(p.krot, tile_m, p.tiles_m, nsteps);
+
+  u32x4_t areg[NBUF][WMB][2];
+  auto issue = [&](int slot) __attribute__((always_inline)) {   // slot: compile-time constant after unrolling
+    const int k0 = kt_issue * BK;
+    const long kw = kt_issue * p.w_kstep;
+    const bool first = k0 < p.k_split;   // wave-uniform: which source this K tile comes from
+    const int ka = first ? k0 : k0 - p.k_split;
+#pragma unroll
+    for (int i = 0; i < WMB; ++i) {
+      const half_t* src = (first ? a_ptr[i] : a2_ptr[i]) + ka * a_adv[i];
+      areg[slot][i][0] = gld16_uncounted(src);
+      areg[slot][i][1] = gld16_uncounted(src + 32);
+    }
+    char* Bs = smem + slot * STAGE;
+#pragma unroll
+    for (int j = 0; j < B_PER_WAVE; ++j) {
+      const int q = wave + NW * j;
+      if (q < B_INSTR) glds16(b_ptr[j] + kw, Bs + q * 1024);
+      else if (B_DUP) glds16(b_ptr[j] + kw, Bs + (q - NW) * 1024);
+    }
+    if (++kt_issue == kt_end) kt_issue = kt_begin;   // wrap-around of the rotated walk (wave-uniform)
+  };
+
+  float4_t acc[WMB][NT];
+#pragma unroll
+  for (int i = 0; i < WMB; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j) acc[i][j] = (float4_t){0.f, 0.f, 0.f, 0.f};
+
+  const int sw = (l15 >> 1) & 7;
+  const int off_k0 = ((0 + g) ^ sw) * 16 + l15 * ROWB;
+  const int off_k1 = ((4 + g) ^ sw) * 16 + l15 * ROWB;
+  const int b_row0 = wn * (16 * NT) * ROWB;
+
+  if (nsteps > 0) {
+    constexpr int PER_STEP = WMB * 2 + B_PER_WAVE;
+    constexpr int KEEP = PER_STEP * (DEPTH - 1);   // VMEM instructions that may stay outstanding
+    static_assert(KEEP < 64, "vmcnt is 6 bits");
+    constexpr int WAIT_KEEP = (KEEP & 15) | ((KEEP >> 4) << 14) | (7 << 4) | (15 << 8);
+#pragma unroll
+    for (int s = 0; s < DEPTH; ++s)
+      if (s < nsteps) issue(s);
+    if (p.ln_in && tid < BM) {   // row statistics of this block's rows from the producer's partial sums
+      const int m = min(m0 + tid, p.M - 1);
+      const float2* src = p.ln_in + (long)m * p.ln_P;
+      float sum = 0.f, sq = 0.f;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float2 v = src[min(j, p.ln_P - 1)];
+        const float w = j < p.ln_P ? 1.f : 0.f;
+        sum = fmaf(v.x, w, sum);
+        sq = fmaf(v.y, w, sq);
+      }
+      const float inv_k = 1.0f / (float)p.K;
+      const float mean = sum * inv_k;
+      const float var = fmaxf(fmaf(-mean, mean, sq * inv_k), 0.f);
+      const float rstd = rsqrtf(var + p.ln_eps);
+      lnstat[tid] = make_float2(rstd, -rstd * mean);
+    }
+    for (int st0 = 0; st0 < nsteps; st0 += NBUF) {
+#pragma unroll
+      for (int u = 0; u < NBUF; ++u) {   // stage / register slot of step st0 + u is u (st0 is a multiple of NBUF)
+        const int st = st0 + u;
+        if (st >= nsteps) break;
+        // only the OLDEST tile has to have landed: its A registers were requested before its weight pieces
+        if (st + DEPTH - 1 < nsteps) __builtin_amdgcn_s_waitcnt(WAIT_KEEP);
+        else __builtin_amdgcn_s_waitcnt(0x0F70);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+#pragma unroll
+        for (int i = 0; i < WMB; ++i) {   // the registers of this step are valid from here on (see gld16_uncounted)
+          asm volatile("" : "+v"(areg[u][i][0]));
+          asm volatile("" : "+v"(areg[u][i][1]));
+        }
+        if (st + DEPTH < nsteps) issue((u + DEPTH) % NBUF);   // the stage / slot step st - 1 has just left
+        const char* base = smem + u * STAGE + b_row0;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+          const int off = ks ? off_k1 : off_k0;
+          half8_t af[WMB], bf[NT];
+#pragma unroll
+          for (int i = 0; i < WMB; ++i) {
+            af[i] = __builtin_bit_cast(half8_t, areg[u][i][ks]);
+          }
+#pragma unroll
+          for (int j = 0; j < NT; ++j) bf[j] = *reinterpret_cast<const half8_t*>(base + j * 16 * ROWB + off);
+#pragma unroll
+          for (int i = 0; i < WMB; ++i)
+#pragma unroll
+            for (int j = 0; j < NT; ++j)
+              acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[j], af[i], acc[i][j], 0, 0, 0);
+        }
+      }
+    }
+    __syncthreads();  // the epilogue reuses the ring as staging space
+  }
+
+  epilogue160<WMB, NT, WAVES_M * 128, true>(acc, p, lane, m0, n0, wm, wn, split, smem, tid, p.ln_in ? lnstat : nullptr,
+                                            tile_m * (BM / GN_SLAB));
+}
+
+// ------------------------------------------------------------------------------------------------
 // Wave-specialised form of the 256 x BN tile kernel: 8 consumer waves (the 4 x 2 MFMA layout above) that
 // never touch VMEM in the K loop + 4 loader waves (one per SIMD) that do nothing but issue the LDS-DMA pieces.
 // Why: on the kernel above, DMA-only (33 us) and MFMA-only (29 us) times of the GEGLU GEMM simply ADD to the
@@ -2132,6 +2322,24 @@ int launch160(G160Params& p, int bucket, hipStream_t s) {
   return pfd_check_launch("pfd_gemm_f16(wide)");
 }
 
+// forced variants 27 / 45 / 85 (round-5 candidates): activation fragments in registers, weights on a 7-stage LDS ring
+template <int WAVES_M, int WMB, int NBUF>
+int launch160ar(G160Params& p, int bucket, hipStream_t s) {
+  constexpr int BM = WAVES_M * WMB * 16;
+  p.tiles_m = (p.M + BM - 1) / BM;
+  p.tiles_n = p.N / 160;
+  p.nmajor = pick_nmajor(p);
+  p.krot = krot_mode() >= 1;
+  const int nk = p.K / BK;
+  p.kt_per_split = (nk + p.splits - 1) / p.splits;
+  p.splits = (nk + p.kt_per_split - 1) / p.kt_per_split;
+  dim3 grid(p.tiles_m * p.tiles_n, 1, p.splits);
+  PfdProfScope prof_scope(bucket, 2.0 * p.M * p.N * p.K, 2.0 * p.M * p.K + 2.0 * p.N * p.K + 2.0 * p.M * p.N * (p.R ? 2 : 1), s);
+  hipLaunchKernelGGL((gemm160ar_kernel<WAVES_M, WMB, NBUF>), grid, dim3(WAVES_M * 128), 0, s, p);
+  if (p.splits > 1) launch_splitk_reduce(p, s);
+  return pfd_check_launch("pfd_gemm_f16(wide, A in registers)");
+}
+
 template <int NT>
 // mode: 0 = two stages, 1 = ping-pong consumer groups, 2 = 3-stage ring
 int launch160ws(G160Params& p, int bucket, hipStream_t s, int pp) {
@@ -2360,7 +2568,7 @@ int pfd_gemm160_try(const PfdGemmDesc* d, int variant, int splits, hipStream_t s
     }
   }
   const int bm = (variant == 44 || variant == 48 || variant == 49 || variant == 47 || variant == 84) ? 256
-                 : (variant == 24 || variant == 25 || variant == 82 || variant == 83) ? 128 : 64;
+                 : (variant == 24 || variant == 25 || variant == 82 || variant == 83 || variant == 85) ? 128 : 64;
   if (splits == 0) {
     splits = 1;
     const long tl = tiles(bm);
@@ -2368,12 +2576,12 @@ int pfd_gemm160_try(const PfdGemmDesc* d, int variant, int splits, hipStream_t s
     if (p.act != PFD_ACT_GEGLU && d->ws && (variant == 44 || variant == 48 || variant == 49 || variant == 47) && tl < 200 && nk >= 48 &&
         (size_t)2 * p.M * p.N * 4 <= d->ws_bytes) {
       splits = 2;  // 128 tiles of 256x160: two K halves fill the chip (758 vs 579 TF at 640->640 @32^2)
-    } else if (p.act != PFD_ACT_GEGLU && d->ws && (variant == 24 || variant == 25 || variant == 82 || variant == 83) && tl < 256) {
+    } else if (p.act != PFD_ACT_GEGLU && d->ws && (variant == 24 || variant == 25 || variant == 82 || variant == 83 || variant == 85) && tl < 256) {
       splits = (int)((512 + tl - 1) / tl);
       if (splits > 8) splits = 8;
       while (splits > 1 && nk / splits < 16) --splits;  // the slab round trip must stay small vs the K loop
       while (splits > 1 && (size_t)splits * p.M * p.N * 4 > d->ws_bytes) --splits;
-    } else if (p.act != PFD_ACT_GEGLU && d->ws && (variant == 22 || variant == 23 || variant == 41 || variant == 43 || variant == 26 || variant == 46) && tl <= 128 && nk >= 16) {
+    } else if (p.act != PFD_ACT_GEGLU && d->ws && (variant == 22 || variant == 23 || variant == 41 || variant == 43 || variant == 26 || variant == 46 || variant == 27 || variant == 45) && tl <= 128 && nk >= 16) {
       splits = (int)(256 / tl);   // M <= 1024 rows (8^2 level, cond-half projections): 25 -> 21 us
       if (splits > 4) splits = 4;
       while (splits > 1 && (size_t)splits * p.M * p.N * 4 > d->ws_bytes) --splits;
@@ -2393,6 +2601,7 @@ int pfd_gemm160_try(const PfdGemmDesc* d, int variant, int splits, hipStream_t s
     if (variant == 82 && (p.ksize == 0 || (p.stride == 1 && !p.ups)) && tiles(128) <= 256 && nk_split >= 6) variant = 83;
   }
   const int conv = p.ksize > 0 ? 1 : 0;
+  if ((variant == 27 || variant == 45 || variant == 85) && (bn != 160 || conv)) return 1;   // 160-wide linear tiles only
   if (variant == 48 || variant == 49 || variant == 47) {   // 8 MFMA waves + 4 loader waves (49: ping-pong consumer groups, 47: 3-stage ring)
     const int mode = variant == 49 ? 1 : variant == 47 ? 2 : 0;
     if (bn == 128) return launch160ws<4>(p, 12 + 4 * conv, s, mode) < 0 ? PFD_ELAUNCH : 0;
@@ -2422,6 +2631,12 @@ int pfd_gemm160_try(const PfdGemmDesc* d, int variant, int splits, hipStream_t s
     // of ~1.9 us each -- so 4 in flight instead of 3 is worth up to a quarter of it if the deeper ring costs nothing else
     case 26: return launch160<2, 2, 5>(p, 14 + 4 * conv, s) < 0 ? PFD_ELAUNCH : 0;
     case 46: return launch160<4, 1, 5>(p, 14 + 4 * conv, s) < 0 ? PFD_ELAUNCH : 0;
+    // round-5 candidates, forced only: activation fragments global -> VGPR, weights alone on a 7-stage LDS ring = 6 K tiles
+    // in flight (gemm160ar_kernel).  Linear layers only (a launch they do not serve falls back to the automatic choice);
+    // 27 = 64 x 160 on 4 waves, 45 = 64 x 160 on 8 waves, 85 = 128 x 160 on 8 waves
+    case 27: return (conv || p.act == PFD_ACT_GEGLU) ? 1 : launch160ar<2, 2, 7>(p, 14, s) < 0 ? PFD_ELAUNCH : 0;
+    case 45: return (conv || p.act == PFD_ACT_GEGLU) ? 1 : launch160ar<4, 1, 7>(p, 14, s) < 0 ? PFD_ELAUNCH : 0;
+    case 85: return (conv || p.act == PFD_ACT_GEGLU) ? 1 : launch160ar<4, 2, 7>(p, 13, s) < 0 ? PFD_ELAUNCH : 0;
     // round 3 experiments: the same tiles on 8 waves (4 x 2 wave layout, wave tile 16 x 80 / 32 x 80): twice the waves
     // issuing LDS-DMA pieces per CU and two waves per SIMD on the problems whose one 4-wave block per CU is bound by the
     // piece issue rate (64-row tiles: 41 two stages, 43 four-stage ring; 128-row tiles: 82 two stages, 83 three)

@@ -441,6 +441,51 @@ static void run_conv_same_case(int B, int H, int W, int Cin, int N, int tile_a, 
   printf("ok   %-58s\n", name);
 }
 
+// the same linear layer (bias, optional residual / split-K / two-source contraction / zero rows) under two forced tile
+// codes: same bits, on every one of `reps` launches of the second code
+static void run_lin_same_case(int M, int N, int K, int tile_a, int tile_b, bool res, int k_split = 0, int zero_rows = 0, int reps = 8) {
+  auto A = rand_h((size_t)M * K), Wt = rand_h((size_t)N * K, 1.7f / sqrtf((float)K)), Bv = rand_h(N), R = rand_h((size_t)M * N);
+  const int K1 = k_split > 0 ? k_split : K, K2 = K - K1, Mz = M - zero_rows;
+  // operand rows below zero_rows are not stored; columns >= k_split live in a second buffer
+  std::vector<h16> A1((size_t)Mz * K1), A2((size_t)Mz * (K2 > 0 ? K2 : 1));
+  for (int m = 0; m < Mz; ++m) {
+    for (int k = 0; k < K1; ++k) A1[(size_t)m * K1 + k] = A[(size_t)(m + zero_rows) * K + k];
+    for (int k = 0; k < K2; ++k) A2[(size_t)m * K2 + k] = A[(size_t)(m + zero_rows) * K + K1 + k];
+  }
+  Dev<h16> dA(A1), dA2(A2), dW(Wt), dB(Bv), dR(R), dC1((size_t)M * N), dC2((size_t)M * N);
+  Dev<float> dWS((size_t)8 * M * N);
+  PfdGemmDesc d;
+  memset(&d, 0, sizeof(d));
+  d.M = M; d.N = N; d.K = K; d.A = dA.p; d.W = dW.p; d.bias = dB.p; d.R = res ? dR.p : nullptr;
+  d.lda = K1; d.ldw = K; d.ldc = N; d.ldr = N; d.ldrv = N; d.rows_per_rv = 1;
+  if (k_split > 0) { d.k_split = k_split; d.A2 = dA2.p; d.lda2 = K2; }
+  d.zero_rows = zero_rows;
+  d.ws = dWS.p; d.ws_bytes = (size_t)8 * M * N * sizeof(float);
+  char name[200];
+  snprintf(name, sizeof(name), "linear %dx%dx%d tile %d == tile %d (bitwise, %d launches)%s ks%d zr%d", M, N, K, tile_a, tile_b, reps,
+           res ? " +res" : "", k_split, zero_rows);
+  ++g_total;
+  d.C = dC1.p;
+  int rc = pfd_gemm_f16_ex(&d, tile_a, nullptr);
+  if (rc != 0) { ++g_fail; printf("FAIL %-58s rc=%d (%s)\n", name, rc, pfd_last_error()); return; }
+  auto y1 = dC1.get();
+  d.C = dC2.p;
+  for (int r = 0; r < reps; ++r) {
+    HIP_OK(hipMemset(dC2.p, 0xFF, (size_t)M * N * sizeof(h16)));
+    rc = pfd_gemm_f16_ex(&d, tile_b, nullptr);
+    if (rc != 0) { ++g_fail; printf("FAIL %-58s rc=%d (%s)\n", name, rc, pfd_last_error()); return; }
+    auto y2 = dC2.get();
+    if (memcmp(y1.data(), y2.data(), y1.size() * sizeof(h16))) {
+      size_t nd = 0;
+      for (size_t i = 0; i < y1.size(); ++i) nd += memcmp(&y1[i], &y2[i], sizeof(h16)) != 0;
+      ++g_fail;
+      printf("FAIL %-58s launch %d: %zu of %zu elements differ\n", name, r, nd, y1.size());
+      return;
+    }
+  }
+  printf("ok   %-58s\n", name);
+}
+
 // pfd_add_rowvec_lnstats_f16 == pfd_add_rowvec_f16 followed by pfd_ln_rowstats_f16, bit for bit (values and statistics)
 static void run_add_rowvec_lnstats_case(int R, int C) {
   auto X = rand_h((size_t)R * C, 3.0f), V = rand_h(C, 1.0f);
@@ -1452,6 +1497,38 @@ int main(int argc, char** argv) {
       run_conv_same_case(8, 64, 64, 960, 320, 10800, 10500, false);
       run_conv_same_case(8, 32, 32, 640, 640, 10800, 10500, true);
       run_conv_same_case(8, 16, 16, 1280, 1280, 10800, 10500, false);
+    }
+    // forced variants 27 / 45 / 85: activation fragments global -> VGPR (uncounted asm loads), weights on a 7-stage ring
+    for (int v : {3700, 5500, 9500}) {
+      run_gemm_case({300, 320, 64, 0, true, true, false, false, v});                                        // ONE K step (ring deeper than the loop)
+      run_gemm_case({300, 320, 192, PFD_ACT_SILU, true, true, true, false, v});                             // three K steps
+      run_gemm_case({300, 320, 448, 0, true, true, false, false, v});                                       // 7 steps = exactly one trip round the ring
+      run_gemm_case({300, 320, 512, 0, true, false, false, false, v});                                      // 8 steps: slot 0 again
+      run_gemm_case({1100, 320, 1024, 0, true, true, true, false, v});                                      // ragged M, 16 steps
+      run_gemm_case({77, 160, 960, 0, true, false, false, false, v, 8});                                    // odd leading dimensions, 15 steps
+      run_gemm_case({2048, 1280, 1280, 0, true, false, true, false, v});                                    // the 16^2 out-projection class
+      run_gemm_case({512, 1280, 1280, PFD_ACT_GELU, true, true, false, false, v + 2});                      // split-K 2
+      run_gemm_case({512, 1280, 5120, 0, true, true, false, false, v + 4});                                 // split-K 4, 20 steps per split
+      { GemmCase c{700, 320, 1024, 0, true, true, true, false, v}; c.k_split = 384; run_gemm_case(c); }
+      { GemmCase c{1100, 320, 512, 0, true, true, false, false, v}; c.zero_rows = 512; run_gemm_case(c); }
+      { GemmCase c{600, 160, 256, PFD_ACT_SILU, true, true, true, false, v}; c.zero_rows = 300; c.k_split = 64; run_gemm_case(c); }
+      { GemmCase c{768, 320, 512, 0, true, true, true, false, v}; c.gn_out = 1; run_gemm_case(c); }
+      { GemmCase c{520, 480, 128, 0, false, false, false, false, v}; c.n_split = 320; run_gemm_case(c); }  // transposed tail
+      { GemmCase c{1100, 320, 1024, 0, true, true, false, false, v}; c.w_tiled = 1; run_gemm_case(c); }     // K-tile-contiguous weights
+    }
+    run_ln_fold_case(200, 1280, 1280, PFD_ACT_GELU, 5300, 3700, 0);   // LayerNorm fold through the new kernels (consumer side)
+    run_ln_fold_case(520, 640, 640, 0, 9200, 9500, 0);
+    run_ln_fold_case(77, 960, 160, 0, 9300, 5500, 0);
+    // same bits as the LDS-ring kernels of the same tile (23 / 43 / 83), launch after launch, at the C2 shapes they would serve
+    for (int pair = 0; pair < 3; ++pair) {
+      const int ta = pair == 0 ? 3300 : pair == 1 ? 5300 : 9300, tb = pair == 0 ? 3700 : pair == 1 ? 5500 : 9500;
+      run_lin_same_case(2048, 1280, 1280, ta, tb, true);
+      run_lin_same_case(2048, 1280, 5120, ta, tb, true);
+      run_lin_same_case(8192, 640, 2560, ta, tb, true);
+      run_lin_same_case(1024, 1280, 1280, ta, tb, false);
+      run_lin_same_case(512, 1280, 2560, ta, tb, false, 1280);          // skip GEMM over [h | skip]
+      run_lin_same_case(2048, 1280, 1280, ta, tb, true, 0, 1024);       // zero-context out-projection
+      run_lin_same_case(512, 1280, 1280, ta + 2, tb + 2, true);         // split-K 2
     }
     printf("%d checks, %d failed\n", g_total, g_fail);
     return g_fail;

@@ -75,6 +75,35 @@ def audit(asm_path):
     return {k: v for k, v in res.items() if "kernel" in k}
 
 
+def areg_loop_waits(asm_path):
+    """gemm160ar_kernel (A fragments in registers, uncounted asm loads): {kernel: (KEEP, bad)} where `bad` lists every VM
+    wait between the first and the last MFMA of the kernel that is neither the counted wait of the K loop (vmcnt(KEEP),
+    KEEP = per-step VMEM instructions x (ring depth - 2)) nor the drain of the loop's tail (a bare vmcnt(0)); a
+    compiler-inserted wait there (it shows as `vmcnt(N) lgkmcnt(M)` or another N) would serialise the ring."""
+    res, name, body = {}, None, []
+    for line in open(asm_path):
+        m = re.match(r"^(_Z[A-Za-z0-9_]+):", line)
+        if m:
+            name, body = m.group(1), []
+            continue
+        if name and "gemm160ar_kernel" in name:
+            t = line.split(";")[0].strip()
+            if t.startswith(".Lfunc_end"):
+                tm = re.search(r"gemm160ar_kernelILi(\d)ELi(\d)ELi(\d)E", name)
+                waves_m, wmb, nbuf = (int(x) for x in tm.groups())
+                nw = 2 * waves_m
+                keep = (2 * wmb + (20 + nw - 1) // nw) * (nbuf - 2)
+                idx = [i for i, x in enumerate(body) if x.startswith("v_mfma")]
+                loop = body[idx[0]:idx[-1] + 1]
+                waits = [x for x in loop if x.startswith("s_waitcnt") and "vmcnt" in x]
+                bad = [x for x in waits if x not in (f"s_waitcnt vmcnt({keep})", "s_waitcnt vmcnt(0)")]
+                res[name] = (keep, bad, len([x for x in waits if x == f"s_waitcnt vmcnt({keep})"]), nbuf)
+                name = None
+            elif t:
+                body.append(t)
+    return res
+
+
 def findings(files=None):
     files = files or [os.path.join(CSRC, f) for f in ("gemm_glds.hip", "gemm_conv.hip", "norm.hip")]
     bad, rows = [], []
