@@ -884,7 +884,7 @@ __device__ __forceinline__ u32x4_t gld16_uncounted(const void* src) {
   asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(d) : "v"((const __attribute__((address_space(1))) void*)src) : "memory");
   return d;
 }
-template <int WAVES_M, int WMB, int NBUF>
+template <int WAVES_M, int WMB, int NBUF, bool CONV = false>
 __global__ __launch_bounds__(WAVES_M * 128) void gemm160ar_kernel(const G160Params p) {
   constexpr int NT = 5;
   constexpr int BN = 32 * NT;
@@ -900,7 +900,7 @@ __global__ __launch_bounds__(WAVES_M * 128) void gemm160ar_kernel(const G160Para
   static_assert(MAIN_BYTES + BM * 8 <= 160 * 1024, "weight ring exceeds the 160 KiB LDS");
   static_assert(BM * stage_row_bytes(BN) <= MAIN_BYTES, "the epilogue's staging image reuses the weight ring");
   static_assert(WAVES_M * 128 >= BM, "one thread per row forms the LayerNorm statistics");
-  __shared__ __attribute__((aligned(1024))) char smem[MAIN_BYTES + BM * 8];
+  __shared__ __attribute__((aligned(1024))) char smem[MAIN_BYTES + (CONV ? 0 : BM * 8)];
   float2* const lnstat = reinterpret_cast<float2*>(smem + MAIN_BYTES);
 
   const int tid = threadIdx.x;
@@ -921,19 +921,42 @@ __global__ __launch_bounds__(WAVES_M * 128) void gemm160ar_kernel(const G160Para
   const int kt_end = min(nk_total, kt_begin + p.kt_per_split);
 
   // A fragments: this lane's 16-byte chunk g of row (wm WMB + i) 16 + l15; rows past M / below zero_rows read the zero
-  // page (their K offset is held at 0: the page is 256 bytes)
+  // page (their K offset is held at 0: the page is 256 bytes).  Convolutions: the row is an output pixel, its source
+  // pixel changes with the tap (tap outer, channel block inner -- the K walk of gemm160_kernel<., ., true>), padding
+  // reads the zero page.
   const half_t* a_ptr[WMB];
   const half_t* a2_ptr[WMB];
   int a_adv[WMB];
+  int a_oy[WMB], a_ox[WMB];
+  long a_img[WMB];
+  bool a_ok[WMB];
 #pragma unroll
   for (int i = 0; i < WMB; ++i) {
     const int m = m0 + (wm * WMB + i) * 16 + l15;
-    const int mz = m - p.zero_rows;
-    const bool ok = m < p.M && mz >= 0;
-    a_ptr[i] = ok ? p.A + (long)mz * p.lda + g * 8 : g_zero_page + g * 8;
-    a2_ptr[i] = ok ? p.A2 + (long)mz * p.lda2 + g * 8 : g_zero_page + g * 8;
-    a_adv[i] = ok ? 1 : 0;
+    if constexpr (CONV) {
+      const int hw = p.Ho * p.Wo;
+      const int b = m / hw;
+      const int rem = m - b * hw;
+      const int oy = rem / p.Wo;
+      a_ok[i] = m < p.M;
+      a_oy[i] = oy * p.stride - p.pad;
+      a_ox[i] = (rem - oy * p.Wo) * p.stride - p.pad;
+      a_img[i] = (long)b * p.H * p.Wd * p.lda;
+      a_ptr[i] = a2_ptr[i] = p.A;
+      a_adv[i] = 1;
+    } else {
+      const int mz = m - p.zero_rows;
+      const bool ok = m < p.M && mz >= 0;
+      a_ptr[i] = ok ? p.A + (long)mz * p.lda + g * 8 : g_zero_page + g * 8;
+      a2_ptr[i] = ok ? p.A2 + (long)mz * p.lda2 + g * 8 : g_zero_page + g * 8;
+      a_adv[i] = ok ? 1 : 0;
+      a_ok[i] = ok;
+      a_oy[i] = a_ox[i] = 0;
+      a_img[i] = 0;
+    }
   }
+  const int Hin = p.ups ? 2 * p.H : p.H;
+  const int Win = p.ups ? 2 * p.Wd : p.Wd;
   const int srow = lane >> 3;
   const int cpos = lane & 7;
   const half_t* b_ptr[B_PER_WAVE];
@@ -946,20 +969,52 @@ __global__ __launch_bounds__(WAVES_M * 128) void gemm160ar_kernel(const G160Para
     b_ptr[j] = w_row_ptr(p, n0 + r, c * 8);
   }
 
-  const int nsteps = (m0 + BM <= p.zero_rows) ? 0 : kt_end - kt_begin;
+  const int nsteps = (!CONV && m0 + BM <= p.zero_rows) ? 0 : kt_end - kt_begin;
   int kt_issue = kt_begin + k_rotation(p.krot, tile_m, p.tiles_m, nsteps);
+  int tap_ky = 0, tap_kx = 0, ci0 = 0;
+  const half_t* a_tap[WMB];   // conv: this lane's source chunk for the current tap at channel 0 (nullptr = padding)
+  auto set_tap = [&]() {
+#pragma unroll
+    for (int i = 0; i < WMB; ++i) {
+      int iy = a_oy[i] + tap_ky, ix = a_ox[i] + tap_kx;
+      const bool ok = a_ok[i] && iy >= 0 && iy < Hin && ix >= 0 && ix < Win;
+      if (p.ups) {
+        iy >>= 1;
+        ix >>= 1;
+      }
+      a_tap[i] = ok ? p.A + a_img[i] + ((long)iy * p.Wd + ix) * p.lda + g * 8 : nullptr;
+    }
+  };
+  auto seek = [&](int kt) {   // (tap, channel block) of K tile kt: once per block and once per wrap-around
+    const int k0 = kt * BK;
+    const int tap = k0 / p.Cin;
+    ci0 = k0 - tap * p.Cin;
+    tap_ky = tap / p.ksize;
+    tap_kx = tap - tap_ky * p.ksize;
+    set_tap();
+  };
+  if constexpr (CONV) seek(kt_issue);
 
   u32x4_t areg[NBUF][WMB][2];
   auto issue = [&](int slot) __attribute__((always_inline)) {   // slot: compile-time constant after unrolling
     const int k0 = kt_issue * BK;
     const long kw = kt_issue * p.w_kstep;
-    const bool first = k0 < p.k_split;   // wave-uniform: which source this K tile comes from
-    const int ka = first ? k0 : k0 - p.k_split;
+    if constexpr (CONV) {
 #pragma unroll
-    for (int i = 0; i < WMB; ++i) {
-      const half_t* src = (first ? a_ptr[i] : a2_ptr[i]) + ka * a_adv[i];
-      areg[slot][i][0] = gld16_uncounted(src);
-      areg[slot][i][1] = gld16_uncounted(src + 32);
+      for (int i = 0; i < WMB; ++i) {
+        const half_t* src = a_tap[i] ? a_tap[i] + ci0 : g_zero_page + g * 8;
+        areg[slot][i][0] = gld16_uncounted(src);
+        areg[slot][i][1] = gld16_uncounted(src + 32);
+      }
+    } else {
+      const bool first = k0 < p.k_split;   // wave-uniform: which source this K tile comes from
+      const int ka = first ? k0 : k0 - p.k_split;
+#pragma unroll
+      for (int i = 0; i < WMB; ++i) {
+        const half_t* src = (first ? a_ptr[i] : a2_ptr[i]) + ka * a_adv[i];
+        areg[slot][i][0] = gld16_uncounted(src);
+        areg[slot][i][1] = gld16_uncounted(src + 32);
+      }
     }
     char* Bs = smem + slot * STAGE;
 #pragma unroll
@@ -968,7 +1023,20 @@ __global__ __launch_bounds__(WAVES_M * 128) void gemm160ar_kernel(const G160Para
       if (q < B_INSTR) glds16(b_ptr[j] + kw, Bs + q * 1024);
       else if (B_DUP) glds16(b_ptr[j] + kw, Bs + (q - NW) * 1024);
     }
-    if (++kt_issue == kt_end) kt_issue = kt_begin;   // wrap-around of the rotated walk (wave-uniform)
+    if (++kt_issue == kt_end) {   // wrap-around of the rotated walk (wave-uniform)
+      kt_issue = kt_begin;
+      if constexpr (CONV) seek(kt_begin);
+    } else if constexpr (CONV) {
+      ci0 += BK;
+      if (ci0 >= p.Cin) {  // next tap (wave-uniform)
+        ci0 = 0;
+        if (++tap_kx == p.ksize) {
+          tap_kx = 0;
+          ++tap_ky;
+        }
+        set_tap();
+      }
+    }
   };
 
   float4_t acc[WMB][NT];
@@ -990,22 +1058,24 @@ __global__ __launch_bounds__(WAVES_M * 128) void gemm160ar_kernel(const G160Para
 #pragma unroll
     for (int s = 0; s < DEPTH; ++s)
       if (s < nsteps) issue(s);
-    if (p.ln_in && tid < BM) {   // row statistics of this block's rows from the producer's partial sums
-      const int m = min(m0 + tid, p.M - 1);
-      const float2* src = p.ln_in + (long)m * p.ln_P;
-      float sum = 0.f, sq = 0.f;
+    if constexpr (!CONV) {
+      if (p.ln_in && tid < BM) {   // row statistics of this block's rows from the producer's partial sums
+        const int m = min(m0 + tid, p.M - 1);
+        const float2* src = p.ln_in + (long)m * p.ln_P;
+        float sum = 0.f, sq = 0.f;
 #pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const float2 v = src[min(j, p.ln_P - 1)];
-        const float w = j < p.ln_P ? 1.f : 0.f;
-        sum = fmaf(v.x, w, sum);
-        sq = fmaf(v.y, w, sq);
+        for (int j = 0; j < 8; ++j) {
+          const float2 v = src[min(j, p.ln_P - 1)];
+          const float w = j < p.ln_P ? 1.f : 0.f;
+          sum = fmaf(v.x, w, sum);
+          sq = fmaf(v.y, w, sq);
+        }
+        const float inv_k = 1.0f / (float)p.K;
+        const float mean = sum * inv_k;
+        const float var = fmaxf(fmaf(-mean, mean, sq * inv_k), 0.f);
+        const float rstd = rsqrtf(var + p.ln_eps);
+        lnstat[tid] = make_float2(rstd, -rstd * mean);
       }
-      const float inv_k = 1.0f / (float)p.K;
-      const float mean = sum * inv_k;
-      const float var = fmaxf(fmaf(-mean, mean, sq * inv_k), 0.f);
-      const float rstd = rsqrtf(var + p.ln_eps);
-      lnstat[tid] = make_float2(rstd, -rstd * mean);
     }
     for (int st0 = 0; st0 < nsteps; st0 += NBUF) {
 #pragma unroll
@@ -1046,8 +1116,8 @@ __global__ __launch_bounds__(WAVES_M * 128) void gemm160ar_kernel(const G160Para
     __syncthreads();  // the epilogue reuses the ring as staging space
   }
 
-  epilogue160<WMB, NT, WAVES_M * 128, true>(acc, p, lane, m0, n0, wm, wn, split, smem, tid, p.ln_in ? lnstat : nullptr,
-                                            tile_m * (BM / GN_SLAB));
+  epilogue160<WMB, NT, WAVES_M * 128, !CONV>(acc, p, lane, m0, n0, wm, wn, split, smem, tid,
+                                             (!CONV && p.ln_in) ? lnstat : nullptr, tile_m * (BM / GN_SLAB));
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -2329,13 +2399,15 @@ int launch160ar(G160Params& p, int bucket, hipStream_t s) {
   p.tiles_m = (p.M + BM - 1) / BM;
   p.tiles_n = p.N / 160;
   p.nmajor = pick_nmajor(p);
-  p.krot = krot_mode() >= 1;
+  p.krot = krot_mode() == 2 || (krot_mode() == 1 && p.ksize == 0);   // as launch160: same K walk, same bits
   const int nk = p.K / BK;
   p.kt_per_split = (nk + p.splits - 1) / p.splits;
   p.splits = (nk + p.kt_per_split - 1) / p.kt_per_split;
   dim3 grid(p.tiles_m * p.tiles_n, 1, p.splits);
-  PfdProfScope prof_scope(bucket, 2.0 * p.M * p.N * p.K, 2.0 * p.M * p.K + 2.0 * p.N * p.K + 2.0 * p.M * p.N * (p.R ? 2 : 1), s);
-  hipLaunchKernelGGL((gemm160ar_kernel<WAVES_M, WMB, NBUF>), grid, dim3(WAVES_M * 128), 0, s, p);
+  const double a_bytes = p.ksize > 0 ? 2.0 * p.B * p.H * p.Wd * p.Cin : 2.0 * p.M * p.K;
+  PfdProfScope prof_scope(bucket, 2.0 * p.M * p.N * p.K, a_bytes + 2.0 * p.N * p.K + 2.0 * p.M * p.N * (p.R ? 2 : 1), s);
+  if (p.ksize > 0) hipLaunchKernelGGL((gemm160ar_kernel<WAVES_M, WMB, NBUF, true>), grid, dim3(WAVES_M * 128), 0, s, p);
+  else hipLaunchKernelGGL((gemm160ar_kernel<WAVES_M, WMB, NBUF, false>), grid, dim3(WAVES_M * 128), 0, s, p);
   if (p.splits > 1) launch_splitk_reduce(p, s);
   return pfd_check_launch("pfd_gemm_f16(wide, A in registers)");
 }
@@ -2601,7 +2673,7 @@ int pfd_gemm160_try(const PfdGemmDesc* d, int variant, int splits, hipStream_t s
     if (variant == 82 && (p.ksize == 0 || (p.stride == 1 && !p.ups)) && tiles(128) <= 256 && nk_split >= 6) variant = 83;
   }
   const int conv = p.ksize > 0 ? 1 : 0;
-  if ((variant == 27 || variant == 45 || variant == 85) && (bn != 160 || conv)) return 1;   // 160-wide linear tiles only
+  if ((variant == 27 || variant == 45 || variant == 85) && bn != 160) return 1;   // 160-wide tiles only
   if (variant == 48 || variant == 49 || variant == 47) {   // 8 MFMA waves + 4 loader waves (49: ping-pong consumer groups, 47: 3-stage ring)
     const int mode = variant == 49 ? 1 : variant == 47 ? 2 : 0;
     if (bn == 128) return launch160ws<4>(p, 12 + 4 * conv, s, mode) < 0 ? PFD_ELAUNCH : 0;
@@ -2632,11 +2704,11 @@ int pfd_gemm160_try(const PfdGemmDesc* d, int variant, int splits, hipStream_t s
     case 26: return launch160<2, 2, 5>(p, 14 + 4 * conv, s) < 0 ? PFD_ELAUNCH : 0;
     case 46: return launch160<4, 1, 5>(p, 14 + 4 * conv, s) < 0 ? PFD_ELAUNCH : 0;
     // round-5 candidates, forced only: activation fragments global -> VGPR, weights alone on a 7-stage LDS ring = 6 K tiles
-    // in flight (gemm160ar_kernel).  Linear layers only (a launch they do not serve falls back to the automatic choice);
-    // 27 = 64 x 160 on 4 waves, 45 = 64 x 160 on 8 waves, 85 = 128 x 160 on 8 waves
-    case 27: return (conv || p.act == PFD_ACT_GEGLU) ? 1 : launch160ar<2, 2, 7>(p, 14, s) < 0 ? PFD_ELAUNCH : 0;
-    case 45: return (conv || p.act == PFD_ACT_GEGLU) ? 1 : launch160ar<4, 1, 7>(p, 14, s) < 0 ? PFD_ELAUNCH : 0;
-    case 85: return (conv || p.act == PFD_ACT_GEGLU) ? 1 : launch160ar<4, 2, 7>(p, 13, s) < 0 ? PFD_ELAUNCH : 0;
+    // in flight (gemm160ar_kernel).  Linears and implicit-GEMM convolutions, no GEGLU (a launch they do not serve falls back
+    // to the automatic choice); 27 = 64 x 160 on 4 waves, 45 = 64 x 160 on 8 waves, 85 = 128 x 160 on 8 waves
+    case 27: return p.act == PFD_ACT_GEGLU ? 1 : launch160ar<2, 2, 7>(p, 14 + 4 * conv, s) < 0 ? PFD_ELAUNCH : 0;
+    case 45: return p.act == PFD_ACT_GEGLU ? 1 : launch160ar<4, 1, 7>(p, 14 + 4 * conv, s) < 0 ? PFD_ELAUNCH : 0;
+    case 85: return p.act == PFD_ACT_GEGLU ? 1 : launch160ar<4, 2, 7>(p, 13 + 4 * conv, s) < 0 ? PFD_ELAUNCH : 0;
     // round 3 experiments: the same tiles on 8 waves (4 x 2 wave layout, wave tile 16 x 80 / 32 x 80): twice the waves
     // issuing LDS-DMA pieces per CU and two waves per SIMD on the problems whose one 4-wave block per CU is bound by the
     // piece issue rate (64-row tiles: 41 two stages, 43 four-stage ring; 128-row tiles: 82 two stages, 83 three)

@@ -1515,6 +1515,14 @@ int main(int argc, char** argv) {
       { GemmCase c{768, 320, 512, 0, true, true, true, false, v}; c.gn_out = 1; run_gemm_case(c); }
       { GemmCase c{520, 480, 128, 0, false, false, false, false, v}; c.n_split = 320; run_gemm_case(c); }  // transposed tail
       { GemmCase c{1100, 320, 1024, 0, true, true, false, false, v}; c.w_tiled = 1; run_gemm_case(c); }     // K-tile-contiguous weights
+      // implicit-GEMM convolutions (im2col gather into the registers, padding from the zero page)
+      run_gemm_case({0, 320, 0, 0, true, true, true, false, v, 0, 3, 1, 1, 0, 2, 16, 16, 128});               // 3x3 s1, 18 steps
+      run_gemm_case({0, 160, 0, 0, true, false, false, false, v, 0, 3, 2, 1, 0, 2, 16, 16, 128});             // stride 2
+      run_gemm_case({0, 320, 0, 0, true, false, false, false, v, 0, 3, 1, 1, 1, 1, 8, 8, 192});               // fused nearest-2x upsample
+      run_gemm_case({0, 160, 0, 0, true, false, false, false, v, 0, 3, 1, 1, 0, 1, 16, 16, 64});              // one K tile per tap, 9 steps
+      run_gemm_case({0, 1280, 0, 0, true, true, true, false, v + 4, 0, 3, 1, 1, 0, 8, 8, 8, 1280});           // the 8^2 conv class, split-K 4
+      run_gemm_case({0, 160, 0, 0, true, true, false, false, v, 0, 1, 1, 0, 0, 3, 12, 12, 192});              // 1x1 as a convolution, ragged M (432 rows)
+      { GemmCase c{0, 320, 0, 0, true, false, false, false, v, 0, 3, 2, 1, 0, 2, 32, 32, 128}; c.gn_out = 1; run_gemm_case(c); }   // stride 2 + statistics
     }
     run_ln_fold_case(200, 1280, 1280, PFD_ACT_GELU, 5300, 3700, 0);   // LayerNorm fold through the new kernels (consumer side)
     run_ln_fold_case(520, 640, 640, 0, 9200, 9500, 0);
@@ -1529,6 +1537,9 @@ int main(int argc, char** argv) {
       run_lin_same_case(512, 1280, 2560, ta, tb, false, 1280);          // skip GEMM over [h | skip]
       run_lin_same_case(2048, 1280, 1280, ta, tb, true, 0, 1024);       // zero-context out-projection
       run_lin_same_case(512, 1280, 1280, ta + 2, tb + 2, true);         // split-K 2
+      run_conv_same_case(8, 8, 8, 1280, 1280, ta + 4, tb + 4, true);    // the 8^2 ResBlock conv, split-K 4
+      run_conv_same_case(8, 8, 8, 2560, 1280, ta + 8, tb + 8, false);   // ... over the skip concat, split-K 8
+      run_conv_same_case(2, 16, 16, 320, 320, ta, tb, true);
     }
     printf("%d checks, %d failed\n", g_total, g_fail);
     return g_fail;
