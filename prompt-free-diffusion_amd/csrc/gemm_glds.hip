@@ -2353,6 +2353,13 @@ inline bool ws_ring_on() {
   return on;
 }
 
+// PFD_AREG=1: the automatic choice takes the register-operand ring kernels (variants 27 / 45 / 85) wherever it picked the
+// LDS-ring ones (23 / 43 / 83).  Default off: the kernels have not run on hardware yet (round-5 candidates)
+inline bool areg_on() {
+  static const bool on = getenv("PFD_AREG") && atoi(getenv("PFD_AREG")) == 1;
+  return on;
+}
+
 // PFD_R3TILES=0 keeps the round-2 tile choice (A/B runs of the round-3 rules in pfd_gemm160_try)
 inline bool r3tiles_on() {
   static const bool on = !(getenv("PFD_R3TILES") && atoi(getenv("PFD_R3TILES")) == 0);
@@ -2673,6 +2680,10 @@ int pfd_gemm160_try(const PfdGemmDesc* d, int variant, int splits, hipStream_t s
     if (variant == 82 && (p.ksize == 0 || (p.stride == 1 && !p.ups)) && tiles(128) <= 256 && nk_split >= 6) variant = 83;
   }
   const int conv = p.ksize > 0 ? 1 : 0;
+  // PFD_AREG=1 (default off; round-5 end-to-end A/B): the ring kernels the rules above picked are replaced by their
+  // register-operand forms -- same tiles, same split counts, same bits (selftest --r5)
+  if (auto_variant && bn == 160 && areg_on() && p.act != PFD_ACT_GEGLU)
+    variant = variant == 23 ? 27 : variant == 43 ? 45 : variant == 83 ? 85 : variant;
   if ((variant == 27 || variant == 45 || variant == 85) && bn != 160) return 1;   // 160-wide tiles only
   if (variant == 48 || variant == 49 || variant == 47) {   // 8 MFMA waves + 4 loader waves (49: ping-pong consumer groups, 47: 3-stage ring)
     const int mode = variant == 49 ? 1 : variant == 47 ? 2 : 0;

@@ -1,0 +1,35 @@
+#!/bin/bash
+# Second GPU call of the next round (prepared at the end of round 4, never run) -- ONLY after tools/r05_first_call.sh showed
+# `selftest --r5` green: end-to-end A/B of the candidates that have an environment switch, alternating on ONE box
+# (boxes differ by +-8 %), then the parity suites under the winning switches.
+#   PFD_AREG=1   ring kernels with the activation fragments in registers (variants 27 / 45 / 85 for 23 / 43 / 83)
+#   PFD_ATTN=7   d = 40 attention with s_setprio around the MFMA clusters
+#   usage (on the GPU box): bash tools/r05_second_call.sh   -> gpurun_out/r05_e2e/
+set -u
+O=gpurun_out/r05_e2e; mkdir -p $O
+B="--steps 6 --warmup 2 --no-cpu-baseline --no-prof"
+T0=$(date +%s)
+run() {   # run <tag> <env assignments...>
+  local tag=$1; shift
+  env "$@" timeout 150 python bench.py $B > $O/$tag.json 2> $O/$tag.err
+  echo "$tag done after $(( $(date +%s) - T0 )) s"
+}
+for rep in 1 2; do
+  run base_$rep PFD_AREG=0
+  run areg_$rep PFD_AREG=1
+  run attn7_$rep PFD_ATTN=7
+  run both_$rep PFD_AREG=1 PFD_ATTN=7
+done
+for f in base_1 areg_1 attn7_1 both_1 base_2 areg_2 attn7_2 both_2; do python - <<P
+import json
+try:
+    d = json.load(open("$O/$f.json")); print("%-8s %7.1f ms per batch  %.3f images/s  loop %s" % ("$f", d["ms_per_step"], d["value"], d.get("stage_ms_per_batch", {}).get("ddim_loop_ms")))
+except Exception as e:
+    print("$f", "no result:", e)
+P
+done
+# parity under the switches (kernel-level suite + the C2 trajectory on the fixture-backed oracle)
+PFD_AREG=1 PFD_ATTN=7 timeout 400 python -m pytest tests/test_hip_parity.py tests/test_hip_kernels_fullsize.py -m gpu -q -x > $O/pytest_switches.log 2>&1
+echo "pytest (PFD_AREG=1 PFD_ATTN=7) rc=$? after $(( $(date +%s) - T0 )) s"; tail -3 $O/pytest_switches.log
+PFD_AREG=1 PFD_ATTN=7 timeout 200 python -m pytest tests/test_hip_trajectory.py -m gpu -q -s -x -k c2 > $O/pytest_trajectory_switches.log 2>&1
+echo "pytest trajectory rc=$? after $(( $(date +%s) - T0 )) s"; tail -3 $O/pytest_trajectory_switches.log
