@@ -202,6 +202,10 @@ struct GnPStats {
   int cpp1, cpp2;    // channels per producer group (C_src / 32)
 };
 
+// PAR (round-5 candidate, PFD_GN_PAR=1, never the default and not yet run on hardware): the fold of the partials issues the
+// loads of eight slabs before the first add instead of one dependent load per slab (64^2: 8 L2 round trips per block in
+// front of the first row); same values added in the same order -- `selftest --gn-par` compares the two forms bit for bit.
+template <bool PAR>
 __global__ __launch_bounds__(256) void gn_apply_pstats_kernel(GnSrc s, GnPStats ps, const half_t* __restrict__ gamma,
                                                               const half_t* __restrict__ beta, half_t* __restrict__ y,
                                                               long ldy, int HW, int G, int rows_per_chunk, int act,
@@ -224,13 +228,37 @@ __global__ __launch_bounds__(256) void gn_apply_pstats_kernel(GnSrc s, GnPStats 
       const int tn = first ? ps.tn1 : ps.tn2, cpp = first ? ps.cpp1 : ps.cpp2;
       const int cl = first ? c0 : c0 - s.C1;
       const int npg = cpg / cpp;                       // producer groups per group of this norm
-      for (int k = part; k < nslab; k += P) {
-        const float2* row = st + ((long)(b * nslab + k) * tn) * 16;
-        for (int j = 0; j < npg; ++j) {
-          const int c = cl + j * cpp;
-          const float2 v = row[(c / 160) * 16 + (c % 160) / cpp];
-          a += v.x;
-          q += v.y;
+      if constexpr (PAR) {                             // host: npg <= 2 for both sources
+        const int c1 = cl + (npg > 1 ? cpp : 0);
+        const int col0 = (cl / 160) * 16 + (cl % 160) / cpp, col1 = (c1 / 160) * 16 + (c1 % 160) / cpp;
+        const float w1 = npg > 1 ? 1.f : 0.f;
+        for (int k0 = part; k0 < nslab; k0 += 8 * P) {
+          float2 v0[8], v1[8];
+#pragma unroll
+          for (int u = 0; u < 8; ++u) {
+            const int k = min(k0 + u * P, nslab - 1);
+            const float2* row = st + ((long)(b * nslab + k) * tn) * 16;
+            v0[u] = row[col0];
+            v1[u] = row[col1];
+          }
+#pragma unroll
+          for (int u = 0; u < 8; ++u) {                // slab outer, producer group inner: the order of the plain loop
+            const float w = k0 + u * P < nslab ? 1.f : 0.f;
+            a += v0[u].x * w;
+            q += v0[u].y * w;
+            a += v1[u].x * (w * w1);
+            q += v1[u].y * (w * w1);
+          }
+        }
+      } else {
+        for (int k = part; k < nslab; k += P) {
+          const float2* row = st + ((long)(b * nslab + k) * tn) * 16;
+          for (int j = 0; j < npg; ++j) {
+            const int c = cl + j * cpp;
+            const float2 v = row[(c / 160) * 16 + (c % 160) / cpp];
+            a += v.x;
+            q += v.y;
+          }
         }
       }
     }
@@ -733,8 +761,16 @@ extern "C" int pfd_groupnorm_pstats_f16(const void* x1, int32_t C1, int64_t ldx1
   int nchunks, rpc;
   gn_chunks(B, C, HW, &nchunks, &rpc);
   PfdProfScope prof_scope(10, 8.0 * B * HW * C, 4.0 * B * HW * C, s);   // 2 B read + 2 B write
-  hipLaunchKernelGGL(gn_apply_pstats_kernel, dim3(nchunks, B), dim3(256), 0, s, src, ps, (const half_t*)gamma,
-                     (const half_t*)beta, (half_t*)y, (long)ldy, HW, G, rpc, act, (float)HW * (float)(C / G), eps);
+  const char* par_s = getenv("PFD_GN_PAR");   // read per launch (selftest flips it between two launches)
+  const bool par_env = par_s && atoi(par_s) == 1;
+  const int cpg = C / G;
+  const bool par = par_env && cpg / ps.cpp1 <= 2 && cpg / ps.cpp2 <= 2;   // round-5 candidate, default off
+  if (par)
+    hipLaunchKernelGGL(gn_apply_pstats_kernel<true>, dim3(nchunks, B), dim3(256), 0, s, src, ps, (const half_t*)gamma,
+                       (const half_t*)beta, (half_t*)y, (long)ldy, HW, G, rpc, act, (float)HW * (float)(C / G), eps);
+  else
+    hipLaunchKernelGGL(gn_apply_pstats_kernel<false>, dim3(nchunks, B), dim3(256), 0, s, src, ps, (const half_t*)gamma,
+                       (const half_t*)beta, (half_t*)y, (long)ldy, HW, G, rpc, act, (float)HW * (float)(C / G), eps);
   return pfd_check_launch("pfd_groupnorm_pstats_f16");
 }
 

@@ -683,7 +683,7 @@ static void run_gn_case(int B, int HW, int C1, int C2, int G, int act, float eps
 // conv's GroupNorm prologue.  Same statistics code, same fp32 affine map, same kernel behind it: the outputs must be
 // identical, not merely close.
 // pfd_groupnorm_pstats_f16: statistics handed over in the producers' layout (host-computed here) vs a plain fp64 GroupNorm
-static void run_gn_pstats_case(int B, int HW, int C1, int C2, int act, float eps) {
+static void run_gn_pstats_case(int B, int HW, int C1, int C2, int act, float eps, bool par_same = false) {
   const int C = C1 + C2, G = 32, cpg = C / G;
   auto x1 = rand_h((size_t)B * HW * C1), x2 = rand_h((size_t)B * HW * std::max(C2, 8)), gm = rand_h(C), bt = rand_h(C);
   for (auto& v : x1) v = (h16)((float)v * 1.5f + 0.3f);
@@ -723,6 +723,23 @@ static void run_gn_pstats_case(int B, int HW, int C1, int C2, int act, float eps
           ref[((size_t)b * HW + r) * C + c] = act_ref((at(b, r, c) - mean) * rstd * (double)gm[c] + (double)bt[c], act);
     }
   report(name, got, ref, 6e-3, 4e-3);
+  if (par_same) {   // PFD_GN_PAR=1 (partials of eight slabs requested before the first add): the same bits
+    Dev<h16> dy2((size_t)B * HW * C);
+    setenv("PFD_GN_PAR", "1", 1);
+    const int rc2 = pfd_groupnorm_pstats_f16(d1.p, C1, C1, ds1.p, C2 ? d2.p : nullptr, C2, C2, C2 ? ds2.p : nullptr, dg.p, db.p, dy2.p, C,
+                                             B, HW, G, eps, act, nullptr);
+    unsetenv("PFD_GN_PAR");
+    ++g_total;
+    auto got2 = dy2.get();
+    if (rc2 != 0 || memcmp(got.data(), got2.data(), got.size() * sizeof(h16))) {
+      size_t nd = 0;
+      for (size_t i = 0; i < got.size(); ++i) nd += memcmp(&got[i], &got2[i], sizeof(h16)) != 0;
+      ++g_fail;
+      printf("FAIL %-58s PFD_GN_PAR=1 rc=%d: %zu of %zu elements differ\n", name, rc2, nd, got.size());
+    } else {
+      printf("ok   %-58s PFD_GN_PAR=1 == plain (bitwise)\n", name);
+    }
+  }
 }
 
 static void run_gn_conv_case(int B, int H, int W, int C1, int C2, int N, int act, bool with_res) {
@@ -1541,6 +1558,13 @@ int main(int argc, char** argv) {
       run_conv_same_case(8, 8, 8, 2560, 1280, ta + 8, tb + 8, false);   // ... over the skip concat, split-K 8
       run_conv_same_case(2, 16, 16, 320, 320, ta, tb, true);
     }
+    // PFD_GN_PAR=1: GroupNorm apply from producer statistics with the partial loads of eight slabs in flight together
+    run_gn_pstats_case(8, 4096, 320, 0, PFD_ACT_SILU, 1e-5f, true);      // 64^2: 64 slabs per sample, 8 per thread
+    run_gn_pstats_case(8, 4096, 320, 320, PFD_ACT_SILU, 1e-5f, true);    // skip concat: two producer groups per group
+    run_gn_pstats_case(3, 1024, 640, 0, PFD_ACT_NONE, 1e-6f, true);      // 16 slabs: two per thread, six clamped slots
+    run_gn_pstats_case(2, 1024, 640, 640, PFD_ACT_SILU, 1e-5f, true);    // 32^2 skip concat
+    run_gn_pstats_case(2, 256, 1280, 1280, PFD_ACT_SILU, 1e-5f, true);   // 16^2 skip concat: 4 slabs, P = 8 parts
+    run_gn_pstats_case(2, 4608, 320, 0, PFD_ACT_SILU, 1e-5f, true);      // 72 slabs: a second trip of the chunked loop
     printf("%d checks, %d failed\n", g_total, g_fail);
     return g_fail;
   }
