@@ -645,7 +645,7 @@ static void run_swin_case(int B, int H, int W, int nH, int shift) {
 }
 
 // ------------------------------------------------------------------ norms
-static void run_gn_case(int B, int HW, int C1, int C2, int G, int act, float eps) {
+static void run_gn_case(int B, int HW, int C1, int C2, int G, int act, float eps, const char* same_env = nullptr) {
   const int C = C1 + C2;
   auto x1 = rand_h((size_t)B * HW * C1, 2.f), x2 = rand_h((size_t)B * HW * std::max(C2, 8), 1.f);
   for (auto& v : x1) v = (h16)((float)v + 0.7f);
@@ -677,6 +677,23 @@ static void run_gn_case(int B, int HW, int C1, int C2, int G, int act, float eps
         }
     }
   report(name, got, ref, 4e-3, 3e-3);
+  if (same_env) {   // the same launch with a round-5 switch set: the same bits
+    Dev<h16> dy2((size_t)B * HW * C);
+    setenv(same_env, "1", 1);
+    const int rc2 = pfd_groupnorm_f16(d1.p, C1, C1, C2 ? d2.p : nullptr, C2, C2, dg.p, db.p, dy2.p, C, B, HW, G, eps, act,
+                                      dws.p, wsb, nullptr);
+    unsetenv(same_env);
+    ++g_total;
+    auto got2 = dy2.get();
+    if (rc2 != 0 || memcmp(got.data(), got2.data(), got.size() * sizeof(h16))) {
+      size_t nd = 0;
+      for (size_t i = 0; i < got.size(); ++i) nd += memcmp(&got[i], &got2[i], sizeof(h16)) != 0;
+      ++g_fail;
+      printf("FAIL %-58s %s=1 rc=%d: %zu of %zu elements differ\n", name, same_env, rc2, nd, got.size());
+    } else {
+      printf("ok   %-58s %s=1 == plain (bitwise)\n", name, same_env);
+    }
+  }
 }
 
 // conv3x3(act(GroupNorm([x1 | x2]))) two ways: pfd_groupnorm_f16 + plain patch conv vs pfd_groupnorm_table_f16 + the
@@ -1558,6 +1575,15 @@ int main(int argc, char** argv) {
       run_conv_same_case(8, 8, 8, 2560, 1280, ta + 8, tb + 8, false);   // ... over the skip concat, split-K 8
       run_conv_same_case(2, 16, 16, 320, 320, ta, tb, true);
     }
+    // PFD_GN_SMALL_FAST=1: the single-launch small-slab GroupNorm without per-chunk divisions / gamma-beta round trips
+    run_gn_case(8, 64, 1280, 0, 32, PFD_ACT_SILU, 1e-5f, "PFD_GN_SMALL_FAST");       // 8^2: 640 chunks, 3 slots per thread
+    run_gn_case(8, 256, 1280, 0, 32, PFD_ACT_SILU, 1e-5f, "PFD_GN_SMALL_FAST");      // 16^2: 2560 chunks
+    run_gn_case(8, 256, 1280, 1280, 32, PFD_ACT_SILU, 1e-5f, "PFD_GN_SMALL_FAST");   // skip concat, cpg 80: 5120 chunks
+    run_gn_case(8, 64, 1280, 1280, 32, PFD_ACT_NONE, 1e-6f, "PFD_GN_SMALL_FAST");
+    run_gn_case(8, 256, 1280, 640, 32, PFD_ACT_SILU, 1e-5f, "PFD_GN_SMALL_FAST");    // cpg 60 straddles the sources: plain both times
+    run_gn_case(4, 64, 1024, 0, 32, PFD_ACT_SILU, 1e-5f, "PFD_GN_SMALL_FAST");       // cpg 32, cpr 8 (256 % cpr == 0: no carries)
+    run_gn_case(16, 100, 1440, 0, 32, PFD_ACT_NONE, 1e-5f, "PFD_GN_SMALL_FAST");     // cpg 45 is not a multiple of 4: two-launch form both times
+    run_gn_case(8, 100, 1408, 0, 32, PFD_ACT_SILU, 1e-5f, "PFD_GN_SMALL_FAST");      // cpg 44, cpr 11, ragged HW
     // PFD_GN_PAR=1: GroupNorm apply from producer statistics with the partial loads of eight slabs in flight together
     run_gn_pstats_case(8, 4096, 320, 0, PFD_ACT_SILU, 1e-5f, true);      // 64^2: 64 slabs per sample, 8 per thread
     run_gn_pstats_case(8, 4096, 320, 320, PFD_ACT_SILU, 1e-5f, true);    // skip concat: two producer groups per group

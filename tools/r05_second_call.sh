@@ -5,6 +5,7 @@
 #   PFD_AREG=1   ring kernels with the activation fragments in registers (variants 27 / 45 / 85 for 23 / 43 / 83)
 #   PFD_ATTN=7   d = 40 attention with s_setprio around the MFMA clusters
 #   PFD_GN_PAR=1 GroupNorm apply from producer statistics: the partials of eight slabs requested before the first add
+#   PFD_GN_SMALL_FAST=1  single-launch GroupNorm of the 8^2 / 16^2 levels without per-chunk divisions / gamma-beta round trips
 #   usage (on the GPU box): bash tools/r05_second_call.sh   -> gpurun_out/r05_e2e/
 set -u
 O=gpurun_out/r05_e2e; mkdir -p $O
@@ -19,10 +20,10 @@ for rep in 1 2; do
   run base_$rep PFD_AREG=0
   run areg_$rep PFD_AREG=1
   run attn7_$rep PFD_ATTN=7
-  run gnpar_$rep PFD_GN_PAR=1
-  run all_$rep PFD_AREG=1 PFD_ATTN=7 PFD_GN_PAR=1
+  run gn_$rep PFD_GN_PAR=1 PFD_GN_SMALL_FAST=1
+  run all_$rep PFD_AREG=1 PFD_ATTN=7 PFD_GN_PAR=1 PFD_GN_SMALL_FAST=1
 done
-for f in base_1 areg_1 attn7_1 gnpar_1 all_1 base_2 areg_2 attn7_2 gnpar_2 all_2; do python - <<P
+for f in base_1 areg_1 attn7_1 gn_1 all_1 base_2 areg_2 attn7_2 gn_2 all_2; do python - <<P
 import json
 try:
     d = json.load(open("$O/$f.json")); print("%-8s %7.1f ms per batch  %.3f images/s  loop %s" % ("$f", d["ms_per_step"], d["value"], d.get("stage_ms_per_batch", {}).get("ddim_loop_ms")))
@@ -31,7 +32,7 @@ except Exception as e:
 P
 done
 # parity under the switches (kernel-level suite + the C2 trajectory on the fixture-backed oracle)
-PFD_AREG=1 PFD_ATTN=7 PFD_GN_PAR=1 timeout 400 python -m pytest tests/test_hip_parity.py tests/test_hip_kernels_fullsize.py -m gpu -q -x > $O/pytest_switches.log 2>&1
-echo "pytest (PFD_AREG=1 PFD_ATTN=7 PFD_GN_PAR=1) rc=$? after $(( $(date +%s) - T0 )) s"; tail -3 $O/pytest_switches.log
-PFD_AREG=1 PFD_ATTN=7 PFD_GN_PAR=1 timeout 200 python -m pytest tests/test_hip_trajectory.py -m gpu -q -s -x -k c2 > $O/pytest_trajectory_switches.log 2>&1
+PFD_AREG=1 PFD_ATTN=7 PFD_GN_PAR=1 PFD_GN_SMALL_FAST=1 timeout 400 python -m pytest tests/test_hip_parity.py tests/test_hip_kernels_fullsize.py -m gpu -q -x > $O/pytest_switches.log 2>&1
+echo "pytest (all four switches) rc=$? after $(( $(date +%s) - T0 )) s"; tail -3 $O/pytest_switches.log
+PFD_AREG=1 PFD_ATTN=7 PFD_GN_PAR=1 PFD_GN_SMALL_FAST=1 timeout 200 python -m pytest tests/test_hip_trajectory.py -m gpu -q -s -x -k c2 > $O/pytest_trajectory_switches.log 2>&1
 echo "pytest trajectory rc=$? after $(( $(date +%s) - T0 )) s"; tail -3 $O/pytest_trajectory_switches.log
