@@ -204,7 +204,9 @@ struct GnPStats {
 
 // PAR (round-5 candidate, PFD_GN_PAR=1, never the default and not yet run on hardware): the fold of the partials issues the
 // loads of eight slabs before the first add instead of one dependent load per slab (64^2: 8 L2 round trips per block in
-// front of the first row); same values added in the same order -- `selftest --gn-par` compares the two forms bit for bit.
+// front of the first row), and the apply loop requests eight rows per round trip instead of four (a block's 64 rows at
+// 64^2 x 320: two trips instead of three); same values added in the same order -- `selftest --r5` compares the two
+// forms bit for bit.
 template <bool PAR>
 __global__ __launch_bounds__(256) void gn_apply_pstats_kernel(GnSrc s, GnPStats ps, const half_t* __restrict__ gamma,
                                                               const half_t* __restrict__ beta, half_t* __restrict__ y,
@@ -296,13 +298,14 @@ __global__ __launch_bounds__(256) void gn_apply_pstats_kernel(GnSrc s, GnPStats 
       w[e] = sc[v * 8 + e];
       o[e] = sh[v * 8 + e];
     }
-    for (int r = r_beg + rt; r < r_end; r += 4 * RT) {
-      Pack16 p[4];
+    constexpr int U = PAR ? 8 : 4;   // rows requested per round trip
+    for (int r = r_beg + rt; r < r_end; r += U * RT) {
+      Pack16 p[U];
 #pragma unroll
-      for (int u = 0; u < 4; ++u)
+      for (int u = 0; u < U; ++u)
         if (r + u * RT < r_end) p[u].u = gn_load(s, (long)b * HW + r + u * RT, v);
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
+      for (int u = 0; u < U; ++u) {
         if (r + u * RT >= r_end) break;
         const long row = (long)b * HW + r + u * RT;
         Pack16 qv;
