@@ -884,8 +884,10 @@ __device__ __forceinline__ u32x4_t gld16_uncounted(const void* src) {
   asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(d) : "v"((const __attribute__((address_space(1))) void*)src) : "memory");
   return d;
 }
-template <int WAVES_M, int WMB, int NBUF, bool CONV = false>
-__global__ __launch_bounds__(WAVES_M * 128) void gemm160ar_kernel(const G160Params p) {
+// MINW = waves per SIMD the register allocation must leave room for: 1 for the 7-stage forms (one 140 KB block per CU), 4 for
+// the 3-stage form of the 128-row tile (variant 86: two 60 KB blocks of 8 waves per CU, as the 2-stage kernel it replaces)
+template <int WAVES_M, int WMB, int NBUF, bool CONV = false, int MINW = 1>
+__global__ __launch_bounds__(WAVES_M * 128, MINW) void gemm160ar_kernel(const G160Params p) {
   constexpr int NT = 5;
   constexpr int BN = 32 * NT;
   constexpr int NW = WAVES_M * 2;
@@ -2355,9 +2357,11 @@ inline bool ws_ring_on() {
 
 // PFD_AREG=1: the automatic choice takes the register-operand ring kernels (variants 27 / 45 / 85) wherever it picked the
 // LDS-ring ones (23 / 43 / 83).  Default off: the kernels have not run on hardware yet (round-5 candidates)
-inline bool areg_on() {
-  static const bool on = getenv("PFD_AREG") && atoi(getenv("PFD_AREG")) == 1;
-  return on;
+// PFD_AREG=2: additionally 86 (two blocks per CU, two K tiles in flight each) wherever the rules picked the 2-stage
+// 128-row tile on 8 waves (82) for a linear layer.
+inline int areg_mode() {
+  static const int m = getenv("PFD_AREG") ? atoi(getenv("PFD_AREG")) : 0;
+  return m;
 }
 
 // PFD_R3TILES=0 keeps the round-2 tile choice (A/B runs of the round-3 rules in pfd_gemm160_try)
@@ -2400,7 +2404,7 @@ int launch160(G160Params& p, int bucket, hipStream_t s) {
 }
 
 // forced variants 27 / 45 / 85 (round-5 candidates): activation fragments in registers, weights on a 7-stage LDS ring
-template <int WAVES_M, int WMB, int NBUF>
+template <int WAVES_M, int WMB, int NBUF, int MINW = 1>
 int launch160ar(G160Params& p, int bucket, hipStream_t s) {
   constexpr int BM = WAVES_M * WMB * 16;
   p.tiles_m = (p.M + BM - 1) / BM;
@@ -2413,8 +2417,10 @@ int launch160ar(G160Params& p, int bucket, hipStream_t s) {
   dim3 grid(p.tiles_m * p.tiles_n, 1, p.splits);
   const double a_bytes = p.ksize > 0 ? 2.0 * p.B * p.H * p.Wd * p.Cin : 2.0 * p.M * p.K;
   PfdProfScope prof_scope(bucket, 2.0 * p.M * p.N * p.K, a_bytes + 2.0 * p.N * p.K + 2.0 * p.M * p.N * (p.R ? 2 : 1), s);
-  if (p.ksize > 0) hipLaunchKernelGGL((gemm160ar_kernel<WAVES_M, WMB, NBUF, true>), grid, dim3(WAVES_M * 128), 0, s, p);
-  else hipLaunchKernelGGL((gemm160ar_kernel<WAVES_M, WMB, NBUF, false>), grid, dim3(WAVES_M * 128), 0, s, p);
+  if constexpr (MINW == 1) {   // (the im2col form of the 128-VGPR build spills: variant 86 serves linears only)
+    if (p.ksize > 0) hipLaunchKernelGGL((gemm160ar_kernel<WAVES_M, WMB, NBUF, true, MINW>), grid, dim3(WAVES_M * 128), 0, s, p);
+  }
+  if (p.ksize == 0) hipLaunchKernelGGL((gemm160ar_kernel<WAVES_M, WMB, NBUF, false, MINW>), grid, dim3(WAVES_M * 128), 0, s, p);
   if (p.splits > 1) launch_splitk_reduce(p, s);
   return pfd_check_launch("pfd_gemm_f16(wide, A in registers)");
 }
@@ -2647,7 +2653,7 @@ int pfd_gemm160_try(const PfdGemmDesc* d, int variant, int splits, hipStream_t s
     }
   }
   const int bm = (variant == 44 || variant == 48 || variant == 49 || variant == 47 || variant == 84) ? 256
-                 : (variant == 24 || variant == 25 || variant == 82 || variant == 83 || variant == 85) ? 128 : 64;
+                 : (variant == 24 || variant == 25 || variant == 82 || variant == 83 || variant == 85 || variant == 86) ? 128 : 64;
   if (splits == 0) {
     splits = 1;
     const long tl = tiles(bm);
@@ -2655,7 +2661,7 @@ int pfd_gemm160_try(const PfdGemmDesc* d, int variant, int splits, hipStream_t s
     if (p.act != PFD_ACT_GEGLU && d->ws && (variant == 44 || variant == 48 || variant == 49 || variant == 47) && tl < 200 && nk >= 48 &&
         (size_t)2 * p.M * p.N * 4 <= d->ws_bytes) {
       splits = 2;  // 128 tiles of 256x160: two K halves fill the chip (758 vs 579 TF at 640->640 @32^2)
-    } else if (p.act != PFD_ACT_GEGLU && d->ws && (variant == 24 || variant == 25 || variant == 82 || variant == 83 || variant == 85) && tl < 256) {
+    } else if (p.act != PFD_ACT_GEGLU && d->ws && (variant == 24 || variant == 25 || variant == 82 || variant == 83 || variant == 85 || variant == 86) && tl < 256) {
       splits = (int)((512 + tl - 1) / tl);
       if (splits > 8) splits = 8;
       while (splits > 1 && nk / splits < 16) --splits;  // the slab round trip must stay small vs the K loop
@@ -2682,9 +2688,9 @@ int pfd_gemm160_try(const PfdGemmDesc* d, int variant, int splits, hipStream_t s
   const int conv = p.ksize > 0 ? 1 : 0;
   // PFD_AREG=1 (default off; round-5 end-to-end A/B): the ring kernels the rules above picked are replaced by their
   // register-operand forms -- same tiles, same split counts, same bits (selftest --r5)
-  if (auto_variant && bn == 160 && areg_on() && p.act != PFD_ACT_GEGLU)
-    variant = variant == 23 ? 27 : variant == 43 ? 45 : variant == 83 ? 85 : variant;
-  if ((variant == 27 || variant == 45 || variant == 85) && bn != 160) return 1;   // 160-wide tiles only
+  if (auto_variant && bn == 160 && areg_mode() >= 1 && p.act != PFD_ACT_GEGLU)
+    variant = variant == 23 ? 27 : variant == 43 ? 45 : variant == 83 ? 85 : (variant == 82 && areg_mode() >= 2 && !conv) ? 86 : variant;
+  if ((variant == 27 || variant == 45 || variant == 85 || variant == 86) && bn != 160) return 1;   // 160-wide tiles only
   if (variant == 48 || variant == 49 || variant == 47) {   // 8 MFMA waves + 4 loader waves (49: ping-pong consumer groups, 47: 3-stage ring)
     const int mode = variant == 49 ? 1 : variant == 47 ? 2 : 0;
     if (bn == 128) return launch160ws<4>(p, 12 + 4 * conv, s, mode) < 0 ? PFD_ELAUNCH : 0;
@@ -2720,6 +2726,9 @@ int pfd_gemm160_try(const PfdGemmDesc* d, int variant, int splits, hipStream_t s
     case 27: return p.act == PFD_ACT_GEGLU ? 1 : launch160ar<2, 2, 7>(p, 14 + 4 * conv, s) < 0 ? PFD_ELAUNCH : 0;
     case 45: return p.act == PFD_ACT_GEGLU ? 1 : launch160ar<4, 1, 7>(p, 14 + 4 * conv, s) < 0 ? PFD_ELAUNCH : 0;
     case 85: return p.act == PFD_ACT_GEGLU ? 1 : launch160ar<4, 2, 7>(p, 13 + 4 * conv, s) < 0 ? PFD_ELAUNCH : 0;
+    // 86 = 128 x 160 on 8 waves, 3 weight stages (60 KB, <= 128 VGPRs): two blocks per CU like variant 82, each with two K
+    // tiles in flight instead of one -- for the short-K linears on >= 8192 rows (many tiles per CU)
+    case 86: return (conv || p.act == PFD_ACT_GEGLU) ? 1 : launch160ar<4, 2, 3, 4>(p, 13 + 4 * conv, s) < 0 ? PFD_ELAUNCH : 0;
     // round 3 experiments: the same tiles on 8 waves (4 x 2 wave layout, wave tile 16 x 80 / 32 x 80): twice the waves
     // issuing LDS-DMA pieces per CU and two waves per SIMD on the problems whose one 4-wave block per CU is bound by the
     // piece issue rate (64-row tiles: 41 two stages, 43 four-stage ring; 128-row tiles: 82 two stages, 83 three)

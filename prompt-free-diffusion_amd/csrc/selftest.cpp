@@ -1558,6 +1558,26 @@ int main(int argc, char** argv) {
       run_gemm_case({0, 160, 0, 0, true, true, false, false, v, 0, 1, 1, 0, 0, 3, 12, 12, 192});              // 1x1 as a convolution, ragged M (432 rows)
       { GemmCase c{0, 320, 0, 0, true, false, false, false, v, 0, 3, 2, 1, 0, 2, 32, 32, 128}; c.gn_out = 1; run_gemm_case(c); }   // stride 2 + statistics
     }
+    // forced variant 86: the 128-row tile with 3 weight stages and <= 128 VGPRs (two blocks per CU), linears only
+    {
+      const int v = 9600;
+      run_gemm_case({300, 320, 64, 0, true, true, false, false, v});
+      run_gemm_case({300, 320, 192, PFD_ACT_SILU, true, true, true, false, v});
+      run_gemm_case({300, 320, 256, 0, true, false, false, false, v});                                      // 4 steps: slot 0 again
+      run_gemm_case({1100, 320, 1024, 0, true, true, true, false, v});
+      run_gemm_case({77, 160, 960, 0, true, false, false, false, v, 8});
+      run_gemm_case({512, 1280, 1280, PFD_ACT_GELU, true, true, false, false, v + 2});
+      { GemmCase c{700, 320, 1024, 0, true, true, true, false, v}; c.k_split = 384; run_gemm_case(c); }
+      { GemmCase c{1100, 320, 512, 0, true, true, false, false, v}; c.zero_rows = 512; run_gemm_case(c); }
+      { GemmCase c{768, 320, 512, 0, true, true, true, false, v}; c.gn_out = 1; run_gemm_case(c); }
+      { GemmCase c{520, 480, 128, 0, false, false, false, false, v}; c.n_split = 320; run_gemm_case(c); }
+      run_ln_fold_case(520, 640, 640, 0, 9200, 9600, 0);
+      run_lin_same_case(32768, 960, 320, 9200, 9600, false);            // qkv 64^2
+      run_lin_same_case(8192, 1920, 640, 9200, 9600, false);            // qkv 32^2
+      run_lin_same_case(32768, 320, 1280, 9200, 9600, true);            // ff-out 64^2
+      run_lin_same_case(32768, 320, 320, 9200, 9600, true, 0, 16384);   // zero-context out-projection 64^2
+      run_lin_same_case(32768, 320, 640, 9200, 9600, false, 320);       // skip GEMM over [h | skip] 64^2
+    }
     run_ln_fold_case(200, 1280, 1280, PFD_ACT_GELU, 5300, 3700, 0);   // LayerNorm fold through the new kernels (consumer side)
     run_ln_fold_case(520, 640, 640, 0, 9200, 9500, 0);
     run_ln_fold_case(77, 960, 160, 0, 9300, 5500, 0);
