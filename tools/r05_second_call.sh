@@ -3,6 +3,7 @@
 # `selftest --r5` green: end-to-end A/B of the candidates that have an environment switch, alternating on ONE box
 # (boxes differ by +-8 %), then the parity suites under the winning switches.
 #   PFD_AREG=1   ring kernels with the activation fragments in registers (variants 27 / 45 / 85 for 23 / 43 / 83)
+#   PFD_AREG=2   ... and variant 86 for 82 (short-K linears on >= 8192 rows: two blocks per CU, two K tiles in flight each)
 #   PFD_ATTN=7   d = 40 attention with s_setprio around the MFMA clusters
 #   PFD_GN_PAR=1 GroupNorm apply from producer statistics: the partials of eight slabs requested before the first add
 #   PFD_GN_SMALL_FAST=1  single-launch GroupNorm of the 8^2 / 16^2 levels without per-chunk divisions / gamma-beta round trips
@@ -19,11 +20,12 @@ run() {   # run <tag> <env assignments...>
 for rep in 1 2; do
   run base_$rep PFD_AREG=0
   run areg_$rep PFD_AREG=1
+  run areg2_$rep PFD_AREG=2
   run attn7_$rep PFD_ATTN=7
   run gn_$rep PFD_GN_PAR=1 PFD_GN_SMALL_FAST=1
   run all_$rep PFD_AREG=1 PFD_ATTN=7 PFD_GN_PAR=1 PFD_GN_SMALL_FAST=1
 done
-for f in base_1 areg_1 attn7_1 gn_1 all_1 base_2 areg_2 attn7_2 gn_2 all_2; do python - <<P
+for f in base_1 areg_1 areg2_1 attn7_1 gn_1 all_1 base_2 areg_2 areg2_2 attn7_2 gn_2 all_2; do python - <<P
 import json
 try:
     d = json.load(open("$O/$f.json")); print("%-8s %7.1f ms per batch  %.3f images/s  loop %s" % ("$f", d["ms_per_step"], d["value"], d.get("stage_ms_per_batch", {}).get("ddim_loop_ms")))
