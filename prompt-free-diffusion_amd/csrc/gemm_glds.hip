@@ -2357,8 +2357,8 @@ inline bool ws_ring_on() {
 
 // PFD_AREG=1: the automatic choice takes the register-operand ring kernels (variants 27 / 45 / 85) wherever it picked the
 // LDS-ring ones (23 / 43 / 83).  Default off: the kernels have not run on hardware yet (round-5 candidates)
-// PFD_AREG=2: additionally 86 (two blocks per CU, two K tiles in flight each) wherever the rules picked the 2-stage
-// 128-row tile on 8 waves (82) for a linear layer.
+// PFD_AREG=2: additionally 86 / 28 (two blocks per CU, two K tiles in flight each) wherever the rules picked the 2-stage
+// 128-row tile on 8 waves (82) / the 2-stage 64-row tile on 4 waves (22) for a linear layer.
 inline int areg_mode() {
   static const int m = getenv("PFD_AREG") ? atoi(getenv("PFD_AREG")) : 0;
   return m;
@@ -2666,7 +2666,7 @@ int pfd_gemm160_try(const PfdGemmDesc* d, int variant, int splits, hipStream_t s
       if (splits > 8) splits = 8;
       while (splits > 1 && nk / splits < 16) --splits;  // the slab round trip must stay small vs the K loop
       while (splits > 1 && (size_t)splits * p.M * p.N * 4 > d->ws_bytes) --splits;
-    } else if (p.act != PFD_ACT_GEGLU && d->ws && (variant == 22 || variant == 23 || variant == 41 || variant == 43 || variant == 26 || variant == 46 || variant == 27 || variant == 45) && tl <= 128 && nk >= 16) {
+    } else if (p.act != PFD_ACT_GEGLU && d->ws && (variant == 22 || variant == 23 || variant == 41 || variant == 43 || variant == 26 || variant == 46 || variant == 27 || variant == 45 || variant == 28) && tl <= 128 && nk >= 16) {
       splits = (int)(256 / tl);   // M <= 1024 rows (8^2 level, cond-half projections): 25 -> 21 us
       if (splits > 4) splits = 4;
       while (splits > 1 && (size_t)splits * p.M * p.N * 4 > d->ws_bytes) --splits;
@@ -2689,8 +2689,9 @@ int pfd_gemm160_try(const PfdGemmDesc* d, int variant, int splits, hipStream_t s
   // PFD_AREG=1 (default off; round-5 end-to-end A/B): the ring kernels the rules above picked are replaced by their
   // register-operand forms -- same tiles, same split counts, same bits (selftest --r5)
   if (auto_variant && bn == 160 && areg_mode() >= 1 && p.act != PFD_ACT_GEGLU)
-    variant = variant == 23 ? 27 : variant == 43 ? 45 : variant == 83 ? 85 : (variant == 82 && areg_mode() >= 2 && !conv) ? 86 : variant;
-  if ((variant == 27 || variant == 45 || variant == 85 || variant == 86) && bn != 160) return 1;   // 160-wide tiles only
+    variant = variant == 23 ? 27 : variant == 43 ? 45 : variant == 83 ? 85 : (variant == 82 && areg_mode() >= 2 && !conv) ? 86
+              : (variant == 22 && areg_mode() >= 2 && !conv) ? 28 : variant;
+  if ((variant == 27 || variant == 45 || variant == 85 || variant == 86 || variant == 28) && bn != 160) return 1;   // 160-wide tiles only
   if (variant == 48 || variant == 49 || variant == 47) {   // 8 MFMA waves + 4 loader waves (49: ping-pong consumer groups, 47: 3-stage ring)
     const int mode = variant == 49 ? 1 : variant == 47 ? 2 : 0;
     if (bn == 128) return launch160ws<4>(p, 12 + 4 * conv, s, mode) < 0 ? PFD_ELAUNCH : 0;
@@ -2729,6 +2730,8 @@ int pfd_gemm160_try(const PfdGemmDesc* d, int variant, int splits, hipStream_t s
     // 86 = 128 x 160 on 8 waves, 3 weight stages (60 KB, <= 128 VGPRs): two blocks per CU like variant 82, each with two K
     // tiles in flight instead of one -- for the short-K linears on >= 8192 rows (many tiles per CU)
     case 86: return (conv || p.act == PFD_ACT_GEGLU) ? 1 : launch160ar<4, 2, 3, 4>(p, 13 + 4 * conv, s) < 0 ? PFD_ELAUNCH : 0;
+    // 28 = 64 x 160 on 4 waves, 3 weight stages (60 KB): two blocks per CU like variant 22, each with two K tiles in flight
+    case 28: return (conv || p.act == PFD_ACT_GEGLU) ? 1 : launch160ar<2, 2, 3, 2>(p, 14, s) < 0 ? PFD_ELAUNCH : 0;
     // round 3 experiments: the same tiles on 8 waves (4 x 2 wave layout, wave tile 16 x 80 / 32 x 80): twice the waves
     // issuing LDS-DMA pieces per CU and two waves per SIMD on the problems whose one 4-wave block per CU is bound by the
     // piece issue rate (64-row tiles: 41 two stages, 43 four-stage ring; 128-row tiles: 82 two stages, 83 three)

@@ -1578,6 +1578,24 @@ int main(int argc, char** argv) {
       run_lin_same_case(32768, 320, 320, 9200, 9600, true, 0, 16384);   // zero-context out-projection 64^2
       run_lin_same_case(32768, 320, 640, 9200, 9600, false, 320);       // skip GEMM over [h | skip] 64^2
     }
+    // forced variant 28: the 64-row 4-wave tile with 3 weight stages (two blocks per CU), linears only
+    {
+      const int v = 3800;
+      run_gemm_case({300, 320, 64, 0, true, true, false, false, v});
+      run_gemm_case({300, 320, 192, PFD_ACT_SILU, true, true, true, false, v});
+      run_gemm_case({300, 320, 256, 0, true, false, false, false, v});
+      run_gemm_case({1100, 320, 1024, 0, true, true, true, false, v});
+      run_gemm_case({77, 160, 960, 0, true, false, false, false, v, 8});
+      run_gemm_case({512, 1280, 1280, PFD_ACT_GELU, true, true, false, false, v + 2});
+      { GemmCase c{700, 320, 1024, 0, true, true, true, false, v}; c.k_split = 384; run_gemm_case(c); }
+      { GemmCase c{1100, 320, 512, 0, true, true, false, false, v}; c.zero_rows = 512; run_gemm_case(c); }
+      { GemmCase c{768, 320, 512, 0, true, true, true, false, v}; c.gn_out = 1; run_gemm_case(c); }
+      run_ln_fold_case(200, 1280, 1280, PFD_ACT_GELU, 5300, 3800, 0);
+      run_lin_same_case(8192, 640, 640, 3200, 3800, true);              // projections 32^2
+      run_lin_same_case(16384, 320, 320, 3200, 3800, true);
+      run_lin_same_case(4096, 640, 640, 3200, 3800, false);             // cond-half to_q 32^2
+      run_lin_same_case(8192, 640, 640, 3200, 3800, true, 0, 4096);     // zero-context out-projection 32^2
+    }
     run_ln_fold_case(200, 1280, 1280, PFD_ACT_GELU, 5300, 3700, 0);   // LayerNorm fold through the new kernels (consumer side)
     run_ln_fold_case(520, 640, 640, 0, 9200, 9500, 0);
     run_ln_fold_case(77, 960, 160, 0, 9300, 5500, 0);
