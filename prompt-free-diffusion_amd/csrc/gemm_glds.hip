@@ -2416,7 +2416,8 @@ int launch160ar(G160Params& p, int bucket, hipStream_t s) {
   p.splits = (nk + p.kt_per_split - 1) / p.kt_per_split;
   dim3 grid(p.tiles_m * p.tiles_n, 1, p.splits);
   const double a_bytes = p.ksize > 0 ? 2.0 * p.B * p.H * p.Wd * p.Cin : 2.0 * p.M * p.K;
-  PfdProfScope prof_scope(bucket, 2.0 * p.M * p.N * p.K, a_bytes + 2.0 * p.N * p.K + 2.0 * p.M * p.N * (p.R ? 2 : 1), s);
+  const double n_out = p.act == PFD_ACT_GEGLU ? p.N / 2 : p.N;
+  PfdProfScope prof_scope(bucket, 2.0 * p.M * p.N * p.K, a_bytes + 2.0 * p.N * p.K + 2.0 * p.M * n_out * (p.R ? 2 : 1), s);
   if constexpr (MINW == 1) {   // (the im2col form of the 128-VGPR build spills: variant 86 serves linears only)
     if (p.ksize > 0) hipLaunchKernelGGL((gemm160ar_kernel<WAVES_M, WMB, NBUF, true, MINW>), grid, dim3(WAVES_M * 128), 0, s, p);
   }
@@ -2688,7 +2689,7 @@ int pfd_gemm160_try(const PfdGemmDesc* d, int variant, int splits, hipStream_t s
   const int conv = p.ksize > 0 ? 1 : 0;
   // PFD_AREG=1 (default off; round-5 end-to-end A/B): the ring kernels the rules above picked are replaced by their
   // register-operand forms -- same tiles, same split counts, same bits (selftest --r5)
-  if (auto_variant && bn == 160 && areg_mode() >= 1 && p.act != PFD_ACT_GEGLU)
+  if (auto_variant && bn == 160 && areg_mode() >= 1)
     variant = variant == 23 ? 27 : variant == 43 ? 45 : variant == 83 ? 85 : (variant == 82 && areg_mode() >= 2 && !conv) ? 86
               : (variant == 22 && areg_mode() >= 2 && !conv) ? 28 : variant;
   if ((variant == 27 || variant == 45 || variant == 85 || variant == 86 || variant == 28) && bn != 160) return 1;   // 160-wide tiles only
@@ -2722,16 +2723,16 @@ int pfd_gemm160_try(const PfdGemmDesc* d, int variant, int splits, hipStream_t s
     case 26: return launch160<2, 2, 5>(p, 14 + 4 * conv, s) < 0 ? PFD_ELAUNCH : 0;
     case 46: return launch160<4, 1, 5>(p, 14 + 4 * conv, s) < 0 ? PFD_ELAUNCH : 0;
     // round-5 candidates, forced only: activation fragments global -> VGPR, weights alone on a 7-stage LDS ring = 6 K tiles
-    // in flight (gemm160ar_kernel).  Linears and implicit-GEMM convolutions, no GEGLU (a launch they do not serve falls back
-    // to the automatic choice); 27 = 64 x 160 on 4 waves, 45 = 64 x 160 on 8 waves, 85 = 128 x 160 on 8 waves
-    case 27: return p.act == PFD_ACT_GEGLU ? 1 : launch160ar<2, 2, 7>(p, 14 + 4 * conv, s) < 0 ? PFD_ELAUNCH : 0;
-    case 45: return p.act == PFD_ACT_GEGLU ? 1 : launch160ar<4, 1, 7>(p, 14 + 4 * conv, s) < 0 ? PFD_ELAUNCH : 0;
-    case 85: return p.act == PFD_ACT_GEGLU ? 1 : launch160ar<4, 2, 7>(p, 13 + 4 * conv, s) < 0 ? PFD_ELAUNCH : 0;
+    // in flight (gemm160ar_kernel).  Linears (GEGLU included: same epilogue) and implicit-GEMM convolutions (a launch they
+    // do not serve falls back to the automatic choice); 27 = 64 x 160 on 4 waves, 45 = 64 x 160 on 8 waves, 85 = 128 x 160 on 8 waves
+    case 27: return launch160ar<2, 2, 7>(p, 14 + 4 * conv, s) < 0 ? PFD_ELAUNCH : 0;
+    case 45: return launch160ar<4, 1, 7>(p, 14 + 4 * conv, s) < 0 ? PFD_ELAUNCH : 0;
+    case 85: return launch160ar<4, 2, 7>(p, 13 + 4 * conv, s) < 0 ? PFD_ELAUNCH : 0;
     // 86 = 128 x 160 on 8 waves, 3 weight stages (60 KB, <= 128 VGPRs): two blocks per CU like variant 82, each with two K
     // tiles in flight instead of one -- for the short-K linears on >= 8192 rows (many tiles per CU)
-    case 86: return (conv || p.act == PFD_ACT_GEGLU) ? 1 : launch160ar<4, 2, 3, 4>(p, 13 + 4 * conv, s) < 0 ? PFD_ELAUNCH : 0;
+    case 86: return conv ? 1 : launch160ar<4, 2, 3, 4>(p, 13 + 4 * conv, s) < 0 ? PFD_ELAUNCH : 0;
     // 28 = 64 x 160 on 4 waves, 3 weight stages (60 KB): two blocks per CU like variant 22, each with two K tiles in flight
-    case 28: return (conv || p.act == PFD_ACT_GEGLU) ? 1 : launch160ar<2, 2, 3, 2>(p, 14, s) < 0 ? PFD_ELAUNCH : 0;
+    case 28: return conv ? 1 : launch160ar<2, 2, 3, 2>(p, 14, s) < 0 ? PFD_ELAUNCH : 0;
     // round 3 experiments: the same tiles on 8 waves (4 x 2 wave layout, wave tile 16 x 80 / 32 x 80): twice the waves
     // issuing LDS-DMA pieces per CU and two waves per SIMD on the problems whose one 4-wave block per CU is bound by the
     // piece issue rate (64-row tiles: 41 two stages, 43 four-stage ring; 128-row tiles: 82 two stages, 83 three)

@@ -1596,6 +1596,11 @@ int main(int argc, char** argv) {
       run_lin_same_case(4096, 640, 640, 3200, 3800, false);             // cond-half to_q 32^2
       run_lin_same_case(8192, 640, 640, 3200, 3800, true, 0, 4096);     // zero-context out-projection 32^2
     }
+    for (int v : {3700, 5500, 9500, 9600, 3800}) {   // GEGLU projections through the register-operand kernels (packed weights, half-width output)
+      run_gemm_case({200, 320, 128, PFD_ACT_GEGLU, true, false, false, false, v});
+      run_gemm_case({600, 640, 320, PFD_ACT_GEGLU, true, false, false, false, v});
+      run_ln_fold_case(300, 640, 1280, PFD_ACT_GEGLU, 5400, v, 0);
+    }
     run_ln_fold_case(200, 1280, 1280, PFD_ACT_GELU, 5300, 3700, 0);   // LayerNorm fold through the new kernels (consumer side)
     run_ln_fold_case(520, 640, 640, 0, 9200, 9500, 0);
     run_ln_fold_case(77, 960, 160, 0, 9300, 5500, 0);
