@@ -40,3 +40,10 @@ def test_register_operand_ring_kernels_keep_only_their_counted_wait():
         assert not bad, (k, bad)
         assert n_keep == nbuf - 1 or n_keep == nbuf, (k, n_keep)   # one counted wait per unrolled step
         assert 0 < keep < 64
+    # and nothing but the consuming MFMAs reads a register one of those loads wrote (no compiler copy / spill of a value
+    # that may not have landed yet)
+    hyg = isa_audit.areg_register_hygiene(isa_audit.compile_asm(os.path.join(isa_audit.CSRC, "gemm_glds.hip")))
+    assert sorted(hyg) == sorted(res)
+    for k, (bad, nring) in hyg.items():
+        assert not bad, (k, bad[:4])
+        assert nring in (48, 56, 112), (k, nring)   # ring stages x row blocks x 2 K halves x 4 registers

@@ -104,6 +104,69 @@ def areg_loop_waits(asm_path):
     return res
 
 
+def _regs(tok):
+    """v[a:b] / vN operand -> set of VGPR numbers"""
+    m = re.match(r"^v\[(\d+):(\d+)\]$", tok)
+    if m:
+        return set(range(int(m.group(1)), int(m.group(2)) + 1))
+    m = re.match(r"^v(\d+)$", tok)
+    return {int(m.group(1))} if m else set()
+
+
+def areg_register_hygiene(asm_path):
+    """gemm160ar_kernel: a register loaded by one of the uncounted asm loads (the activation ring) may be READ by nothing but
+    the MFMAs that consume it -- a compiler copy / spill of such a register between the load and the counted wait would move
+    garbage (guide 5.7 item 1).  hipcc does use the ring registers as address temporaries while they are dead (between the
+    last MFMA of a slot and the load that refills it, often as the load's own address operand); those reads see a value
+    written by an ordinary instruction and are fine.  Walks each kernel in program order with, per register, whether its last
+    writer was an asm load.  -> {kernel: (offending instructions, ring registers)}"""
+    res, name, body, in_asm = {}, None, [], False
+    for line in open(asm_path):
+        m = re.match(r"^(_Z[A-Za-z0-9_]+):", line)
+        if m:
+            name, body = m.group(1), []
+            continue
+        if name and "gemm160ar_kernel" in name:
+            raw = line.strip()
+            if raw.startswith(";;#ASMSTART"):
+                in_asm = True
+                continue
+            if raw.startswith(";;#ASMEND"):
+                in_asm = False
+                continue
+            t = line.split(";")[0].strip()
+            if t.startswith(".Lfunc_end"):
+                ring = set()
+                for asm, x in body:
+                    if asm and x.startswith("global_load_dwordx4"):
+                        ring |= _regs(x.split()[1].rstrip(","))
+                loaded = set()      # ring registers whose last writer is an asm load
+                bad = []
+                for asm, x in body:
+                    parts = x.split()
+                    if len(parts) < 2 or x.endswith(":"):
+                        continue
+                    ops = [o.rstrip(",") for o in parts[1:]]
+                    if asm and x.startswith("global_load_dwordx4"):
+                        loaded |= _regs(ops[0])       # (its address operand may overlap: read at issue, before the write)
+                        continue
+                    store = parts[0].startswith(("global_store", "scratch_store", "ds_write", "buffer_store"))
+                    srcs = ops if store else ops[1:]
+                    dsts = [] if store else ops[:1]
+                    if parts[0].startswith("v_mfma"):
+                        srcs, dsts = [ops[3]], [ops[0]]          # A / B operands may read the ring; C / D must not be it
+                    for o in srcs:
+                        if _regs(o) & loaded:
+                            bad.append(x)
+                    for o in dsts:
+                        loaded -= _regs(o)
+                res[name] = (bad, len(ring))
+                name = None
+            elif t:
+                body.append((in_asm, t))
+    return res
+
+
 def findings(files=None):
     files = files or [os.path.join(CSRC, f) for f in ("gemm_glds.hip", "gemm_conv.hip", "norm.hip")]
     bad, rows = [], []
