@@ -1542,7 +1542,7 @@ int main(int argc, char** argv) {
       run_gemm_case({77, 160, 960, 0, true, false, false, false, v, 8});                                    // odd leading dimensions, 15 steps
       run_gemm_case({2048, 1280, 1280, 0, true, false, true, false, v});                                    // the 16^2 out-projection class
       run_gemm_case({512, 1280, 1280, PFD_ACT_GELU, true, true, false, false, v + 2});                      // split-K 2
-      run_gemm_case({512, 1280, 5120, 0, true, true, false, false, v + 4});                                 // split-K 4, 20 steps per split
+      run_gemm_case({512, 320, 5120, 0, true, true, false, false, v + 4});                                  // split-K 4, 20 steps per split
       { GemmCase c{700, 320, 1024, 0, true, true, true, false, v}; c.k_split = 384; run_gemm_case(c); }
       { GemmCase c{1100, 320, 512, 0, true, true, false, false, v}; c.zero_rows = 512; run_gemm_case(c); }
       { GemmCase c{600, 160, 256, PFD_ACT_SILU, true, true, true, false, v}; c.zero_rows = 300; c.k_split = 64; run_gemm_case(c); }
@@ -1554,7 +1554,7 @@ int main(int argc, char** argv) {
       run_gemm_case({0, 160, 0, 0, true, false, false, false, v, 0, 3, 2, 1, 0, 2, 16, 16, 128});             // stride 2
       run_gemm_case({0, 320, 0, 0, true, false, false, false, v, 0, 3, 1, 1, 1, 1, 8, 8, 192});               // fused nearest-2x upsample
       run_gemm_case({0, 160, 0, 0, true, false, false, false, v, 0, 3, 1, 1, 0, 1, 16, 16, 64});              // one K tile per tap, 9 steps
-      run_gemm_case({0, 1280, 0, 0, true, true, true, false, v + 4, 0, 3, 1, 1, 0, 8, 8, 8, 1280});           // the 8^2 conv class, split-K 4
+      run_gemm_case({0, 320, 0, 0, true, true, true, false, v + 4, 0, 3, 1, 1, 0, 8, 8, 8, 1280});            // the 8^2 conv class (narrower), split-K 4
       run_gemm_case({0, 160, 0, 0, true, true, false, false, v, 0, 1, 1, 0, 0, 3, 12, 12, 192});              // 1x1 as a convolution, ragged M (432 rows)
       { GemmCase c{0, 320, 0, 0, true, false, false, false, v, 0, 3, 2, 1, 0, 2, 32, 32, 128}; c.gn_out = 1; run_gemm_case(c); }   // stride 2 + statistics
     }

@@ -11,7 +11,7 @@ set -u
 O=gpurun_out/r05_ring5; mkdir -p $O
 S=prompt-free-diffusion_amd/csrc/build/selftest
 L=profiles/unet_c2_gemm_shapes.txt
-timeout 240 $S --r5 > $O/selftest_r5.log 2>&1; echo "selftest --r5 rc=$?"; tail -1 $O/selftest_r5.log; grep FAIL $O/selftest_r5.log | head
+timeout 400 $S --r5 > $O/selftest_r5.log 2>&1; echo "selftest --r5 rc=$?"; tail -1 $O/selftest_r5.log; grep FAIL $O/selftest_r5.log | head
 for rep in 1 2; do
   for t in 0 3300 3600 3700 5300 5600 5500 9300 9500 9200 9600 3200 3800; do     # 0 = automatic, 33 / 53 / 93 = today's rings (variants 23 / 43 / 83), 36 / 56 = 5 stages, 37 / 55 / 95 = A in registers + 7 weight stages, 92 = the 2-stage 128-row tile on 8 waves (variant 82), 96 = its register-operand form with 3 weight stages (86), 32 / 38 = the 2-stage 64-row tile (22) and its register-operand form (28)
     timeout 60 $S --replay-time $L $t > $O/replay_t${t}_$rep.log 2>&1; echo "tile $t run $rep: $(tail -1 $O/replay_t${t}_$rep.log)"
