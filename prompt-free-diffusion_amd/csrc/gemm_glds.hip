@@ -1960,32 +1960,38 @@ __global__ __launch_bounds__(768) void conv3x3_patch_ws_kernel(const G160Params 
 // Round-5 candidate, forced only (variant 95; never the automatic choice, not yet run on hardware): the wave-specialised
 // patch kernel WITHOUT the block-wide barrier per tap.  conv3x3_patch_ws_kernel passes 12 waves through one s_barrier
 // per tap: all eight consumers start their fragment reads together and drain the MFMA pipe together (wait share 0.50,
-// in-loop rate 0.67 of the instruction's ceiling).  Here the two sides hand over through two counters in LDS:
-//   ready  += 1 by every loader wave when ITS pieces of tap T (and, at a block's tap 0, of the patch) have landed
-//             (its own s_waitcnt vmcnt(0));  a consumer starts tap T when ready >= 4 (T + 1)
-//   done   += 1 by every consumer wave when its fragment reads of tap T have returned (lgkmcnt(0));  a loader refills the
+// in-loop rate 0.67 of the instruction's ceiling).  Here the two sides hand over through per-wave progress words in LDS:
+//   ready[lw] = T + 1 by loader wave lw when ITS pieces of tap T (and, at a block's tap 0, of the patch) have landed
+//             (its own s_waitcnt vmcnt(0));  a consumer starts tap T when all four words are >= T + 1
+//   done[w]   = T + 1 by consumer wave w when its fragment reads of tap T have returned (lgkmcnt(0));  a loader refills the
 //             weight stage of tap T - 1 with tap T + 1 -- and writes the next block's patch pieces into the buffer block
-//             ci - 1 used -- when done >= 8 T
+//             ci - 1 used -- when all eight words are >= T
 // so waves drift up to one tap apart and the two MFMA waves of a SIMD stop waiting at the same instant.  Two weight
-// stages (the 3-stage ring fills all 160 KiB; the counters need 8 bytes), same LDS images, swizzles, DMA pieces,
+// stages (the 3-stage ring fills all 160 KiB; the progress words need 48 bytes), same LDS images, swizzles, DMA pieces,
 // summation order and epilogue as the <0, false, 2> instantiation: results must be bit-identical to it.  Every poll is
 // bounded (FL_SPIN_CAP): a protocol error gives wrong numbers in selftest, not a hung GPU.
 // ------------------------------------------------------------------------------------------------
+// (One WORD PER WAVE, not one shared counter per side: with a counter, `ready >= 4 (T + 1)` is also reached by three loaders
+//  that have handed over tap T + 1 and a fourth that is still on tap T - 1 -- 3 (T + 2) + T -- and the consumers would start
+//  tap T on pieces that have not landed; likewise `done`.  Each wave publishes its own progress, a waiter needs ALL of them.)
 constexpr int FL_SPIN_CAP = 1 << 16;   // ~3 ms of polling: three orders of magnitude above a tap, far below a watchdog
 typedef __attribute__((address_space(3))) unsigned lds_u32_t;
-__device__ __forceinline__ void fl_wait(const char* flag, unsigned target) {
-  const volatile lds_u32_t* f = (const volatile lds_u32_t*)flag;   // ds_read_b32, not a flat load through the aperture
+// wait until every one of the N (4 | 8) progress words at `flags` is >= target: lane l polls word l % N, the wave votes
+template <int N>
+__device__ __forceinline__ void fl_wait_all(const char* flags, unsigned target, int lane) {
+  const volatile lds_u32_t* f = (const volatile lds_u32_t*)flags + (lane & (N - 1));   // ds_read_b32, not a flat load
 #pragma nounroll
   for (int spin = 0; spin < FL_SPIN_CAP; ++spin) {
-    const unsigned v = __builtin_amdgcn_readfirstlane(*f);
-    if (v >= target) break;
+    const unsigned v = *f;
+    if (__builtin_amdgcn_ballot_w64(v < target) == 0) break;
     __builtin_amdgcn_s_sleep(1);
   }
   asm volatile("" ::: "memory");
 }
-__device__ __forceinline__ void fl_signal(char* flag, int lane) {
+// publish this wave's progress (its own word: a plain store, program order behind the waits that precede the call)
+__device__ __forceinline__ void fl_publish(char* flags, int w, unsigned count, int lane) {
   asm volatile("" ::: "memory");
-  if (lane == 0) __hip_atomic_fetch_add((lds_u32_t*)flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  if (lane == 0) *((volatile lds_u32_t*)flags + w) = count;
   asm volatile("" ::: "memory");
 }
 
@@ -1994,7 +2000,7 @@ __global__ __launch_bounds__(768) void conv3x3_patch_fl_kernel(const G160Params 
   constexpr int PATCH_BYTES = PATCH_ROWS * ROWB;  // 51200
   constexpr int WT_BYTES = BN * ROWB;             // 20480
   constexpr int OFF_W = 2 * PATCH_BYTES;
-  constexpr int OFF_FLAGS = OFF_W + 2 * WT_BYTES; // {ready, done}
+  constexpr int OFF_FLAGS = OFF_W + 2 * WT_BYTES; // ready[4] (loader waves), done[8] (consumer waves): taps handed over / read
   constexpr int SMEM = OFF_FLAGS + 1024;
   static_assert(SMEM <= 160 * 1024, "LDS");
   constexpr int P_INSTR = PATCH_ROWS / 8;          // 50 DMA pieces per patch
@@ -2024,7 +2030,7 @@ __global__ __launch_bounds__(768) void conv3x3_patch_fl_kernel(const G160Params 
   const int ncbs = max(0, cb_end - cb_begin);
   const int nsteps = ncbs * 9;
   char* const f_ready = smem + OFF_FLAGS;
-  char* const f_done = smem + OFF_FLAGS + 4;
+  char* const f_done = smem + OFF_FLAGS + 16;
 
   auto block_barrier = [&]() {
     __builtin_amdgcn_sched_barrier(0);
@@ -2033,10 +2039,9 @@ __global__ __launch_bounds__(768) void conv3x3_patch_fl_kernel(const G160Params 
     asm volatile("" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
   };
-  if (tid == 0) {
+  if (tid < 12) {
     volatile lds_u32_t* f = (volatile lds_u32_t*)(smem + OFF_FLAGS);
-    f[0] = 0u;
-    f[1] = 0u;
+    f[tid] = 0u;
   }
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   block_barrier();                            // the counters are zero before anyone polls or adds
@@ -2095,8 +2100,8 @@ __global__ __launch_bounds__(768) void conv3x3_patch_fl_kernel(const G160Params 
 #pragma unroll
       for (int tap = 0; tap < 9; ++tap) {
         __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): this wave's pieces of tap T (and of the patch) are in LDS
-        fl_signal(f_ready, lane);
-        fl_wait(f_done, 8u * T);              // every consumer has read tap T - 1: its weight stage (and block ci - 1's patch) are free
+        fl_publish(f_ready, lw, T + 1, lane);
+        fl_wait_all<8>(f_done, T, lane);      // every consumer has read tap T - 1: its weight stage (and block ci - 1's patch) are free
         if (tap < 8) issue_w(stage ^ 1, tap + 1, cb);
         else if (more) issue_w(stage ^ 1, 0, cb1);
         if (more) {
@@ -2142,7 +2147,7 @@ __global__ __launch_bounds__(768) void conv3x3_patch_fl_kernel(const G160Params 
 #pragma nounroll
         for (int kx = 0; kx < 3; ++kx) {
           ++T;
-          fl_wait(f_ready, 4u * T);           // all four loaders' pieces of this tap have landed
+          fl_wait_all<4>(f_ready, T, lane);   // all four loaders' pieces of this tap have landed
           const char* wt = smem + OFF_W + stage * WT_BYTES;
 #pragma unroll
           for (int ks = 0; ks < 2; ++ks) {
@@ -2159,7 +2164,7 @@ __global__ __launch_bounds__(768) void conv3x3_patch_fl_kernel(const G160Params 
                 acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[j], af[i], acc[i][j], 0, 0, 0);
           }
           asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this tap's fragments are in registers
-          fl_signal(f_done, lane);
+          fl_publish(f_done, wave, T, lane);
           stage ^= 1;
           toff += 1;
         }
