@@ -2672,7 +2672,7 @@ int pfd_gemm160_try(const PfdGemmDesc* d, int variant, int splits, hipStream_t s
       if (splits > 8) splits = 8;
       while (splits > 1 && nk / splits < 16) --splits;  // the slab round trip must stay small vs the K loop
       while (splits > 1 && (size_t)splits * p.M * p.N * 4 > d->ws_bytes) --splits;
-    } else if (p.act != PFD_ACT_GEGLU && d->ws && (variant == 22 || variant == 23 || variant == 41 || variant == 43 || variant == 26 || variant == 46 || variant == 27 || variant == 45 || variant == 28) && tl <= 128 && nk >= 16) {
+    } else if (p.act != PFD_ACT_GEGLU && d->ws && (variant == 22 || variant == 23 || variant == 41 || variant == 43 || variant == 26 || variant == 46 || variant == 27 || variant == 45 || variant == 28 || variant == 29) && tl <= 128 && nk >= 16) {
       splits = (int)(256 / tl);   // M <= 1024 rows (8^2 level, cond-half projections): 25 -> 21 us
       if (splits > 4) splits = 4;
       while (splits > 1 && (size_t)splits * p.M * p.N * 4 > d->ws_bytes) --splits;
@@ -2697,7 +2697,7 @@ int pfd_gemm160_try(const PfdGemmDesc* d, int variant, int splits, hipStream_t s
   if (auto_variant && bn == 160 && areg_mode() >= 1)
     variant = variant == 23 ? 27 : variant == 43 ? 45 : variant == 83 ? 85 : (variant == 82 && areg_mode() >= 2 && !conv) ? 86
               : (variant == 22 && areg_mode() >= 2 && !conv) ? 28 : variant;
-  if ((variant == 27 || variant == 45 || variant == 85 || variant == 86 || variant == 28) && bn != 160) return 1;   // 160-wide tiles only
+  if ((variant == 27 || variant == 45 || variant == 85 || variant == 86 || variant == 28 || variant == 29) && bn != 160) return 1;   // 160-wide tiles only
   if (variant == 48 || variant == 49 || variant == 47) {   // 8 MFMA waves + 4 loader waves (49: ping-pong consumer groups, 47: 3-stage ring)
     const int mode = variant == 49 ? 1 : variant == 47 ? 2 : 0;
     if (bn == 128) return launch160ws<4>(p, 12 + 4 * conv, s, mode) < 0 ? PFD_ELAUNCH : 0;
@@ -2733,6 +2733,9 @@ int pfd_gemm160_try(const PfdGemmDesc* d, int variant, int splits, hipStream_t s
     case 27: return launch160ar<2, 2, 7>(p, 14 + 4 * conv, s) < 0 ? PFD_ELAUNCH : 0;
     case 45: return launch160ar<4, 1, 7>(p, 14 + 4 * conv, s) < 0 ? PFD_ELAUNCH : 0;
     case 85: return launch160ar<4, 2, 7>(p, 13 + 4 * conv, s) < 0 ? PFD_ELAUNCH : 0;
+    // 29 = 27 with 5 weight stages: the same four K tiles in flight as the all-LDS 5-stage ring (26), i.e. the price of
+    // moving the activations through registers at equal depth (A/B only)
+    case 29: return launch160ar<2, 2, 5>(p, 14 + 4 * conv, s) < 0 ? PFD_ELAUNCH : 0;
     // 86 = 128 x 160 on 8 waves, 3 weight stages (60 KB, <= 128 VGPRs): two blocks per CU like variant 82, each with two K
     // tiles in flight instead of one -- for the short-K linears on >= 8192 rows (many tiles per CU)
     case 86: return conv ? 1 : launch160ar<4, 2, 3, 4>(p, 13 + 4 * conv, s) < 0 ? PFD_ELAUNCH : 0;

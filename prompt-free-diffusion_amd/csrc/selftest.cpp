@@ -1533,7 +1533,7 @@ int main(int argc, char** argv) {
       run_conv_same_case(8, 16, 16, 1280, 1280, 10800, 10500, false);
     }
     // forced variants 27 / 45 / 85: activation fragments global -> VGPR (uncounted asm loads), weights on a 7-stage ring
-    for (int v : {3700, 5500, 9500}) {
+    for (int v : {3700, 5500, 9500, 3900}) {
       run_gemm_case({300, 320, 64, 0, true, true, false, false, v});                                        // ONE K step (ring deeper than the loop)
       run_gemm_case({300, 320, 192, PFD_ACT_SILU, true, true, true, false, v});                             // three K steps
       run_gemm_case({300, 320, 448, 0, true, true, false, false, v});                                       // 7 steps = exactly one trip round the ring
@@ -1605,8 +1605,8 @@ int main(int argc, char** argv) {
     run_ln_fold_case(520, 640, 640, 0, 9200, 9500, 0);
     run_ln_fold_case(77, 960, 160, 0, 9300, 5500, 0);
     // same bits as the LDS-ring kernels of the same tile (23 / 43 / 83), launch after launch, at the C2 shapes they would serve
-    for (int pair = 0; pair < 3; ++pair) {
-      const int ta = pair == 0 ? 3300 : pair == 1 ? 5300 : 9300, tb = pair == 0 ? 3700 : pair == 1 ? 5500 : 9500;
+    for (int pair = 0; pair < 4; ++pair) {
+      const int ta = pair == 0 ? 3300 : pair == 1 ? 5300 : pair == 2 ? 9300 : 3300, tb = pair == 0 ? 3700 : pair == 1 ? 5500 : pair == 2 ? 9500 : 3900;
       run_lin_same_case(2048, 1280, 1280, ta, tb, true);
       run_lin_same_case(2048, 1280, 5120, ta, tb, true);
       run_lin_same_case(8192, 640, 2560, ta, tb, true);
