@@ -1,0 +1,50 @@
+"""CPU emulation of the wide-tile GEMM / convolution kernels (tools/cpu_emu): the kernel file csrc/gemm_glds.hip is compiled
+for the HOST against a shim of the HIP runtime -- one OS thread per GPU thread of a block, MFMA / shuffles / ballot as
+rendezvous of a wave's 64 threads, LDS as block-shared statics, real barriers -- and the library's own dispatcher
+(pfd_gemm160_try, forced variants, split-K) runs small problems through it.  Checked against a double-precision reference,
+and the round-5 candidates that have never run on hardware (register-operand rings 27 / 45 / 85 / 29 / 86 / 28, the patch
+kernel that hands over through LDS progress words, 95) bit for bit against the hardware-validated kernels they would
+replace (23 / 43 / 83 / 82 / 22 / 98).  What the model cannot see: s_waitcnt counts (tests/test_ring_protocol.py and
+tests/test_isa_audit.py cover those), register allocation, timing."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CXX = os.environ.get("EMU_CXX", "/opt/rocm/lib/llvm/bin/clang++")
+
+pytestmark = pytest.mark.skipif(not os.path.exists(CXX), reason="clang++ of the ROCm toolchain not available")
+
+
+@pytest.fixture(scope="module")
+def emu(tmp_path_factory):
+    out = str(tmp_path_factory.mktemp("pfd_cpu_emu"))
+    subprocess.run([sys.executable, os.path.join(REPO, "tools", "cpu_emu", "build.py"), out], check=True,
+                   stdout=subprocess.DEVNULL)
+    return os.path.join(out, "emu_gemm")
+
+
+def _run(emu, *filters):
+    r = subprocess.run([emu, *filters], capture_output=True, text=True, timeout=900)
+    lines = [l for l in r.stdout.splitlines() if l.startswith(("ok", "FAIL"))]
+    assert r.returncode == 0 and lines and not any(l.startswith("FAIL") for l in lines), r.stdout[-3000:] + r.stderr[-1000:]
+    return lines
+
+
+def test_emulation_reproduces_the_hardware_validated_kernels(emu):
+    lines = _run(emu, "variant 23 (", "variant 83 (", "variant 98", "variant 96", "variant 99")
+    assert len(lines) == 5
+    assert sum("== variant 98 bitwise" in l for l in lines) == 2      # 3-stage ring and 8-wave forms of the patch kernel
+
+
+def test_register_operand_ring_kernels_match_the_lds_ring_kernels_bit_for_bit(emu):
+    lines = _run(emu, "variant 27", "variant 45", "variant 85", "variant 29", "variant 86", "variant 28")
+    assert len(lines) == 17
+    assert all("bitwise" in l for l in lines), "\n".join(lines)
+
+
+def test_flag_handover_patch_kernel_matches_the_barrier_form(emu):
+    lines = _run(emu, "variant 95")
+    assert len(lines) == 2 and all("== variant 98 bitwise" in l for l in lines)

@@ -1,0 +1,231 @@
+// CPU emulation of the wide-tile GEMM / convolution kernels of csrc/gemm_glds.hip (test infrastructure; see hip/hip_runtime.h
+// in this directory for the execution model).  tools/cpu_emu/build.py writes gemm_glds_emu.inc -- the kernel file with its
+// gfx950 inline-asm statements replaced by their C meaning -- and compiles this file for the host.  The same host dispatcher
+// (pfd_gemm160_try: tile choice, split-K, forced variants) and the same device code (index arithmetic, LDS images and
+// swizzles, ring slots, barriers, the flag hand-over of variant 95, epilogues) then run on CPU threads, and the result is
+// compared with a double-precision reference.  What it cannot see: s_waitcnt counts (a copy lands when it is issued),
+// register allocation, timing.
+//   usage: emu_gemm [case ...]      no argument = the built-in list; exit code = number of failed cases
+#include <stdio.h>
+
+#include <random>
+#include <string>
+
+#include "hip/hip_runtime.h"
+
+namespace emu {
+thread_local dim3 t_idx, b_idx;
+dim3 b_dim, g_dim;
+Block* cur = nullptr;
+const void* kernarg = nullptr;
+
+void launch(const std::function<void()>& body, dim3 grid, dim3 block, const void* arg0) {
+  const int nthr = (int)block.x, nw = (nthr + 63) / 64;
+  if (nthr % 64) { fprintf(stderr, "emu: block size %d is not a multiple of 64\n", nthr); abort(); }
+  b_dim = block;
+  g_dim = grid;
+  kernarg = arg0;
+  for (unsigned bz = 0; bz < grid.z; ++bz)
+    for (unsigned by = 0; by < grid.y; ++by)
+      for (unsigned bx = 0; bx < grid.x; ++bx) {
+        Block blk;
+        blk.waves = std::vector<Wave>(nw);
+        pthread_barrier_init(&blk.bar, nullptr, nthr);
+        for (auto& w : blk.waves) pthread_barrier_init(&w.bar, nullptr, 64);
+        cur = &blk;
+        std::vector<std::thread> th;
+        th.reserve(nthr);
+        for (int t = 0; t < nthr; ++t)
+          th.emplace_back([&, t]() {
+            t_idx = dim3(t, 0, 0);
+            b_idx = dim3(bx, by, bz);
+            body();
+          });
+        for (auto& x : th) x.join();
+        for (auto& w : blk.waves) pthread_barrier_destroy(&w.bar);
+        pthread_barrier_destroy(&blk.bar);
+        cur = nullptr;
+      }
+}
+}  // namespace emu
+
+// ---- what the kernel file expects from the rest of the library ----
+#include "pfd_common.h"
+bool pfd_prof_on() { return false; }
+void pfd_prof_begin(int, double, double, hipStream_t) {}
+void pfd_prof_end(hipStream_t) {}
+static std::string g_err;
+int pfd_check_launch(const char*) { return 0; }
+void pfd_set_error(const char* m) { g_err = m; }
+int pfd_ln_rowstats_launch(const half_t*, long, int, int, float*, hipStream_t, bool) { return PFD_ESHAPE; }
+
+#include "gemm_glds_emu.inc"
+
+// ---- cases ----
+typedef _Float16 h16;
+static std::mt19937 rng(99);
+static std::vector<h16> rand_h(size_t n, float scale) {
+  std::uniform_real_distribution<float> d(-1.f, 1.f);
+  std::vector<h16> v(n);
+  for (auto& x : v) x = (h16)(d(rng) * scale);
+  return v;
+}
+
+struct Case {
+  const char* what;
+  int M, N, K, variant, splits;
+  bool res = false, rowvec = false;
+  int act = 0, k_split = 0, zero_rows = 0;
+  int ksize = 0, stride = 1, pad = 0, ups = 0, B = 0, H = 0, W = 0, Cin = 0;
+  int base_variant = -1;   // >= 0: additionally demand the same bits as this variant
+};
+
+static int run_variant(const Case& c, int variant, const std::vector<h16>& A, const std::vector<h16>& A2, const std::vector<h16>& Wt,
+                       const std::vector<h16>& bias, const std::vector<h16>& rv, const std::vector<h16>& R, int M, int K, int Ho, int Wo,
+                       std::vector<h16>& C, std::vector<float>& ws) {
+  const bool conv = c.ksize > 0;
+  PfdGemmDesc d;
+  memset(&d, 0, sizeof(d));
+  d.M = M; d.N = c.N; d.K = K;
+  d.A = A.data(); d.W = Wt.data(); d.bias = bias.data(); d.C = C.data();
+  d.R = c.res ? R.data() : nullptr;
+  d.rowvec = c.rowvec ? rv.data() : nullptr;
+  d.lda = conv ? c.Cin : (c.k_split ? c.k_split : K);
+  d.ldw = K; d.ldc = c.N; d.ldr = c.N; d.ldrv = c.N;
+  d.rows_per_rv = conv ? Ho * Wo : 64;
+  d.act = c.act;
+  d.ksize = c.ksize; d.stride = c.stride; d.pad = c.pad; d.ups = c.ups;
+  d.B = c.B; d.H = c.H; d.Wd = c.W; d.Cin = c.Cin; d.Ho = Ho; d.Wo = Wo;
+  if (c.k_split) { d.k_split = c.k_split; d.A2 = A2.data(); d.lda2 = K - c.k_split; }
+  d.zero_rows = c.zero_rows;
+  d.ws = ws.data(); d.ws_bytes = ws.size() * sizeof(float);
+  return pfd_gemm160_try(&d, variant, c.splits, nullptr);
+}
+
+static int run_case(const Case& c) {
+  const bool conv = c.ksize > 0;
+  int M = c.M, K = c.K, Ho = 0, Wo = 0;
+  if (conv) {
+    const int Hin = c.ups ? 2 * c.H : c.H, Win = c.ups ? 2 * c.W : c.W;
+    Ho = (Hin + 2 * c.pad - c.ksize) / c.stride + 1;
+    Wo = (Win + 2 * c.pad - c.ksize) / c.stride + 1;
+    M = c.B * Ho * Wo;
+    K = c.ksize * c.ksize * c.Cin;
+  }
+  const int N = c.N;
+  const long a_rows = conv ? (long)c.B * c.H * c.W : M, lda_full = conv ? c.Cin : K;
+  auto Afull = rand_h((size_t)a_rows * lda_full, 1.f);
+  auto Wt = rand_h((size_t)N * K, 1.7f / sqrtf((float)K)), bias = rand_h(N, 0.5f), R = rand_h((size_t)M * N, 1.f);
+  const int rows_per_rv = conv ? Ho * Wo : 64;
+  auto rv = rand_h((size_t)((M + rows_per_rv - 1) / rows_per_rv) * N, 0.5f);
+  for (long r = 0; r < c.zero_rows; ++r)
+    for (long k = 0; k < lda_full; ++k) Afull[r * lda_full + k] = (h16)0;
+  // device operands: rows below zero_rows are not stored; columns >= k_split live in a second buffer
+  const int K1 = c.k_split ? c.k_split : (int)lda_full, K2 = c.k_split ? K - c.k_split : 0;
+  const long Mz = a_rows - c.zero_rows;
+  std::vector<h16> A1((size_t)Mz * K1 + 64), A2((size_t)Mz * std::max(K2, 1) + 64);
+  for (long m = 0; m < Mz; ++m) {
+    for (int k = 0; k < K1; ++k) A1[(size_t)m * K1 + k] = Afull[(size_t)(m + c.zero_rows) * lda_full + k];
+    for (int k = 0; k < K2; ++k) A2[(size_t)m * K2 + k] = Afull[(size_t)(m + c.zero_rows) * lda_full + K1 + k];
+  }
+  std::vector<h16> C((size_t)M * N, (h16)-77.f);
+  std::vector<float> ws((size_t)8 * M * N + 64);
+  g_err.clear();
+  const int rc = run_variant(c, c.variant, A1, A2, Wt, bias, rv, R, M, K, Ho, Wo, C, ws);
+  if (rc != 0) { printf("FAIL %-70s rc=%d %s\n", c.what, rc, g_err.c_str()); return 1; }
+  // double-precision reference
+  double max_err = 0, max_ref = 0;
+  for (int m = 0; m < M; ++m) {
+    int b = 0, oy = 0, ox = 0;
+    if (conv) { b = m / (Ho * Wo); oy = (m % (Ho * Wo)) / Wo; ox = m % Wo; }
+    for (int n = 0; n < N; ++n) {
+      double s = 0;
+      if (!conv) {
+        for (int k = 0; k < K; ++k) s += (double)Afull[(size_t)m * K + k] * (double)Wt[(size_t)n * K + k];
+      } else {
+        const int Hin = c.ups ? 2 * c.H : c.H, Win = c.ups ? 2 * c.W : c.W;
+        for (int ky = 0; ky < c.ksize; ++ky)
+          for (int kx = 0; kx < c.ksize; ++kx) {
+            int iy = oy * c.stride + ky - c.pad, ix = ox * c.stride + kx - c.pad;
+            if (iy < 0 || iy >= Hin || ix < 0 || ix >= Win) continue;
+            if (c.ups) { iy /= 2; ix /= 2; }
+            const h16* ap = &Afull[(((size_t)b * c.H + iy) * c.W + ix) * c.Cin];
+            const h16* wp = &Wt[(size_t)n * K + (ky * c.ksize + kx) * c.Cin];
+            for (int ci = 0; ci < c.Cin; ++ci) s += (double)ap[ci] * (double)wp[ci];
+          }
+      }
+      s += (double)bias[n];
+      if (c.rowvec) s += (double)rv[(size_t)(m / rows_per_rv) * N + n];
+      if (c.act == PFD_ACT_SILU) s = s / (1.0 + exp(-s));
+      else if (c.act == PFD_ACT_RELU) s = s > 0 ? s : 0;
+      if (c.res) s += (double)R[(size_t)m * N + n];
+      max_ref = std::max(max_ref, fabs(s));
+      max_err = std::max(max_err, fabs(s - (double)C[(size_t)m * N + n]));
+    }
+  }
+  const bool ok = max_err <= 4e-3 * std::max(1.0, max_ref);
+  int fails = ok ? 0 : 1;
+  std::string extra;
+  if (ok && c.base_variant >= 0) {
+    std::vector<h16> C2((size_t)M * N, (h16)-55.f);
+    const int rc2 = run_variant(c, c.base_variant, A1, A2, Wt, bias, rv, R, M, K, Ho, Wo, C2, ws);
+    size_t nd = 0;
+    for (size_t i = 0; i < C.size(); ++i) nd += memcmp(&C[i], &C2[i], sizeof(h16)) != 0;
+    if (rc2 != 0 || nd) { fails = 1; extra = " | vs variant " + std::to_string(c.base_variant) + ": rc " + std::to_string(rc2) + ", " + std::to_string(nd) + " elements differ"; }
+    else extra = " | == variant " + std::to_string(c.base_variant) + " bitwise";
+  }
+  printf("%s %-70s max err %.2e (max |ref| %.2f)%s\n", fails ? "FAIL" : "ok  ", c.what, max_err, max_ref, extra.c_str());
+  fflush(stdout);
+  return fails;
+}
+
+int main(int argc, char** argv) {
+  std::vector<Case> cases;
+  auto lin = [&](const char* w, int M, int N, int K, int v, int sp, bool res, int base) {
+    Case c{w, M, N, K, v, sp}; c.res = res; c.base_variant = base; cases.push_back(c); return &cases.back();
+  };
+  auto conv = [&](const char* w, int N, int v, int sp, int ks, int st, int pad, int ups, int B, int H, int W, int Cin, bool res, int base) {
+    Case c{w, 0, N, 0, v, sp}; c.res = res; c.ksize = ks; c.stride = st; c.pad = pad; c.ups = ups; c.B = B; c.H = H; c.W = W; c.Cin = Cin;
+    c.base_variant = base; cases.push_back(c); return &cases.back();
+  };
+  // the LDS-ring kernels the register-operand ones must agree with (sanity of the emulation itself)
+  lin("variant 23 (64x160, 4-stage LDS ring) 200x160x512", 200, 160, 512, 23, 1, true, -1);
+  lin("variant 83 (128x160, 8 waves, 3-stage LDS ring) 200x160x320", 200, 160, 320, 83, 1, false, -1);
+  // register-operand ring kernels (forced variants 27 / 45 / 85 / 29 / 86 / 28)
+  lin("variant 27 one K step", 100, 160, 64, 27, 1, true, 23);
+  lin("variant 27 seven steps = one trip round the ring", 130, 160, 448, 27, 1, true, 23);
+  lin("variant 27 eleven steps, ragged M, two column tiles", 200, 320, 704, 27, 1, false, 23);
+  lin("variant 27 split-K 2 (8 steps per split)", 100, 160, 1024, 27, 2, true, 23);
+  { auto c = lin("variant 27 two-source contraction (k_split 192)", 130, 160, 512, 27, 1, true, 23); c->k_split = 192; }
+  { auto c = lin("variant 27 zero rows (64 whole + a straddling tile)", 200, 160, 256, 27, 1, true, 23); c->zero_rows = 100; }
+  { auto c = lin("variant 27 SiLU + row vector", 130, 160, 256, 27, 1, false, 23); c->act = PFD_ACT_SILU; c->rowvec = true; }
+  lin("variant 45 (8 waves) nine steps", 130, 160, 576, 45, 1, true, 43);
+  lin("variant 85 (128 rows, 8 waves) nine steps", 260, 160, 576, 85, 1, true, 83);
+  lin("variant 29 (5 weight stages) nine steps", 130, 160, 576, 29, 1, true, 23);
+  lin("variant 86 (128 rows, 3 stages) five steps", 260, 160, 320, 86, 1, true, 82);
+  lin("variant 28 (64 rows, 3 stages) five steps", 130, 320, 320, 28, 1, true, 22);
+  conv("variant 27 conv 3x3 s1 p1, 2 x 8 x 8 x 64 -> 160", 160, 27, 1, 3, 1, 1, 0, 2, 8, 8, 64, true, 23);
+  conv("variant 85 conv 3x3 s1 p1, 2 x 8 x 8 x 128 -> 160 (18 steps)", 160, 85, 1, 3, 1, 1, 0, 2, 8, 8, 128, true, 83);
+  conv("variant 45 conv 3x3 stride 2, 1 x 16 x 16 x 64 -> 160", 160, 45, 1, 3, 2, 1, 0, 1, 16, 16, 64, false, 43);
+  conv("variant 27 conv 3x3 + nearest-2x upsample, 1 x 4 x 4 x 64 -> 160", 160, 27, 1, 3, 1, 1, 1, 1, 4, 4, 64, false, 23);
+  conv("variant 85 conv 3x3 split-K 2, 1 x 8 x 8 x 128 -> 160", 160, 85, 2, 3, 1, 1, 0, 1, 8, 8, 128, true, 83);
+  // the barrier forms of the patch kernel (sanity of the emulation on the hardware-validated kernels)
+  conv("variant 98 patch conv 16x16 (loader waves, barrier per tap), 2 channel blocks", 160, 98, 1, 3, 1, 1, 0, 1, 16, 16, 128, true, -1);
+  conv("variant 96 patch conv 16x16 (3-stage weight ring), 2 channel blocks", 160, 96, 1, 3, 1, 1, 0, 1, 16, 16, 128, true, 98);
+  conv("variant 99 patch conv 16x16 (8-wave form), 2 channel blocks", 160, 99, 1, 3, 1, 1, 0, 1, 16, 16, 128, true, 98);
+  // the patch kernel that hands over through LDS progress words (95) against the barrier form (98)
+  conv("variant 95 patch conv 16x16, 2 channel blocks", 160, 95, 1, 3, 1, 1, 0, 1, 16, 16, 128, true, 98);
+  conv("variant 95 patch conv 16x16, one block (no successor), two samples", 160, 95, 1, 3, 1, 1, 0, 2, 16, 16, 64, false, 98);
+  int fails = 0, n = 0;
+  for (const auto& c : cases) {
+    if (argc > 1) {
+      bool hit = false;
+      for (int i = 1; i < argc; ++i) hit = hit || strstr(c.what, argv[i]);
+      if (!hit) continue;
+    }
+    fails += run_case(c);
+    ++n;
+  }
+  printf("%d cases, %d failed\n", n, fails);
+  return fails;
+}
