@@ -1,7 +1,8 @@
 #!/usr/bin/env python
-"""Build the CPU emulation of csrc/gemm_glds.hip (tools/cpu_emu/emu_gemm.cpp): write gemm_glds_emu.inc = the kernel file
-with its gfx950 inline-asm statements replaced by their C meaning, then compile for the host with clang++.
-usage: build.py [outdir]   (default /tmp/pfd_cpu_emu)  -> <outdir>/emu_gemm"""
+"""Build the CPU emulation of csrc/gemm_glds.hip and csrc/norm.hip (tools/cpu_emu/emu_gemm.cpp, emu_norm.cpp): write
+<file>_emu.inc = the kernel file with its gfx950 inline-asm statements replaced by their C meaning, then compile the
+drivers for the host with clang++.
+usage: build.py [outdir]   (default /tmp/pfd_cpu_emu)  -> <outdir>/emu_gemm, <outdir>/emu_norm"""
 import os
 import re
 import subprocess
@@ -17,6 +18,7 @@ SUBST = [
     (r'asm volatile\("s_waitcnt lgkmcnt\(0\)" ::: "memory"\);', 'emu::wave_sync();'),
     # register pins / opaque values
     (r'asm volatile\("" : "\+v"\(([^;]*?)\)\);', '((void)0);'),
+    (r'asm volatile\("" : "\+v"\(r\), "\+v"\(ch\)\);', '((void)0);'),
     (r'asm volatile\("" : "\+s"\(k\)::"memory"\);', '((void)0);'),
     # the uncounted activation load of gemm160ar_kernel
     (r'asm volatile\("global_load_dwordx4 %0, %1, off" : "=v"\(d\) : "v"\(\(const __attribute__\(\(address_space\(1\)\)\) void\*\)src\) : "memory"\);',
@@ -26,24 +28,27 @@ SUBST = [
 ]
 
 
+def preprocess(name, out, required=True):
+    src = open(os.path.join(CSRC, name + ".hip")).read()
+    for pat, rep in SUBST:
+        src, n = re.subn(pat, rep, src)
+    left = [l for l in src.splitlines() if "asm volatile" in l and 'asm volatile("" :::' not in l]
+    if left:
+        sys.exit(f"build.py: inline asm in {name}.hip the emulation does not translate:\n" + "\n".join(left))
+    with open(os.path.join(out, name + "_emu.inc"), "w") as f:
+        f.write(src)
+
+
 def main():
     out = sys.argv[1] if len(sys.argv) > 1 else "/tmp/pfd_cpu_emu"
     os.makedirs(out, exist_ok=True)
-    src = open(os.path.join(CSRC, "gemm_glds.hip")).read()
-    for pat, rep in SUBST:
-        src, n = re.subn(pat, rep, src)
-        if n == 0:
-            sys.exit(f"build.py: pattern not found any more: {pat}")
-    left = [l for l in src.splitlines() if "asm volatile" in l and 'asm volatile("" :::' not in l.replace("  ", " ")]
-    if left:
-        sys.exit("build.py: inline asm the emulation does not translate:\n" + "\n".join(left))
-    with open(os.path.join(out, "gemm_glds_emu.inc"), "w") as f:
-        f.write(src)
-    exe = os.path.join(out, "emu_gemm")
-    cmd = [CXX, "-std=c++17", "-O1", "-pthread", "-w", f"-I{HERE}", f"-I{out}", f"-I{REPO}/include", f"-I{CSRC}",
-           os.path.join(HERE, "emu_gemm.cpp"), "-o", exe]
-    subprocess.run(cmd, check=True)
-    print(exe)
+    for name, driver in (("gemm_glds", "emu_gemm"), ("norm", "emu_norm")):
+        preprocess(name, out)
+        exe = os.path.join(out, driver)
+        cmd = [CXX, "-std=c++17", "-O1", "-pthread", "-w", f"-I{HERE}", f"-I{out}", f"-I{REPO}/include", f"-I{CSRC}",
+               os.path.join(HERE, driver + ".cpp"), "-o", exe]
+        subprocess.run(cmd, check=True)
+        print(exe)
 
 
 if __name__ == "__main__":

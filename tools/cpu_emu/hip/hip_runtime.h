@@ -92,6 +92,7 @@ template <class T> static inline T max(T a, T b) { return a > b ? a : b; }
 static inline long min(long a, int b) { return a < b ? a : (long)b; }
 static inline long max(long a, int b) { return a > b ? a : (long)b; }
 static inline float rsqrtf(float x) { return 1.0f / sqrtf(x); }
+#define __expf(x) expf(x)   /* glibc declares (but does not export) __expf */
 
 template <class T> static inline T __shfl(T v, int src, int = 64) { return emu::exchange(v, src); }
 template <class T> static inline T __shfl_xor(T v, int mask, int = 64) { return emu::exchange(v, emu::lane() ^ mask); }
