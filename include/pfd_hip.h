@@ -326,6 +326,10 @@ int pfd_timestep_embedding_f16(const int64_t* t, void* out, int32_t B, int32_t d
 int pfd_cfg_ddim_step(const void* eps, int32_t nb, const float* x, const float* noise,
                       const float* coef, float* x_prev, float* pred_x0, void* xin_next, int32_t rep,
                       int32_t B, int32_t C, int32_t h, int32_t w, pfd_stream_t stream);
+/* Read `bytes` (ptr 16-byte aligned) and discard them: warms the memory-side cache / L2 for a launch that streams the same
+ * data shortly afterwards.  No counterpart in the reference (torch leaves weight residency to the hardware); used for the
+ * layer weights under PFD_WPREFETCH=1 (round-5 candidate, off by default).  No functional effect. */
+int pfd_prefetch(const void* ptr, size_t bytes, pfd_stream_t stream);
 /* y = a + b (f16, fp32 add), n elements; b may be NULL (copy). */
 int pfd_add_f16(const void* a, const void* b, void* y, int64_t n, pfd_stream_t stream);
 /* y = alpha*a + beta*b (f16 storage, fp32 math), n elements; b may be NULL (y = alpha*a).  The

@@ -80,6 +80,7 @@ SIGNATURES = {
     "pfd_im2col_f16": (_i32, [_vp, _i64, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
     "pfd_timestep_embedding_f16": (_i32, [_vp, _vp, _i32, _i32, _f32, _vp]),
     "pfd_cfg_ddim_step": (_i32, [_vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp]),
+    "pfd_prefetch": (_i32, [_vp, _sz, _vp]),
     "pfd_add_f16": (_i32, [_vp, _vp, _vp, _i64, _vp]),
     "pfd_axpby_f16": (_i32, [_vp, _f32, _vp, _f32, _vp, _i64, _vp]),
     "pfd_add_rowvec_f16": (_i32, [_vp, _i64, _vp, _vp, _i64, _i32, _i32, _vp]),

@@ -43,8 +43,76 @@ def serialised(fn):
     @functools.wraps(fn)
     def wrapper(*a, **k):
         with DEVICE_LOCK:
-            return fn(*a, **k)
+            try:
+                return fn(*a, **k)
+            finally:
+                if WPREFETCH:
+                    prefetch_join()
     return wrapper
+
+
+# ---- weight prefetch (round-5 candidate, PFD_WPREFETCH=1, default off, never run on hardware) ----
+# The weights of a UNet step (1.7 GB) pass through the 256 MB memory-side cache between two uses of a layer, so every weight
+# tile is an HBM miss when its GEMM asks for it, and the launches that fill the chip once are chains of such round trips
+# (round 1 measured them 40-60 % slower on cold weights than on warm ones).  With the switch on, gemm() / conv()
+# read their weight matrix on a side stream (pfd_prefetch: load and discard) as soon as the launch TWO GEMMs back has
+# finished, i.e. while the previous GEMM runs; the consumer itself does not wait for it.  Pure reads: no functional effect.
+# The side stream forks from and joins the current stream with events, which hipGraph capture records as parallel branches;
+# prefetch_join() must run before a capture ends (ddim.py / pipeline.py call it) and runs at the end of every public entry.
+WPREFETCH = os.environ.get("PFD_WPREFETCH", "0") == "1"
+_PF = threading.local()
+_PF_JOIN_EVERY = 32
+
+
+def _pf_state():
+    st = getattr(_PF, "st", None)
+    if st is None:
+        st = _PF.st = {"side": None, "marks": [], "last": None, "n": 0, "main": None}
+    return st
+
+
+def _prefetch_weights(w):
+    """enqueue the read of w on the side stream, gated on the completion of the launch two GEMMs back"""
+    st = _pf_state()
+    main = torch.cuda.current_stream()
+    if st["main"] is not None and st["main"] != main:
+        prefetch_join()                       # the caller switched streams: do not carry events across
+    st["main"] = main
+    if st["side"] is None or st["side"].device != w.device:
+        st["side"] = torch.cuda.Stream(device=w.device)
+    side = st["side"]
+    if len(st["marks"]) >= 2:
+        gate = st["marks"][-2]
+    else:                                     # first launches of a sequence: fork here
+        gate = torch.cuda.Event()
+        gate.record(main)
+    side.wait_event(gate)
+    _b.check(_lib().pfd_prefetch(w.data_ptr(), w.numel() * w.element_size(), side.cuda_stream), "pfd_prefetch")
+    done = torch.cuda.Event()
+    done.record(side)
+    st["last"] = done
+    st["n"] += 1
+    if st["n"] % _PF_JOIN_EVERY == 0:         # keep the fork shallow: this read was gated two launches back, it is long done
+        main.wait_event(done)
+        st["last"] = None
+
+
+def _prefetch_mark():
+    """after the consumer's launch: the event the prefetch two launches ahead will be gated on"""
+    st = _pf_state()
+    e = torch.cuda.Event()
+    e.record(torch.cuda.current_stream())
+    st["marks"] = (st["marks"] + [e])[-2:]
+
+
+def prefetch_join():
+    """the current stream waits for the outstanding prefetches; forget the events (they must not cross a capture boundary)"""
+    st = getattr(_PF, "st", None)
+    if st is None:
+        return
+    if st["last"] is not None:
+        torch.cuda.current_stream().wait_event(st["last"])
+    st["marks"], st["last"], st["main"] = [], None, None
 
 
 _WS = {}
@@ -277,8 +345,12 @@ def gemm(a, w, *, bias=None, rowvec=None, rows_per_rv=1, res=None, act=ACT_NONE,
     if _TRACE:
         _trace(d)
     lib = _lib()
+    if WPREFETCH:
+        _prefetch_weights(w)
     rc = lib.pfd_gemm_f16_ex(_byref(d), tile, _stream()) if tile else lib.pfd_gemm_f16(_byref(d), _stream())
     _b.check(rc, f"pfd_gemm_f16 M{M} N{N} K{K}")
+    if WPREFETCH:
+        _prefetch_mark()
     if gst is not None:
         set_gn_stats(out, gst)
     return out if stats is None else (out, stats)
@@ -359,8 +431,12 @@ def conv(x, w, ksize, *, stride=1, pad=None, ups=False, bias=None, rowvec=None, 
     if _TRACE:
         _trace(d)
     lib = _lib()
+    if WPREFETCH:
+        _prefetch_weights(w)
     rc = lib.pfd_gemm_f16_ex(_byref(d), tile, _stream()) if tile else lib.pfd_gemm_f16(_byref(d), _stream())
     _b.check(rc, f"pfd_gemm_f16(conv) M{M} N{N} K{K}" + (" with GroupNorm prologue" if gn is not None else ""))
+    if WPREFETCH:
+        _prefetch_mark()
     if gst is not None:
         set_gn_stats(out, gst)
     return out

@@ -6,6 +6,8 @@
 #   PFD_AREG=2   ... and variant 86 for 82 (short-K linears on >= 8192 rows: two blocks per CU, two K tiles in flight each)
 #   PFD_ATTN=7   d = 40 attention with s_setprio around the MFMA clusters
 #   PFD_GN_PAR=1 GroupNorm apply from producer statistics: the partials of eight slabs requested before the first add
+#   PFD_WPREFETCH=1  every GEMM / conv weight matrix is read on a side stream one launch ahead of its consumer (warm instead of
+#                    cold weight tiles for the latency-chain launches); parallel branches in the captured graph
 #   PFD_GN_SMALL_FAST=1  single-launch GroupNorm of the 8^2 / 16^2 levels without per-chunk divisions / gamma-beta round trips
 #   usage (on the GPU box): bash tools/r05_second_call.sh   -> gpurun_out/r05_e2e/
 set -u
@@ -23,9 +25,10 @@ for rep in 1 2; do
   run areg2_$rep PFD_AREG=2
   run attn7_$rep PFD_ATTN=7
   run gn_$rep PFD_GN_PAR=1 PFD_GN_SMALL_FAST=1
+  run wpf_$rep PFD_WPREFETCH=1
   run all_$rep PFD_AREG=1 PFD_ATTN=7 PFD_GN_PAR=1 PFD_GN_SMALL_FAST=1
 done
-for f in base_1 areg_1 areg2_1 attn7_1 gn_1 all_1 base_2 areg_2 areg2_2 attn7_2 gn_2 all_2; do python - <<P
+for f in base_1 areg_1 areg2_1 attn7_1 gn_1 wpf_1 all_1 base_2 areg_2 areg2_2 attn7_2 gn_2 wpf_2 all_2; do python - <<P
 import json
 try:
     d = json.load(open("$O/$f.json")); print("%-8s %7.1f ms per batch  %.3f images/s  loop %s" % ("$f", d["ms_per_step"], d["value"], d.get("stage_ms_per_batch", {}).get("ddim_loop_ms")))
