@@ -191,6 +191,9 @@ int main(int argc, char** argv) {
   // the LDS-ring kernels the register-operand ones must agree with (sanity of the emulation itself)
   lin("variant 23 (64x160, 4-stage LDS ring) 200x160x512", 200, 160, 512, 23, 1, true, -1);
   lin("variant 83 (128x160, 8 waves, 3-stage LDS ring) 200x160x320", 200, 160, 320, 83, 1, false, -1);
+  // 5-stage LDS rings (forced variants 26 / 46, never run on hardware either)
+  lin("variant 26 (64x160, 5-stage LDS ring) eleven steps", 200, 320, 704, 26, 1, true, 23);
+  lin("variant 46 (64x160 on 8 waves, 5-stage LDS ring) nine steps", 130, 160, 576, 46, 1, true, 43);
   // register-operand ring kernels (forced variants 27 / 45 / 85 / 29 / 86 / 28)
   lin("variant 27 one K step", 100, 160, 64, 27, 1, true, 23);
   lin("variant 27 seven steps = one trip round the ring", 130, 160, 448, 27, 1, true, 23);
