@@ -29,9 +29,9 @@ def emu(tmp_path_factory):
 def test_groupnorm_candidates_match_the_plain_kernels_bit_for_bit(emu):
     """csrc/norm.hip on the same emulation: PFD_GN_SMALL_FAST=1 and PFD_GN_PAR=1 (round-5 candidates, never run on hardware)
     against the plain kernels and a double-precision GroupNorm"""
-    r = subprocess.run([os.path.join(os.path.dirname(emu), "emu_norm")], capture_output=True, text=True, timeout=900)
+    r = subprocess.run([os.path.join(os.path.dirname(emu), "emu_norm"), "--quick"], capture_output=True, text=True, timeout=900)
     lines = [l for l in r.stdout.splitlines() if l.startswith(("ok", "FAIL"))]
-    assert r.returncode == 0 and len(lines) == 10, r.stdout[-3000:] + r.stderr[-1000:]
+    assert r.returncode == 0 and len(lines) == 5, r.stdout[-3000:] + r.stderr[-1000:]
     assert all(l.startswith("ok") and "== plain form bitwise" in l for l in lines), "\n".join(lines)
 
 

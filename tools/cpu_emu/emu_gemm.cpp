@@ -13,41 +13,6 @@
 
 #include "hip/hip_runtime.h"
 
-namespace emu {
-thread_local dim3 t_idx, b_idx;
-dim3 b_dim, g_dim;
-Block* cur = nullptr;
-const void* kernarg = nullptr;
-
-void launch(const std::function<void()>& body, dim3 grid, dim3 block, const void* arg0) {
-  const int nthr = (int)block.x, nw = (nthr + 63) / 64;
-  if (nthr % 64) { fprintf(stderr, "emu: block size %d is not a multiple of 64\n", nthr); abort(); }
-  b_dim = block;
-  g_dim = grid;
-  kernarg = arg0;
-  for (unsigned bz = 0; bz < grid.z; ++bz)
-    for (unsigned by = 0; by < grid.y; ++by)
-      for (unsigned bx = 0; bx < grid.x; ++bx) {
-        Block blk;
-        blk.waves = std::vector<Wave>(nw);
-        pthread_barrier_init(&blk.bar, nullptr, nthr);
-        for (auto& w : blk.waves) pthread_barrier_init(&w.bar, nullptr, 64);
-        cur = &blk;
-        std::vector<std::thread> th;
-        th.reserve(nthr);
-        for (int t = 0; t < nthr; ++t)
-          th.emplace_back([&, t]() {
-            t_idx = dim3(t, 0, 0);
-            b_idx = dim3(bx, by, bz);
-            body();
-          });
-        for (auto& x : th) x.join();
-        for (auto& w : blk.waves) pthread_barrier_destroy(&w.bar);
-        pthread_barrier_destroy(&blk.bar);
-        cur = nullptr;
-      }
-}
-}  // namespace emu
 
 // ---- what the kernel file expects from the rest of the library ----
 #include "pfd_common.h"

@@ -9,38 +9,6 @@
 
 #include "hip/hip_runtime.h"
 
-namespace emu {
-thread_local dim3 t_idx, b_idx;
-dim3 b_dim, g_dim;
-Block* cur = nullptr;
-const void* kernarg = nullptr;
-void launch(const std::function<void()>& body, dim3 grid, dim3 block, const void* arg0) {
-  const int nthr = (int)block.x, nw = (nthr + 63) / 64;
-  b_dim = block;
-  g_dim = grid;
-  kernarg = arg0;
-  for (unsigned bz = 0; bz < grid.z; ++bz)
-    for (unsigned by = 0; by < grid.y; ++by)
-      for (unsigned bx = 0; bx < grid.x; ++bx) {
-        Block blk;
-        blk.waves = std::vector<Wave>(nw);
-        pthread_barrier_init(&blk.bar, nullptr, nthr);
-        for (auto& w : blk.waves) pthread_barrier_init(&w.bar, nullptr, 64);
-        cur = &blk;
-        std::vector<std::thread> th;
-        for (int t = 0; t < nthr; ++t)
-          th.emplace_back([&, t]() {
-            t_idx = dim3(t, 0, 0);
-            b_idx = dim3(bx, by, bz);
-            body();
-          });
-        for (auto& x : th) x.join();
-        for (auto& w : blk.waves) pthread_barrier_destroy(&w.bar);
-        pthread_barrier_destroy(&blk.bar);
-        cur = nullptr;
-      }
-}
-}  // namespace emu
 
 #include "pfd_common.h"
 bool pfd_prof_on() { return false; }
@@ -146,17 +114,22 @@ static void pstats_case(int B, int HW, int C1, int C2, int act) {
   check(name, y2, gn_ref(x1, x2, gm, bt, B, HW, C1, C2, G, 1e-5f, act), &y, "plain form");
 }
 
-int main() {
+int main(int argc, char** argv) {
+  const bool quick = argc > 1 && !strcmp(argv[1], "--quick");   // the CPU suite's subset
   small_case(8, 64, 1280, 0, PFD_ACT_SILU);      // 8^2: 640 chunks per group slab, 3 slots per thread
-  small_case(4, 256, 1280, 0, PFD_ACT_SILU);     // 16^2 (B x G = 128): 2560 chunks
   small_case(4, 64, 1280, 1280, PFD_ACT_NONE);   // skip concat, cpg 80
   small_case(4, 100, 1408, 0, PFD_ACT_SILU);     // cpg 44, cpr 11 (carries in the index walk), ragged HW
-  small_case(4, 64, 1024, 0, PFD_ACT_SILU);      // cpg 32, cpr 8: no carries
-  small_case(4, 64, 1280, 640, PFD_ACT_SILU);    // cpg 60 straddles the two sources: the plain form both times
+  if (!quick) {
+    small_case(4, 256, 1280, 0, PFD_ACT_SILU);   // 16^2 (B x G = 128): 2560 chunks
+    small_case(4, 64, 1024, 0, PFD_ACT_SILU);    // cpg 32, cpr 8: no carries
+    small_case(4, 64, 1280, 640, PFD_ACT_SILU);  // cpg 60 straddles the two sources: the plain form both times
+  }
   pstats_case(1, 4096, 320, 0, PFD_ACT_SILU);    // 64^2: 64 slabs, 8 per thread
   pstats_case(1, 1024, 320, 320, PFD_ACT_SILU);  // skip concat: two producer groups per group
-  pstats_case(1, 4608, 320, 0, PFD_ACT_NONE);    // 72 slabs: a second trip of the chunked fold
-  pstats_case(2, 256, 640, 0, PFD_ACT_SILU);     // 4 slabs, six clamped slots
+  if (!quick) {
+    pstats_case(1, 4608, 320, 0, PFD_ACT_NONE);  // 72 slabs: a second trip of the chunked fold
+    pstats_case(2, 256, 640, 0, PFD_ACT_SILU);   // 4 slabs, six clamped slots
+  }
   printf("%d cases, %d failed\n", g_total, g_fail);
   return g_fail;
 }

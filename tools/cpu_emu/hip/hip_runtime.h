@@ -11,6 +11,7 @@
 #define PFD_CPU_EMU 1
 #include <pthread.h>
 #include <stdint.h>
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -51,15 +52,45 @@ struct Block {
   pthread_barrier_t bar;
   std::vector<Wave> waves;
 };
-extern thread_local dim3 t_idx, b_idx;
-extern dim3 b_dim, g_dim;
-extern Block* cur;
-extern const void* kernarg;
+inline thread_local dim3 t_idx, b_idx;
+inline dim3 b_dim, g_dim;
+inline Block* cur = nullptr;
+inline const void* kernarg = nullptr;
 inline int lane() { return t_idx.x & 63; }
 inline Wave& wave() { return cur->waves[t_idx.x >> 6]; }
 inline void wave_sync() { pthread_barrier_wait(&wave().bar); }
 inline void block_sync() { pthread_barrier_wait(&cur->bar); }
-void launch(const std::function<void()>& body, dim3 grid, dim3 block, const void* arg0);
+// one team of block.x OS threads per launch walks the blocks of the grid one after another (a block barrier between two
+// blocks keeps them sequential: the __shared__ statics are the CU's LDS, reused by the next block as on the device)
+inline void launch(const std::function<void()>& body, dim3 grid, dim3 block, const void* arg0) {
+  const int nthr = (int)block.x, nw = (nthr + 63) / 64;
+  if (nthr % 64) { fprintf(stderr, "emu: block size %d is not a multiple of 64\n", nthr); abort(); }
+  b_dim = block;
+  g_dim = grid;
+  kernarg = arg0;
+  Block blk;
+  blk.waves = std::vector<Wave>(nw);
+  pthread_barrier_init(&blk.bar, nullptr, nthr);
+  for (auto& w : blk.waves) pthread_barrier_init(&w.bar, nullptr, 64);
+  cur = &blk;
+  std::vector<std::thread> th;
+  th.reserve(nthr);
+  for (int t = 0; t < nthr; ++t)
+    th.emplace_back([&, t]() {
+      t_idx = dim3(t, 0, 0);
+      for (unsigned bz = 0; bz < grid.z; ++bz)
+        for (unsigned by = 0; by < grid.y; ++by)
+          for (unsigned bx = 0; bx < grid.x; ++bx) {
+            b_idx = dim3(bx, by, bz);
+            body();
+            pthread_barrier_wait(&blk.bar);
+          }
+    });
+  for (auto& x : th) x.join();
+  for (auto& w : blk.waves) pthread_barrier_destroy(&w.bar);
+  pthread_barrier_destroy(&blk.bar);
+  cur = nullptr;
+}
 template <class T>
 inline T exchange(T v, int src) {   // every lane of the wave calls this; returns lane src's value
   static_assert(sizeof(T) <= 8, "exchange");
