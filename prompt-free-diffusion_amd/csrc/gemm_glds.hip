@@ -2360,10 +2360,11 @@ inline bool ws_ring_on() {
   return on;
 }
 
-// PFD_AREG=1: the automatic choice takes the register-operand ring kernels (variants 27 / 45 / 85) wherever it picked the
-// LDS-ring ones (23 / 43 / 83).  Default off: the kernels have not run on hardware yet (round-5 candidates)
-// PFD_AREG=2: additionally 86 / 28 (two blocks per CU, two K tiles in flight each) wherever the rules picked the 2-stage
-// 128-row tile on 8 waves (82) / the 2-stage 64-row tile on 4 waves (22) for a linear layer.
+// PFD_AREG=<bit mask>: the automatic choice takes a register-operand kernel wherever it picked its LDS counterpart --
+//   1: 23 -> 27 (64 x 160 ring, 4 waves)   2: 43 -> 45 (64 x 160 ring, 8 waves)   4: 83 -> 85 (128 x 160 ring, 8 waves)
+//   8: 82 -> 86 (2-stage 128-row tile -> 3 weight stages, two blocks per CU; linears)   16: 22 -> 28 (the same for the 64-row tile)
+// 7 = the ring family, 31 = everything.  Default 0: the kernels have not run on hardware yet (round-5 candidates); adopting a
+// winner is a change of this default.
 inline int areg_mode() {
   static const int m = getenv("PFD_AREG") ? atoi(getenv("PFD_AREG")) : 0;
   return m;
@@ -2692,11 +2693,13 @@ int pfd_gemm160_try(const PfdGemmDesc* d, int variant, int splits, hipStream_t s
     if (variant == 82 && (p.ksize == 0 || (p.stride == 1 && !p.ups)) && tiles(128) <= 256 && nk_split >= 6) variant = 83;
   }
   const int conv = p.ksize > 0 ? 1 : 0;
-  // PFD_AREG=1 (default off; round-5 end-to-end A/B): the ring kernels the rules above picked are replaced by their
-  // register-operand forms -- same tiles, same split counts, same bits (selftest --r5)
-  if (auto_variant && bn == 160 && areg_mode() >= 1)
-    variant = variant == 23 ? 27 : variant == 43 ? 45 : variant == 83 ? 85 : (variant == 82 && areg_mode() >= 2 && !conv) ? 86
-              : (variant == 22 && areg_mode() >= 2 && !conv) ? 28 : variant;
+  // PFD_AREG=<mask> (default 0; round-5 end-to-end A/B): the kernels the rules above picked are replaced by their
+  // register-operand forms -- same tiles, same split counts, same bits (selftest --r5, tests/test_cpu_emulation.py)
+  if (auto_variant && bn == 160 && areg_mode() != 0) {
+    const int am = areg_mode();
+    variant = (variant == 23 && (am & 1)) ? 27 : (variant == 43 && (am & 2)) ? 45 : (variant == 83 && (am & 4)) ? 85
+              : (variant == 82 && (am & 8) && !conv) ? 86 : (variant == 22 && (am & 16) && !conv) ? 28 : variant;
+  }
   if ((variant == 27 || variant == 45 || variant == 85 || variant == 86 || variant == 28 || variant == 29) && bn != 160) return 1;   // 160-wide tiles only
   if (variant == 48 || variant == 49 || variant == 47) {   // 8 MFMA waves + 4 loader waves (49: ping-pong consumer groups, 47: 3-stage ring)
     const int mode = variant == 49 ? 1 : variant == 47 ? 2 : 0;

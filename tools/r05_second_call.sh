@@ -2,8 +2,8 @@
 # Second GPU call of the next round (prepared at the end of round 4, never run) -- ONLY after tools/r05_first_call.sh showed
 # `selftest --r5` green: end-to-end A/B of the candidates that have an environment switch, alternating on ONE box
 # (boxes differ by +-8 %), then the parity suites under the winning switches.
-#   PFD_AREG=1   ring kernels with the activation fragments in registers (variants 27 / 45 / 85 for 23 / 43 / 83)
-#   PFD_AREG=2   ... and variant 86 for 82 (short-K linears on >= 8192 rows: two blocks per CU, two K tiles in flight each)
+#   PFD_AREG=7   ring kernels with the activation fragments in registers (bit mask: 1 = 27 for 23, 2 = 45 for 43, 4 = 85 for 83)
+#   PFD_AREG=31  ... and 86 for 82 (8), 28 for 22 (16): the 2-stage tiles -> 3 weight stages, two blocks per CU, two K tiles in flight each
 #   PFD_ATTN=7   d = 40 attention with s_setprio around the MFMA clusters
 #   PFD_GN_PAR=1 GroupNorm apply from producer statistics: the partials of eight slabs requested before the first add
 #   PFD_WPREFETCH=1  every GEMM / conv weight matrix is read on a side stream one launch ahead of its consumer (warm instead of
@@ -21,12 +21,12 @@ run() {   # run <tag> <env assignments...>
 }
 for rep in 1 2; do
   run base_$rep PFD_AREG=0
-  run areg_$rep PFD_AREG=1
-  run areg2_$rep PFD_AREG=2
+  run areg_$rep PFD_AREG=7
+  run areg2_$rep PFD_AREG=31
   run attn7_$rep PFD_ATTN=7
   run gn_$rep PFD_GN_PAR=1 PFD_GN_SMALL_FAST=1
   run wpf_$rep PFD_WPREFETCH=1
-  run all_$rep PFD_AREG=1 PFD_ATTN=7 PFD_GN_PAR=1 PFD_GN_SMALL_FAST=1
+  run all_$rep PFD_AREG=31 PFD_ATTN=7 PFD_GN_PAR=1 PFD_GN_SMALL_FAST=1
 done
 for f in base_1 areg_1 areg2_1 attn7_1 gn_1 wpf_1 all_1 base_2 areg_2 areg2_2 attn7_2 gn_2 wpf_2 all_2; do python - <<P
 import json
@@ -37,7 +37,7 @@ except Exception as e:
 P
 done
 # parity under the switches (kernel-level suite + the C2 trajectory on the fixture-backed oracle)
-PFD_AREG=1 PFD_ATTN=7 PFD_GN_PAR=1 PFD_GN_SMALL_FAST=1 timeout 400 python -m pytest tests/test_hip_parity.py tests/test_hip_kernels_fullsize.py -m gpu -q -x > $O/pytest_switches.log 2>&1
+PFD_AREG=31 PFD_ATTN=7 PFD_GN_PAR=1 PFD_GN_SMALL_FAST=1 timeout 400 python -m pytest tests/test_hip_parity.py tests/test_hip_kernels_fullsize.py -m gpu -q -x > $O/pytest_switches.log 2>&1
 echo "pytest (all four switches) rc=$? after $(( $(date +%s) - T0 )) s"; tail -3 $O/pytest_switches.log
-PFD_AREG=1 PFD_ATTN=7 PFD_GN_PAR=1 PFD_GN_SMALL_FAST=1 timeout 200 python -m pytest tests/test_hip_trajectory.py -m gpu -q -s -x -k c2 > $O/pytest_trajectory_switches.log 2>&1
+PFD_AREG=31 PFD_ATTN=7 PFD_GN_PAR=1 PFD_GN_SMALL_FAST=1 timeout 200 python -m pytest tests/test_hip_trajectory.py -m gpu -q -s -x -k c2 > $O/pytest_trajectory_switches.log 2>&1
 echo "pytest trajectory rc=$? after $(( $(date +%s) - T0 )) s"; tail -3 $O/pytest_trajectory_switches.log
