@@ -1,8 +1,8 @@
 #!/usr/bin/env python
-"""Build the CPU emulation of csrc/gemm_glds.hip and csrc/norm.hip (tools/cpu_emu/emu_gemm.cpp, emu_norm.cpp): write
+"""Build the CPU emulation of csrc/gemm_glds.hip, csrc/norm.hip and csrc/attention.hip (tools/cpu_emu/emu_*.cpp): write
 <file>_emu.inc = the kernel file with its gfx950 inline-asm statements replaced by their C meaning, then compile the
 drivers for the host with clang++.
-usage: build.py [outdir]   (default /tmp/pfd_cpu_emu)  -> <outdir>/emu_gemm, <outdir>/emu_norm"""
+usage: build.py [outdir]   (default /tmp/pfd_cpu_emu)  -> <outdir>/emu_gemm, <outdir>/emu_norm, <outdir>/emu_attn"""
 import os
 import re
 import subprocess
@@ -42,7 +42,7 @@ def preprocess(name, out, required=True):
 def main():
     out = sys.argv[1] if len(sys.argv) > 1 else "/tmp/pfd_cpu_emu"
     os.makedirs(out, exist_ok=True)
-    for name, driver in (("gemm_glds", "emu_gemm"), ("norm", "emu_norm")):
+    for name, driver in (("gemm_glds", "emu_gemm"), ("norm", "emu_norm"), ("attention", "emu_attn")):
         preprocess(name, out)
         exe = os.path.join(out, driver)
         cmd = [CXX, "-std=c++17", "-O1", "-pthread", "-w", f"-I{HERE}", f"-I{out}", f"-I{REPO}/include", f"-I{CSRC}",

@@ -1,0 +1,92 @@
+// CPU emulation of csrc/attention.hip (see hip/hip_runtime.h): the fused attention kernels against a double-precision
+// softmax(scale Q K^T) V, and the kernel stages of PFD_ATTN against each other -- mode 7 (round-5 candidate: s_setprio
+// around the MFMA clusters, never run on hardware) must give the bits of mode 6.
+//   usage: emu_attn <mode> [--quick]     (the mode is read once per process by the library: one process per mode;
+//   prints one line per case with a checksum of the output bits, which the caller compares between modes)
+#include <stdio.h>
+
+#include <random>
+#include <string>
+
+#include "hip/hip_runtime.h"
+#include "pfd_common.h"
+bool pfd_prof_on() { return false; }
+void pfd_prof_begin(int, double, double, hipStream_t) {}
+void pfd_prof_end(hipStream_t) {}
+int pfd_check_launch(const char*) { return 0; }
+void pfd_set_error(const char*) {}
+
+#include "attention_emu.inc"
+
+typedef _Float16 h16;
+static std::mt19937 rng(11);
+static std::vector<h16> rand_h(size_t n, float scale) {
+  std::uniform_real_distribution<float> d(-1.f, 1.f);
+  std::vector<h16> v(n);
+  for (auto& x : v) x = (h16)(d(rng) * scale);
+  return v;
+}
+static int g_fail = 0, g_total = 0;
+
+static void run_case(int B, int H, int Nq, int Nk, int D) {
+  const int C = H * D;
+  const long nkp = (Nk + 7) / 8 * 8;
+  auto Q = rand_h((size_t)B * Nq * C, 1.5f), K = rand_h((size_t)B * Nk * C, 1.5f), V = rand_h((size_t)B * Nk * C, 1.f);
+  std::vector<h16> Vt((size_t)C * B * nkp, (h16)0.f), O((size_t)B * Nq * C, (h16)-9.f);
+  for (int b = 0; b < B; ++b)
+    for (int j = 0; j < Nk; ++j)
+      for (int c = 0; c < C; ++c) Vt[(size_t)c * B * nkp + (size_t)b * nkp + j] = V[((size_t)b * Nk + j) * C + c];
+  PfdAttnDesc d;
+  memset(&d, 0, sizeof(d));
+  d.Q = Q.data(); d.K = K.data(); d.Vt = Vt.data(); d.O = O.data();
+  d.ldq = C; d.ldk = C; d.ldo = C; d.ldvt = (long)B * nkp;
+  d.q_bs = (long)Nq * C; d.k_bs = (long)Nk * C; d.o_bs = (long)Nq * C; d.vt_bs = nkp;
+  d.B = B; d.H = H; d.Nq = Nq; d.Nk = Nk; d.D = D;
+  d.scale = 1.0f / sqrtf((float)D);
+  const int rc = pfd_attention_f16(&d, nullptr);
+  double me = 0, mr = 0;
+  std::vector<double> s(Nk);
+  for (int b = 0; b < B && rc == 0; ++b)
+    for (int h = 0; h < H; ++h)
+      for (int i = 0; i < Nq; ++i) {
+        double mx = -1e300;
+        for (int j = 0; j < Nk; ++j) {
+          double a = 0;
+          for (int e = 0; e < D; ++e) a += (double)Q[((size_t)b * Nq + i) * C + h * D + e] * (double)K[((size_t)b * Nk + j) * C + h * D + e];
+          s[j] = a * d.scale;
+          mx = std::max(mx, s[j]);
+        }
+        double den = 0;
+        for (int j = 0; j < Nk; ++j) { s[j] = exp(s[j] - mx); den += s[j]; }
+        for (int e = 0; e < D; ++e) {
+          double o = 0;
+          for (int j = 0; j < Nk; ++j) o += s[j] * (double)V[((size_t)b * Nk + j) * C + h * D + e];
+          o /= den;
+          mr = std::max(mr, fabs(o));
+          me = std::max(me, fabs(o - (double)O[((size_t)b * Nq + i) * C + h * D + e]));
+        }
+      }
+  uint64_t sum = 1469598103934665603ull;   // FNV-1a over the output bits
+  for (auto& x : O) { unsigned short u; memcpy(&u, &x, 2); sum = (sum ^ u) * 1099511628211ull; }
+  const bool ok = rc == 0 && me <= 4e-3 * std::max(1.0, mr);
+  ++g_total;
+  g_fail += !ok;
+  printf("%s attention B%d H%d Nq%d Nk%d D%d  rc %d  max err %.2e (max |ref| %.2f)  bits %016llx\n", ok ? "ok  " : "FAIL", B, H, Nq, Nk, D, rc, me,
+         mr, (unsigned long long)sum);
+  fflush(stdout);
+}
+
+int main(int argc, char** argv) {
+  const bool quick = argc > 2 && !strcmp(argv[2], "--quick");
+  if (argc > 1) setenv("PFD_ATTN", argv[1], 1);
+  setenv("PFD_ATTN_FORCE8", "1", 1);      // the 8-wave d = 40 form at these (small) sizes
+  run_case(1, 2, 300, 200, 40);           // ragged queries and keys, 4 KV tiles (3 full + 1 peeled)
+  run_case(1, 1, 256, 148, 40);           // the cross-attention length (148 context tokens)
+  if (!quick) {
+    run_case(2, 1, 64, 64, 160);          // 8^2 level
+    run_case(1, 1, 100, 77, 80);
+    run_case(1, 1, 130, 96, 96);          // SeeCoder
+  }
+  printf("%d cases, %d failed\n", g_total, g_fail);
+  return g_fail;
+}

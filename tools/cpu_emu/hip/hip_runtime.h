@@ -153,6 +153,8 @@ static inline uint64_t emu_ballot(bool p) {
   return m;
 }
 #define __builtin_amdgcn_ballot_w64(p) emu_ballot(p)
+static inline int __any(int p) { return emu_ballot(p != 0) != 0; }
+static inline int __all(int p) { return emu_ballot(p != 0) == ~0ull; }
 
 // LDS-DMA: lane l's 16 bytes go to (wave-uniform destination) + 16 l
 static inline void emu_global_load_lds(const void* src, void* dst, int bytes, int, int) {
@@ -185,3 +187,49 @@ static inline emu_f4 emu_mfma_16x16x32_f16(emu_h8 a, emu_h8 b, emu_f4 c) {
   return d;
 }
 #define __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, x, y, z) emu_mfma_16x16x32_f16(a, b, c)
+
+// v_mfma_f32_32x32x16_f16: lane l holds 8 consecutive k (group l >> 5) of row (A) / column (B) l & 31; D / C as
+// col = l & 31, row = (r & 3) + 8 (r >> 2) + 4 (l >> 5), r in [0, 16)  (pfd_common.h mfma32_row, guide section 3)
+typedef float emu_f16v __attribute__((ext_vector_type(16)));
+static inline emu_f16v emu_mfma_32x32x16_f16(emu_h8 a, emu_h8 b, emu_f16v c) {
+  emu::Wave& w = emu::wave();
+  const int l = emu::lane();
+  for (int e = 0; e < 8; ++e) {
+    w.a[l][e] = a[e];
+    w.b[l][e] = b[e];
+  }
+  emu::wave_sync();
+  emu_f16v d;
+  const int j = l & 31, hi = l >> 5;
+  for (int r = 0; r < 16; ++r) {
+    const int i = (r & 3) + 8 * (r >> 2) + 4 * hi;
+    float s = c[r];
+    for (int g = 0; g < 2; ++g)
+      for (int e = 0; e < 8; ++e) s += (float)w.a[i + 32 * g][e] * (float)w.b[j + 32 * g][e];
+    d[r] = s;
+  }
+  emu::wave_sync();
+  return d;
+}
+#define __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, x, y, z) emu_mfma_32x32x16_f16(a, b, c)
+
+// v_permlane16_swap: the odd 16-lane rows of the first operand trade places with the even rows of the second
+// ({a', b'}: a' = a.row0 b.row0 a.row2 b.row2, b' = a.row1 b.row1 a.row3 b.row3)
+struct emu_u2 {
+  unsigned v[2];
+  unsigned operator[](int i) const { return v[i]; }
+};
+static inline emu_u2 emu_permlane16_swap(unsigned a, unsigned b) {
+  emu::Wave& w = emu::wave();
+  const int l = emu::lane(), row = l >> 4, pos = l & 15;
+  w.slot[l] = ((uint64_t)b << 32) | a;
+  emu::wave_sync();
+  auto A = [&](int lane) { return (unsigned)(w.slot[lane] & 0xffffffffu); };
+  auto B = [&](int lane) { return (unsigned)(w.slot[lane] >> 32); };
+  emu_u2 r;
+  r.v[0] = (row & 1) ? B((row - 1) * 16 + pos) : A(l);
+  r.v[1] = (row & 1) ? B(l) : A((row + 1) * 16 + pos);
+  emu::wave_sync();
+  return r;
+}
+#define __builtin_amdgcn_permlane16_swap(a, b, fi, bc) emu_permlane16_swap(a, b)
