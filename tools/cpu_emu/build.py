@@ -42,12 +42,16 @@ def preprocess(name, out, required=True):
 def main():
     out = sys.argv[1] if len(sys.argv) > 1 else "/tmp/pfd_cpu_emu"
     os.makedirs(out, exist_ok=True)
+    procs = []
     for name, driver in (("gemm_glds", "emu_gemm"), ("norm", "emu_norm"), ("attention", "emu_attn")):
         preprocess(name, out)
         exe = os.path.join(out, driver)
         cmd = [CXX, "-std=c++17", "-O1", "-pthread", "-w", f"-I{HERE}", f"-I{out}", f"-I{REPO}/include", f"-I{CSRC}",
                os.path.join(HERE, driver + ".cpp"), "-o", exe]
-        subprocess.run(cmd, check=True)
+        procs.append((exe, cmd, subprocess.Popen(cmd)))     # the three drivers compile side by side
+    for exe, cmd, p in procs:
+        if p.wait() != 0:
+            sys.exit("build.py: " + " ".join(cmd) + " failed")
         print(exe)
 
 
