@@ -72,3 +72,17 @@ def test_attention_kernels_and_the_setprio_candidate(emu):
         out[mode] = [l.split()[-1] for l in lines]
     assert len(out["6"]) == 5 and len(out["7"]) == 2
     assert out["7"] == out["6"][:2]
+
+
+def test_areg_mask_redirects_the_automatic_choice(emu):
+    """PFD_AREG=<mask>: the automatic tile choice launches the register-operand kernel exactly where the mask says (ring picks:
+    bits 1 / 2 / 4, two-stage picks: bits 8 / 16) and the LDS kernels otherwise (default 0)"""
+    def picks(mask):
+        env = dict(os.environ, PFD_AREG=str(mask))
+        r = subprocess.run([emu, "--auto"], capture_output=True, text=True, timeout=600, env=env)
+        assert r.returncode == 0, r.stdout + r.stderr
+        return {l.split()[1]: "gemm160ar_kernel" in l for l in r.stdout.splitlines() if l.startswith("auto")}
+    assert picks(0) == {"ring23": False, "ring83": False, "two-stage22": False, "two-stage82": False}
+    assert picks(31) == {"ring23": True, "ring83": True, "two-stage22": True, "two-stage82": True}
+    assert picks(7) == {"ring23": True, "ring83": True, "two-stage22": False, "two-stage82": False}
+    assert picks(24) == {"ring23": False, "ring83": False, "two-stage22": True, "two-stage82": True}

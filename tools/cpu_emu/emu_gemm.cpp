@@ -144,7 +144,25 @@ static int run_case(const Case& c) {
   return fails;
 }
 
+// --auto: which kernel the AUTOMATIC choice (variant 0) launches for a few small problems under the current environment
+// (PFD_AREG=<mask> must turn the ring / 2-stage picks into their register-operand forms, and only those)
+static int auto_map() {
+  struct P { const char* what; int M, N, K; };
+  const P ps[] = {{"ring23", 130, 160, 576}, {"ring83", 2100, 160, 576}, {"two-stage22", 700, 320, 320}, {"two-stage82", 9000, 160, 320}};
+  for (const auto& q : ps) {
+    Case c{q.what, q.M, q.N, q.K, 0, 0};
+    auto A = rand_h((size_t)q.M * q.K + 64, 1.f), W = rand_h((size_t)q.N * q.K, 0.1f), b = rand_h(q.N, 0.5f), rv = b, R = b, A2 = b;
+    std::vector<h16> C((size_t)q.M * q.N);
+    std::vector<float> ws((size_t)8 * q.M * q.N + 64);
+    emu::launched.clear();
+    const int rc = run_variant(c, 0, A, A2, W, b, rv, R, q.M, q.K, 0, 0, C, ws);
+    printf("auto %-12s rc %d -> %s\n", q.what, rc, emu::launched.empty() ? "(nothing)" : emu::launched[0].c_str());
+  }
+  return 0;
+}
+
 int main(int argc, char** argv) {
+  if (argc > 1 && !strcmp(argv[1], "--auto")) return auto_map();
   std::vector<Case> cases;
   auto lin = [&](const char* w, int M, int N, int K, int v, int sp, bool res, int base) {
     Case c{w, M, N, K, v, sp}; c.res = res; c.base_variant = base; cases.push_back(c); return &cases.back();

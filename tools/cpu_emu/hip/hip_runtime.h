@@ -18,6 +18,7 @@
 #include <algorithm>
 #include <cmath>
 #include <functional>
+#include <string>
 #include <thread>
 #include <vector>
 
@@ -56,6 +57,7 @@ inline thread_local dim3 t_idx, b_idx;
 inline dim3 b_dim, g_dim;
 inline Block* cur = nullptr;
 inline const void* kernarg = nullptr;
+inline std::vector<std::string> launched;   // the kernel expression of every launch, in order (hipLaunchKernelGGL's first argument)
 inline int lane() { return t_idx.x & 63; }
 inline Wave& wave() { return cur->waves[t_idx.x >> 6]; }
 inline void wave_sync() { pthread_barrier_wait(&wave().bar); }
@@ -115,6 +117,7 @@ inline T exchange(T v, int src) {   // every lane of the wave calls this; return
 #define hipLaunchKernelGGL(kernel, grid, block, shmem, stream, ...)                                      \
   do {                                                                                                    \
     auto emu_arg0 = EMU_FIRST(__VA_ARGS__);                                                               \
+    emu::launched.push_back(#kernel);                                                                     \
     emu::launch([&]() { kernel(__VA_ARGS__); }, grid, block, &emu_arg0);                                  \
   } while (0)
 
