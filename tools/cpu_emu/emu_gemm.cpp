@@ -147,6 +147,7 @@ static int run_case(const Case& c) {
 // --auto: which kernel the AUTOMATIC choice (variant 0) launches for a few small problems under the current environment
 // (PFD_AREG=<mask> must turn the ring / 2-stage picks into their register-operand forms, and only those)
 static int auto_map() {
+  emu::dry_run = true;   // the choice is made on the host: nothing has to run
   struct P { const char* what; int M, N, K; };
   const P ps[] = {{"ring23", 130, 160, 576}, {"ring83", 2100, 160, 576}, {"two-stage22", 700, 320, 320}, {"two-stage82", 9000, 160, 320}};
   for (const auto& q : ps) {

@@ -57,6 +57,7 @@ inline thread_local dim3 t_idx, b_idx;
 inline dim3 b_dim, g_dim;
 inline Block* cur = nullptr;
 inline const void* kernarg = nullptr;
+inline bool dry_run = false;                // record the launches, do not execute them
 inline std::vector<std::string> launched;   // the kernel expression of every launch, in order (hipLaunchKernelGGL's first argument)
 inline int lane() { return t_idx.x & 63; }
 inline Wave& wave() { return cur->waves[t_idx.x >> 6]; }
@@ -65,6 +66,7 @@ inline void block_sync() { pthread_barrier_wait(&cur->bar); }
 // one team of block.x OS threads per launch walks the blocks of the grid one after another (a block barrier between two
 // blocks keeps them sequential: the __shared__ statics are the CU's LDS, reused by the next block as on the device)
 inline void launch(const std::function<void()>& body, dim3 grid, dim3 block, const void* arg0) {
+  if (dry_run) return;
   const int nthr = (int)block.x, nw = (nthr + 63) / 64;
   if (nthr % 64) { fprintf(stderr, "emu: block size %d is not a multiple of 64\n", nthr); abort(); }
   b_dim = block;
