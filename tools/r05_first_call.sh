@@ -2,8 +2,10 @@
 # First GPU call of the next round (prepared at the end of round 4, never run): correctness of the forced-only candidates --
 # 5-stage ring variants (26 = 64x160 on 4 waves, 46 = on 8 waves), the linear ring kernels whose activation fragments stay in
 # registers with the weights alone on a 7-stage LDS ring (27 = 64x160 on 4 waves, 45 = on 8 waves, 85 = 128x160 on 8 waves:
-# 6 K tiles in flight instead of 3 / 2) and the patch kernel that hands over through LDS counters instead of a barrier per
-# tap (95; every poll is bounded, a protocol error shows as a FAIL, not a hang) -- under a short
+# 6 K tiles in flight instead of 3 / 2; 29 = 27 at the depth of 26; 86 / 28 = the 2-stage tiles 82 / 22 with 3 weight stages and
+# two blocks per CU) and the patch kernel that hands over through per-wave progress words in LDS instead of a barrier per
+# tap (95; every poll is bounded, a protocol error shows as a FAIL, not a hang).  All of them are bit-identical to the kernels
+# they would replace on the CPU emulation (tests/test_cpu_emulation.py); `selftest --r5` is the hardware confirmation, under a
 # timeout FIRST, then their per-problem A/B on the cold replay of the C2 launch list
 # (tile code 1000 + 100 * variant: a launch the forced variant does not serve falls back to the automatic choice).
 #   usage (on the GPU box): bash tools/r05_first_call.sh   -> gpurun_out/r05_ring5/
@@ -18,7 +20,7 @@ for rep in 1 2; do
   done
 done
 for rep in 1 2; do
-  for t in 10800 10500; do               # patch kernel: 98 = barrier per tap with two weight stages (the like-for-like base), 95 = LDS counters
+  for t in 10800 10500; do               # patch kernel: 98 = barrier per tap with two weight stages (the like-for-like base), 95 = progress words in LDS
     timeout 60 $S --replay-time $L $t > $O/replay_t${t}_$rep.log 2>&1; echo "tile $t run $rep: $(tail -1 $O/replay_t${t}_$rep.log)"
   done
 done
