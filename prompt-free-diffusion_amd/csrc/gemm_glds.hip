@@ -2310,10 +2310,93 @@ __global__ __launch_bounds__(256) void splitk_reduce_gn_kernel(const G160Params 
   gn_slab_reduce<1, 256>(cs, cq, tid, p.N / 32, slab, p.M / GN_SLAB, tiles_n, tile_n, p.gn_out, [&](int) { return red; });
 }
 
+// Round-5 candidate (PFD_GN_PAR=1, default off, never run on hardware): the same reduction with the loads of THREE row sweeps
+// requested before the first add.  The plain kernel walks its 64-row slab in six sweeps of 12 rows, each a dependent
+// round trip (row vector / residual / 4-8 slab slices -> wait -> add -> store): 14.7 us per launch for 2-10 MB at the
+// 8^2 / 16^2 levels, where the grid is 64-256 blocks of four waves.  Same slab order per element, same order of the rows in
+// the statistics: bit-identical (tools/cpu_emu checks).  Up to 8 splits x 3 sweeps x 32 bytes = 96 + 24 VGPRs of loads.
+__global__ __launch_bounds__(256) void splitk_reduce_gn_par_kernel(const G160Params p) {
+  __shared__ __attribute__((aligned(16))) float red[5 * 320];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int tiles_n = p.N / 160;
+  const int slab = blockIdx.x / tiles_n, tile_n = blockIdx.x - slab * tiles_n;
+  const int n = tile_n * 160 + (lane % 20) * 8;
+  const bool active = lane < 60;
+  const int rsub = lane / 20;
+  float cs[8], cq[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) cs[e] = cq[e] = 0.f;
+  Pack16 bb;
+  bb.u = *reinterpret_cast<const uint4*>(p.bias ? p.bias + n : g_zero_page);
+  constexpr int SWEEPS = (GN_SLAB + 11) / 12, U = 3;
+  static_assert(SWEEPS % U == 0, "six sweeps, three at a time");
+  for (int it0 = 0; it0 < SWEEPS; it0 += U) {
+    int m[U];
+    bool ok[U];
+    Pack16 rv[U], rr[U];
+    float v[U][8];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int row_u = w * 3 + rsub + (it0 + u) * 12;
+      m[u] = min(slab * GN_SLAB + min(row_u, GN_SLAB - 1), p.M - 1);
+      ok[u] = active && row_u < GN_SLAB && slab * GN_SLAB + row_u < p.M;
+      rv[u].u = *reinterpret_cast<const uint4*>(p.rowvec ? p.rowvec + (long)(m[u] / p.rows_per_rv) * p.ldrv + n : g_zero_page);
+      rr[u].u = *reinterpret_cast<const uint4*>(p.R ? p.R + (long)m[u] * p.ldr + n : g_zero_page);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[u][e] = 0.f;
+    }
+    for (int s0 = 0; s0 < p.splits; s0 += 4) {   // same order of the slabs as splitk_reduce_kernel
+      float4_t a[U][4], b[U][4];
+#pragma unroll
+      for (int u = 0; u < U; ++u)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const float* src = p.ws + ((long)min(s0 + k, p.splits - 1) * p.M + m[u]) * p.N + n;
+          a[u][k] = *reinterpret_cast<const float4_t*>(src);
+          b[u][k] = *reinterpret_cast<const float4_t*>(src + 4);
+        }
+#pragma unroll
+      for (int u = 0; u < U; ++u)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const float wgt = s0 + k < p.splits ? 1.f : 0.f;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            v[u][e] += a[u][k][e] * wgt;
+            v[u][4 + e] += b[u][k][e] * wgt;
+          }
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {   // the rows in the order of the plain kernel's sweeps
+      Pack16 o;
+      const float mk = ok[u] ? 1.f : 0.f;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        float x = v[u][e] + (float)bb.e[e];
+        x += (float)rv[u].e[e];
+        if (p.act == PFD_ACT_GELU) x = pfd_gelu(x);
+        else if (p.act == PFD_ACT_RELU) x = fmaxf(x, 0.f);
+        else if (p.act == PFD_ACT_SILU) x = pfd_silu(x);
+        o.e[e] = (half_t)(x + (float)rr[u].e[e]);
+        const float f = (float)o.e[e] * mk;
+        cs[e] += f;
+        cq[e] = fmaf(f, f, cq[e]);
+      }
+      if (ok[u]) *reinterpret_cast<uint4*>(p.C + (long)m[u] * p.ldc + n) = o.u;
+    }
+  }
+  gn_slab_reduce<1, 256>(cs, cq, tid, p.N / 32, slab, p.M / GN_SLAB, tiles_n, tile_n, p.gn_out, [&](int) { return red; });
+}
+
 // launches the reduction of a split-K launch (plain, or the statistics-emitting form) and the LayerNorm fallback statistics
 inline void launch_splitk_reduce(const G160Params& p, hipStream_t s) {
   if (p.gn_out) {
-    hipLaunchKernelGGL(splitk_reduce_gn_kernel, dim3((p.M / GN_SLAB) * (p.N / 160)), dim3(256), 0, s, p);
+    const char* par_s = getenv("PFD_GN_PAR");   // read per launch (the emulation / selftest flip it between two launches)
+    if (par_s && atoi(par_s) == 1)
+      hipLaunchKernelGGL(splitk_reduce_gn_par_kernel, dim3((p.M / GN_SLAB) * (p.N / 160)), dim3(256), 0, s, p);
+    else
+      hipLaunchKernelGGL(splitk_reduce_gn_kernel, dim3((p.M / GN_SLAB) * (p.N / 160)), dim3(256), 0, s, p);
   } else {
     const long nvec = (long)p.M * (p.N / 8);
     int g = (int)((nvec + 255) / 256);

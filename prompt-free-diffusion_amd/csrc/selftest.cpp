@@ -1618,6 +1618,11 @@ int main(int argc, char** argv) {
       run_conv_same_case(8, 8, 8, 2560, 1280, ta + 8, tb + 8, false);   // ... over the skip concat, split-K 8
       run_conv_same_case(2, 16, 16, 320, 320, ta, tb, true);
     }
+    // PFD_GN_PAR=1 also switches the statistics-emitting split-K reduction to three row sweeps in flight
+    setenv("PFD_GN_PAR", "1", 1);
+    { GemmCase c{512, 1280, 2048, 0, true, true, true, false, 3304}; c.gn_out = 1; run_gemm_case(c); }                          // split-K 4, cpg 40
+    { GemmCase c{0, 320, 0, 0, true, true, true, false, 9302, 0, 3, 1, 1, 0, 2, 16, 16, 128}; c.gn_out = 1; run_gemm_case(c); }   // conv, split-K 2
+    unsetenv("PFD_GN_PAR");
     // PFD_GN_SMALL_FAST=1: the single-launch small-slab GroupNorm without per-chunk divisions / gamma-beta round trips
     run_gn_case(8, 64, 1280, 0, 32, PFD_ACT_SILU, 1e-5f, "PFD_GN_SMALL_FAST");       // 8^2: 640 chunks, 3 slots per thread
     run_gn_case(8, 256, 1280, 0, 32, PFD_ACT_SILU, 1e-5f, "PFD_GN_SMALL_FAST");      // 16^2: 2560 chunks

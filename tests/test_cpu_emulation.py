@@ -54,6 +54,13 @@ def test_register_operand_ring_kernels_match_the_lds_ring_kernels_bit_for_bit(em
     assert all("bitwise" in l for l in lines), "\n".join(lines)
 
 
+def test_statistics_emitting_splitk_reduce_and_its_three_sweep_form(emu):
+    """split-K reduction that also emits the GroupNorm statistics of what it stores: statistics == sums of the stored f16 values,
+    and PFD_GN_PAR=1 (three row sweeps of loads in flight; round-5 candidate) gives the same output and statistics bit for bit"""
+    lines = _run(emu, "statistics")
+    assert len(lines) == 2 and all("PFD_GN_PAR=1: same output and statistics bitwise" in l for l in lines), "\n".join(lines)
+
+
 def test_flag_handover_patch_kernel_matches_the_barrier_form(emu):
     lines = _run(emu, "variant 95")
     assert len(lines) == 2 and all("== variant 98 bitwise" in l for l in lines)

@@ -43,11 +43,12 @@ struct Case {
   int act = 0, k_split = 0, zero_rows = 0;
   int ksize = 0, stride = 1, pad = 0, ups = 0, B = 0, H = 0, W = 0, Cin = 0;
   int base_variant = -1;   // >= 0: additionally demand the same bits as this variant
+  bool gn_par = false;     // the launch emits GroupNorm statistics; run it again under PFD_GN_PAR=1: same output, same statistics
 };
 
 static int run_variant(const Case& c, int variant, const std::vector<h16>& A, const std::vector<h16>& A2, const std::vector<h16>& Wt,
                        const std::vector<h16>& bias, const std::vector<h16>& rv, const std::vector<h16>& R, int M, int K, int Ho, int Wo,
-                       std::vector<h16>& C, std::vector<float>& ws) {
+                       std::vector<h16>& C, std::vector<float>& ws, std::vector<float>* gn = nullptr) {
   const bool conv = c.ksize > 0;
   PfdGemmDesc d;
   memset(&d, 0, sizeof(d));
@@ -64,6 +65,7 @@ static int run_variant(const Case& c, int variant, const std::vector<h16>& A, co
   if (c.k_split) { d.k_split = c.k_split; d.A2 = A2.data(); d.lda2 = K - c.k_split; }
   d.zero_rows = c.zero_rows;
   d.ws = ws.data(); d.ws_bytes = ws.size() * sizeof(float);
+  if (gn) d.gn_out = gn->data();
   return pfd_gemm160_try(&d, variant, c.splits, nullptr);
 }
 
@@ -96,7 +98,8 @@ static int run_case(const Case& c) {
   std::vector<h16> C((size_t)M * N, (h16)-77.f);
   std::vector<float> ws((size_t)8 * M * N + 64);
   g_err.clear();
-  const int rc = run_variant(c, c.variant, A1, A2, Wt, bias, rv, R, M, K, Ho, Wo, C, ws);
+  std::vector<float> gn1((size_t)(M / 64 + 1) * (N / 160) * 32, -1.f), gn2 = gn1;
+  const int rc = run_variant(c, c.variant, A1, A2, Wt, bias, rv, R, M, K, Ho, Wo, C, ws, c.gn_par ? &gn1 : nullptr);
   if (rc != 0) { printf("FAIL %-70s rc=%d %s\n", c.what, rc, g_err.c_str()); return 1; }
   // double-precision reference
   double max_err = 0, max_ref = 0;
@@ -138,6 +141,27 @@ static int run_case(const Case& c) {
     for (size_t i = 0; i < C.size(); ++i) nd += memcmp(&C[i], &C2[i], sizeof(h16)) != 0;
     if (rc2 != 0 || nd) { fails = 1; extra = " | vs variant " + std::to_string(c.base_variant) + ": rc " + std::to_string(rc2) + ", " + std::to_string(nd) + " elements differ"; }
     else extra = " | == variant " + std::to_string(c.base_variant) + " bitwise";
+  }
+  if (ok && c.gn_par) {
+    // the statistics are the sums of the f16 values the launch stored, per 64-row slab and group of N / 32 channels
+    const int cpg = N / 32, tn = N / 160, ngl = 160 / cpg;
+    double worst = 0;
+    for (int sl = 0; sl < M / 64; ++sl)
+      for (int t = 0; t < tn; ++t)
+        for (int gl = 0; gl < ngl; ++gl) {
+          double a = 0, q = 0;
+          for (int r = 0; r < 64; ++r)
+            for (int cc = 0; cc < cpg; ++cc) { const double v = (double)C[(size_t)(sl * 64 + r) * N + t * 160 + gl * cpg + cc]; a += v; q += v * v; }
+          const size_t o = (((size_t)sl * tn + t) * 16 + gl) * 2;
+          worst = std::max(worst, std::max(fabs(a - gn1[o]) / (1 + fabs(a)), fabs(q - gn1[o + 1]) / (1 + fabs(q))));
+        }
+    std::vector<h16> C2((size_t)M * N, (h16)-55.f);
+    setenv("PFD_GN_PAR", "1", 1);
+    const int rc2 = run_variant(c, c.variant, A1, A2, Wt, bias, rv, R, M, K, Ho, Wo, C2, ws, &gn2);
+    unsetenv("PFD_GN_PAR");
+    const bool same = rc2 == 0 && !memcmp(C.data(), C2.data(), C.size() * sizeof(h16)) && !memcmp(gn1.data(), gn2.data(), gn1.size() * sizeof(float));
+    if (worst > 1e-3 || !same) fails = 1;
+    extra += std::string(" | statistics err ") + std::to_string(worst) + (same ? " | PFD_GN_PAR=1: same output and statistics bitwise" : " | PFD_GN_PAR=1 DIFFERS");
   }
   printf("%s %-70s max err %.2e (max |ref| %.2f)%s\n", fails ? "FAIL" : "ok  ", c.what, max_err, max_ref, extra.c_str());
   fflush(stdout);
@@ -196,6 +220,9 @@ int main(int argc, char** argv) {
   conv("variant 45 conv 3x3 stride 2, 1 x 16 x 16 x 64 -> 160", 160, 45, 1, 3, 2, 1, 0, 1, 16, 16, 64, false, 43);
   conv("variant 27 conv 3x3 + nearest-2x upsample, 1 x 4 x 4 x 64 -> 160", 160, 27, 1, 3, 1, 1, 1, 1, 4, 4, 64, false, 23);
   conv("variant 85 conv 3x3 split-K 2, 1 x 8 x 8 x 128 -> 160", 160, 85, 2, 3, 1, 1, 0, 1, 8, 8, 128, true, 83);
+  // split-K reduction that also emits the GroupNorm statistics, plain and with three row sweeps in flight (PFD_GN_PAR=1)
+  { auto c = lin("split-K 4 + GroupNorm statistics (N 320: cpg 10), residual", 128, 320, 1024, 23, 4, true, -1); c->gn_par = true; }
+  { auto c = conv("split-K 2 conv 8x8x128 -> 1280 + statistics (cpg 40), SiLU-free", 1280, 83, 2, 3, 1, 1, 0, 2, 8, 8, 128, true, -1); c->gn_par = true; }
   // the barrier forms of the patch kernel (sanity of the emulation on the hardware-validated kernels)
   conv("variant 98 patch conv 16x16 (loader waves, barrier per tap), 2 channel blocks", 160, 98, 1, 3, 1, 1, 0, 1, 16, 16, 128, true, -1);
   conv("variant 96 patch conv 16x16 (3-stage weight ring), 2 channel blocks", 160, 96, 1, 3, 1, 1, 0, 1, 16, 16, 128, true, 98);
