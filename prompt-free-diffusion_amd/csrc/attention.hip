@@ -330,7 +330,11 @@ __global__ __launch_bounds__(256, (D <= 40 ? 4 : 1)) void attention_kernel(const
 // PRIO (round-5 candidate, PFD_ATTN=7, never the default and not yet run on hardware): s_setprio(1) around the two MFMA
 // clusters of a tile (the guide's T5: +4-7 % on attention kernels whose waves are in different phases -- here the two
 // 8-wave blocks of a CU are not synchronised with each other, so a wave in its softmax competes with a wave in its MFMAs)
-template <int D, int NWAVES, bool PV16, bool FOLD = false, bool PRIO = false>
+// ZF (round-5 candidate, PFD_ATTN=8 = the default mode + ZF, never run on hardware): the LDS image is cleared with 16-byte
+// stores.  The plain form is a rolled loop of ds_write_b16 -- 7 instructions and a branch per HALF: 169 trips per thread at
+// d = 160 (43 KB of tiles on 256 threads), ~2 us of an 18 us launch, 95 trips at d = 80 -- on the launches whose whole K / V
+// fits in a handful of tiles.  Same bytes cleared, nothing else changes: the same bits as mode 6.
+template <int D, int NWAVES, bool PV16, bool FOLD = false, bool PRIO = false, bool ZF = false>
 __global__ __launch_bounds__(NWAVES * 64, (D <= 40 ? 4 : 1)) void attention2_kernel(const AttnParams p) {
   static_assert(!PV16 || D == 40, "the 16x16x32 PV path is laid out for d = 40 (48 padded rows, row 40 = ones)");
   static_assert(!FOLD || D == 40, "the folded maximum uses contraction slot 40 of the d = 40 build (DQK = 48)");
@@ -365,7 +369,13 @@ __global__ __launch_bounds__(NWAVES * 64, (D <= 40 ? 4 : 1)) void attention2_ker
   const int b = bh / p.H, h = bh - b * p.H;
   const int q_row = qb * QB + wave * 32 + l31;
 
-  for (int i = tid; i < 2 * K_TILE_HALFS + 2 * V_TILE_HALFS; i += NTHR) lds[i] = (half_t)0.f;
+  if constexpr (ZF) {
+    static_assert((2 * K_TILE_HALFS + 2 * V_TILE_HALFS) % 8 == 0, "16-byte clears");
+    for (int i = tid; i < (2 * K_TILE_HALFS + 2 * V_TILE_HALFS) / 8; i += NTHR)
+      reinterpret_cast<uint4*>(lds)[i] = make_uint4(0, 0, 0, 0);
+  } else {
+    for (int i = tid; i < 2 * K_TILE_HALFS + 2 * V_TILE_HALFS; i += NTHR) lds[i] = (half_t)0.f;
+  }
   __syncthreads();
   if (SUM_MFMA) {   // row D of V^T = 1: O^T[D, q] accumulates sum_kv P (every slot of the row, so the swizzle is moot)
     for (int i = tid; i < 2 * KV_TILE; i += NTHR)
@@ -935,7 +945,7 @@ static int launch512(const AttnParams& p, hipStream_t s) {
 // PFD_ATTN: 0 = round-2 kernel; 1 = peeled loop, 4 waves, PV on 32x32x16; 2 = + 8 waves per block (d = 40, big grids);
 // 3 = 4 waves + PV on 16x16x32 (d = 40); 4 = 8 waves + PV on 16x16x32 where 8-wave blocks apply, mode 1 elsewhere;
 // 5 = mode 2 + the maximum folded into the QK^T MFMA; 6 (default) = mode 4 + fold; 7 = mode 6 + s_setprio around the MFMA
-// clusters (round-5 candidate, unmeasured).
+// clusters (round-5 candidate, unmeasured); 8 = mode 6 + 16-byte clears of the LDS image in every head dim (round-5 candidate, unmeasured).
 // PFD_ATTN_FORCE8=1 takes the 8-wave form for every d = 40 problem (tests).
 static int attn_mode() {
   static const int m = getenv("PFD_ATTN") ? atoi(getenv("PFD_ATTN")) : 6;
@@ -955,14 +965,16 @@ int launch(const AttnParams& p, hipStream_t s) {
   const int mode = attn_mode();
   // 8-wave blocks pay when a block has many queries to amortise the staging over and the grid still fills the chip twice
   const bool big = p.Nq >= 1024 && (long)p.B * p.H * ((p.Nq + 255) / 256) >= 512;
-  const bool w8 = (mode == 2 || mode == 4 || mode == 5 || mode == 6 || mode == 7) && D == 40 && (big || attn_force8());
+  const bool w8 = (mode == 2 || mode == 4 || mode == 5 || mode == 6 || mode == 7 || mode == 8) && D == 40 && (big || attn_force8());
   const int qb = w8 ? 256 : 128;
   dim3 grid(((p.Nq + qb - 1) / qb) * p.H * p.B);
   if (mode == 0) {
     hipLaunchKernelGGL((attention_kernel<D, 64>), grid, dim3(256), 0, s, p);
   } else if constexpr (D == 40) {
-    const bool pv16 = mode == 3 || ((mode == 4 || mode == 6 || mode == 7) && w8);   // (the 4-wave PV16 build spills 24 bytes at 128 VGPRs)
-    if (w8 && mode == 7) hipLaunchKernelGGL((attention2_kernel<D, 8, true, true, true>), grid, dim3(512), 0, s, p);
+    const bool pv16 = mode == 3 || ((mode == 4 || mode == 6 || mode == 7 || mode == 8) && w8);   // (the 4-wave PV16 build spills 24 bytes at 128 VGPRs)
+    if (w8 && mode == 8) hipLaunchKernelGGL((attention2_kernel<D, 8, true, true, false, true>), grid, dim3(512), 0, s, p);
+    else if (mode == 8) hipLaunchKernelGGL((attention2_kernel<D, 4, false, false, false, true>), grid, dim3(256), 0, s, p);
+    else if (w8 && mode == 7) hipLaunchKernelGGL((attention2_kernel<D, 8, true, true, true>), grid, dim3(512), 0, s, p);
     else if (w8 && mode == 6) hipLaunchKernelGGL((attention2_kernel<D, 8, true, true>), grid, dim3(512), 0, s, p);
     else if (w8 && mode == 5) hipLaunchKernelGGL((attention2_kernel<D, 8, false, true>), grid, dim3(512), 0, s, p);
     else if (w8 && pv16) hipLaunchKernelGGL((attention2_kernel<D, 8, true>), grid, dim3(512), 0, s, p);
@@ -970,7 +982,8 @@ int launch(const AttnParams& p, hipStream_t s) {
     else if (pv16) hipLaunchKernelGGL((attention2_kernel<D, 4, true>), grid, dim3(256), 0, s, p);
     else hipLaunchKernelGGL((attention2_kernel<D, 4, false>), grid, dim3(256), 0, s, p);
   } else {
-    hipLaunchKernelGGL((attention2_kernel<D, 4, false>), grid, dim3(256), 0, s, p);
+    if (mode == 8) hipLaunchKernelGGL((attention2_kernel<D, 4, false, false, false, true>), grid, dim3(256), 0, s, p);
+    else hipLaunchKernelGGL((attention2_kernel<D, 4, false>), grid, dim3(256), 0, s, p);
   }
   if (prof) pfd_prof_end(s);
   return pfd_check_launch("pfd_attention_f16");

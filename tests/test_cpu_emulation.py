@@ -69,16 +69,19 @@ def test_flag_handover_patch_kernel_matches_the_barrier_form(emu):
 def test_attention_kernels_and_the_setprio_candidate(emu):
     """csrc/attention.hip on the same emulation (v_mfma_f32_32x32x16_f16, v_permlane16_swap): the default stage (PFD_ATTN=6)
     against a double-precision softmax(Q K^T) V at d = 40 / 80 / 96 / 160 with ragged query / key counts, and the round-5
-    candidate PFD_ATTN=7 (s_setprio around the MFMA clusters, never run on hardware): the same bits as stage 6"""
+    candidates PFD_ATTN=7 (s_setprio around the MFMA clusters) and PFD_ATTN=8 (16-byte clears of the LDS image), never run on
+    hardware: the same bits as stage 6"""
     exe = os.path.join(os.path.dirname(emu), "emu_attn")
     out = {}
-    for mode, extra in (("6", []), ("7", ["--quick"])):
-        r = subprocess.run([exe, mode] + extra, capture_output=True, text=True, timeout=900)
+    for mode, extra in (("6", []), ("7", ["--quick"]), ("8", []), ("6w4", ["--quick", "--w4"]), ("8w4", ["--quick", "--w4"])):
+        r = subprocess.run([exe, mode[0]] + extra, capture_output=True, text=True, timeout=900)
         lines = [l for l in r.stdout.splitlines() if l.startswith(("ok", "FAIL"))]
         assert r.returncode == 0 and lines and all(l.startswith("ok") for l in lines), r.stdout[-2000:] + r.stderr[-1000:]
         out[mode] = [l.split()[-1] for l in lines]
     assert len(out["6"]) == 5 and len(out["7"]) == 2
     assert out["7"] == out["6"][:2]
+    # PFD_ATTN=8 (16-byte clears of the LDS image, every head dim; round-5 candidate): the bits of stage 6, 8-wave and 4-wave forms
+    assert out["8"] == out["6"] and out["8w4"] == out["6w4"] and len(out["8w4"]) == 2
 
 
 def test_areg_mask_redirects_the_automatic_choice(emu):

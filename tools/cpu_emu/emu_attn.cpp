@@ -77,9 +77,14 @@ static void run_case(int B, int H, int Nq, int Nk, int D) {
 }
 
 int main(int argc, char** argv) {
-  const bool quick = argc > 2 && !strcmp(argv[2], "--quick");
+  bool quick = false, force8 = true;
+  for (int i = 2; i < argc; ++i) {
+    quick = quick || !strcmp(argv[i], "--quick");
+    if (!strcmp(argv[i], "--w4")) force8 = false;   // the 4-wave d = 40 form (what small launches take)
+  }
   if (argc > 1) setenv("PFD_ATTN", argv[1], 1);
-  setenv("PFD_ATTN_FORCE8", "1", 1);      // the 8-wave d = 40 form at these (small) sizes
+  if (force8) setenv("PFD_ATTN_FORCE8", "1", 1);      // the 8-wave d = 40 form at these (small) sizes
+  else unsetenv("PFD_ATTN_FORCE8");
   run_case(1, 2, 300, 200, 40);           // ragged queries and keys, 4 KV tiles (3 full + 1 peeled)
   run_case(1, 1, 256, 148, 40);           // the cross-attention length (148 context tokens)
   if (!quick) {

@@ -30,5 +30,5 @@ python tools/replay_merge.py $O 0 3300 3600 3700 5300 5600 5500 9300 9500 9200 9
 # attention d = 40: mode 7 = today's default (6) + s_setprio(1) around the two MFMA clusters of a tile (built, unmeasured)
 ( cd prompt-free-diffusion_amd/csrc
   PFD_ATTN=7 PFD_ATTN_FORCE8=1 timeout 100 ./build/selftest --attn > ../../$O/selftest_attn_mode7.log 2>&1; echo "selftest --attn (mode 7) rc=$?"; tail -1 ../../$O/selftest_attn_mode7.log
-  for rep in 1 2; do for m in 6 7; do PFD_ATTN=$m timeout 60 ./build/selftest --bench-attn > ../../$O/bench_attn_mode${m}_$rep.log 2>&1; echo "mode $m run $rep:"; grep -i "d=40\|D40\|40 " ../../$O/bench_attn_mode${m}_$rep.log | head -4; done; done )
+  for rep in 1 2; do for m in 6 7 8; do PFD_ATTN=$m timeout 60 ./build/selftest --bench-attn > ../../$O/bench_attn_mode${m}_$rep.log 2>&1; echo "mode $m run $rep:"; grep -i "bench" ../../$O/bench_attn_mode${m}_$rep.log | head -8; done; done )
 

@@ -5,6 +5,7 @@
 #   PFD_AREG=7   ring kernels with the activation fragments in registers (bit mask: 1 = 27 for 23, 2 = 45 for 43, 4 = 85 for 83)
 #   PFD_AREG=31  ... and 86 for 82 (8), 28 for 22 (16): the 2-stage tiles -> 3 weight stages, two blocks per CU, two K tiles in flight each
 #   PFD_ATTN=7   d = 40 attention with s_setprio around the MFMA clusters
+#   PFD_ATTN=8   every attention launch clears its LDS image with 16-byte stores (the plain form: a rolled loop of ds_write_b16, ~2 us at d = 160)
 #   PFD_GN_PAR=1 GroupNorm apply from producer statistics: the partials of eight slabs requested before the first add
 #   PFD_WPREFETCH=1  every GEMM / conv weight matrix is read on a side stream one launch ahead of its consumer (warm instead of
 #                    cold weight tiles for the latency-chain launches); parallel branches in the captured graph
@@ -24,11 +25,12 @@ for rep in 1 2; do
   run areg_$rep PFD_AREG=7
   run areg2_$rep PFD_AREG=31
   run attn7_$rep PFD_ATTN=7
+  run attn8_$rep PFD_ATTN=8
   run gn_$rep PFD_GN_PAR=1 PFD_GN_SMALL_FAST=1
   run wpf_$rep PFD_WPREFETCH=1
   run all_$rep PFD_AREG=31 PFD_ATTN=7 PFD_GN_PAR=1 PFD_GN_SMALL_FAST=1
 done
-for f in base_1 areg_1 areg2_1 attn7_1 gn_1 wpf_1 all_1 base_2 areg_2 areg2_2 attn7_2 gn_2 wpf_2 all_2; do python - <<P
+for f in base_1 areg_1 areg2_1 attn7_1 attn8_1 gn_1 wpf_1 all_1 base_2 areg_2 areg2_2 attn7_2 attn8_2 gn_2 wpf_2 all_2; do python - <<P
 import json
 try:
     d = json.load(open("$O/$f.json")); print("%-8s %7.1f ms per batch  %.3f images/s  loop %s" % ("$f", d["ms_per_step"], d["value"], d.get("stage_ms_per_batch", {}).get("ddim_loop_ms")))
