@@ -968,7 +968,9 @@ __global__ __launch_bounds__(WAVES_M * 128, MINW) void gemm160ar_kernel(const G1
     if (q >= B_INSTR) q = B_DUP ? q - NW : 0;
     const int r = q * 8 + srow;
     const int c = cpos ^ ((r >> 1) & 7);
-    b_ptr[j] = w_row_ptr(p, n0 + r, c * 8);
+    // (w_row_ptr without its division: this kernel's tile IS the weight layout's tile, so row n0 + r of the K-tile-contiguous
+    //  layout is row r of tile tile_n -- the ten v_rcp divisions were a quarter of the ~590 instructions in front of the first load)
+    b_ptr[j] = p.w_tu == 0 ? p.W + (long)(n0 + r) * p.ldw + c * 8 : p.W + ((long)tile_n * nk_total * BN + r) * BK + c * 8;
   }
 
   const int nsteps = (!CONV && m0 + BM <= p.zero_rows) ? 0 : kt_end - kt_begin;

@@ -43,6 +43,7 @@ struct Case {
   int act = 0, k_split = 0, zero_rows = 0;
   int ksize = 0, stride = 1, pad = 0, ups = 0, B = 0, H = 0, W = 0, Cin = 0;
   int base_variant = -1;   // >= 0: additionally demand the same bits as this variant
+  bool w_tiled = false;    // the weight is handed over K-tile-contiguous (PfdGemmDesc.w_tiled)
   bool gn_par = false;     // the launch emits GroupNorm statistics; run it again under PFD_GN_PAR=1: same output, same statistics
 };
 
@@ -53,7 +54,14 @@ static int run_variant(const Case& c, int variant, const std::vector<h16>& A, co
   PfdGemmDesc d;
   memset(&d, 0, sizeof(d));
   d.M = M; d.N = c.N; d.K = K;
-  d.A = A.data(); d.W = Wt.data(); d.bias = bias.data(); d.C = C.data();
+  std::vector<h16> Wtiled;
+  if (c.w_tiled) {   // (n, k) -> (((n / 160) * (K / 64) + k / 64) * 160 + n % 160) * 64 + k % 64
+    Wtiled.resize(Wt.size());
+    for (int n = 0; n < c.N; ++n)
+      for (int k = 0; k < K; ++k) Wtiled[(((size_t)(n / 160) * (K / 64) + k / 64) * 160 + n % 160) * 64 + k % 64] = Wt[(size_t)n * K + k];
+  }
+  d.A = A.data(); d.W = c.w_tiled ? Wtiled.data() : Wt.data(); d.bias = bias.data(); d.C = C.data();
+  d.w_tiled = c.w_tiled ? 1 : 0;
   d.R = c.res ? R.data() : nullptr;
   d.rowvec = c.rowvec ? rv.data() : nullptr;
   d.lda = conv ? c.Cin : (c.k_split ? c.k_split : K);
@@ -210,6 +218,8 @@ int main(int argc, char** argv) {
   { auto c = lin("variant 27 two-source contraction (k_split 192)", 130, 160, 512, 27, 1, true, 23); c->k_split = 192; }
   { auto c = lin("variant 27 zero rows (64 whole + a straddling tile)", 200, 160, 256, 27, 1, true, 23); c->zero_rows = 100; }
   { auto c = lin("variant 27 SiLU + row vector", 130, 160, 256, 27, 1, false, 23); c->act = PFD_ACT_SILU; c->rowvec = true; }
+  { auto c = lin("variant 27 K-tile-contiguous weights, two column tiles", 130, 320, 448, 27, 1, true, 23); c->w_tiled = true; }
+  { auto c = lin("variant 85 K-tile-contiguous weights, split-K 2", 260, 320, 1024, 85, 2, false, 83); c->w_tiled = true; }
   lin("variant 45 (8 waves) nine steps", 130, 160, 576, 45, 1, true, 43);
   lin("variant 85 (128 rows, 8 waves) nine steps", 260, 160, 576, 85, 1, true, 83);
   lin("variant 29 (5 weight stages) nine steps", 130, 160, 576, 29, 1, true, 23);
