@@ -905,6 +905,12 @@ __global__ __launch_bounds__(WAVES_M * 128, MINW) void gemm160ar_kernel(const G1
   __shared__ __attribute__((aligned(1024))) char smem[MAIN_BYTES + (CONV ? 0 : BM * 8)];
   float2* const lnstat = reinterpret_cast<float2*>(smem + MAIN_BYTES);
 
+  // ONE batch of argument loads.  hipcc sinks each kernel-argument load into the branch that first uses it, so the setup below
+  // ran four dependent s_load -> s_waitcnt lgkmcnt(0) round trips (the argument block spans five cache lines) before the
+  // first operand load could be issued; naming the scalars the setup needs in one asm statement puts all their loads here.
+  asm volatile("" ::"s"(p.tiles_m), "s"(p.tiles_n), "s"(p.nmajor), "s"(p.kt_per_split), "s"(p.K), "s"(p.M), "s"(p.zero_rows),
+               "s"(p.k_split), "s"(p.krot), "s"(p.w_tu), "s"(p.A), "s"(p.A2), "s"(p.W), "s"(p.lda), "s"(p.lda2), "s"(p.ldw),
+               "s"(p.w_kstep));
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);

@@ -20,6 +20,7 @@ SUBST = [
     (r'asm volatile\("" : "\+v"\(([^;]*?)\)\);', '((void)0);'),
     (r'asm volatile\("" : "\+v"\(r\), "\+v"\(ch\)\);', '((void)0);'),
     (r'asm volatile\("" : "\+s"\(k\)::"memory"\);', '((void)0);'),
+    (r'(?s)asm volatile\("" ::"s"\(p\.tiles_m\).*?\);', '((void)0);'),   # the argument-load batch of gemm160ar_kernel
     # the uncounted activation load of gemm160ar_kernel
     (r'asm volatile\("global_load_dwordx4 %0, %1, off" : "=v"\(d\) : "v"\(\(const __attribute__\(\(address_space\(1\)\)\) void\*\)src\) : "memory"\);',
      'memcpy(&d, src, 16);'),
