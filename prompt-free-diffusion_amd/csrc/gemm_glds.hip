@@ -100,6 +100,42 @@ __device__ __forceinline__ const half_t* w_row_ptr(const G160Params& p, int n, i
   return p.W + ((long)tn * (p.K / BK) * p.w_tu + (n - tn * p.w_tu)) * BK + c8;
 }
 
+// PFD_FAST_PROLOGUE (compile-time switch, OFF in the shipped build: `make EXTRA=-DPFD_FAST_PROLOGUE`; round-5 candidate, never
+// run on hardware, emulation-validated).  The ISA of these kernels runs 460-980 instructions before the FIRST operand load is
+// issued (DESIGN work queue 4c); two mechanical causes are removed under the switch:
+//   * the kernel arguments arrive in 3-5 dependent s_load -> s_waitcnt batches because hipcc sinks each argument load into the
+//     branch that first uses it: PFD_ARG_BATCH names the scalars of the setup in one statement at entry (one batch);
+//   * w_row_ptr divides by the weight layout's tile width once per weight piece, although that width is the kernel's own tile
+//     width (or half of it, for the 320-wide GEGLU tile): w_row_ptr_tile forms the same address from the tile index.
+// With the switch off every kernel compiles to the instruction stream of the GPU-validated library (tools/isa_diff.py).
+#if defined(PFD_FAST_PROLOGUE) && !defined(PFD_CPU_EMU)
+#define PFD_ARG_BATCH_LIN(p)                                                                                              \
+  asm volatile("" ::"s"((p).tiles_m), "s"((p).tiles_n), "s"((p).nmajor), "s"((p).kt_per_split), "s"((p).K), "s"((p).M),      \
+               "s"((p).zero_rows), "s"((p).k_split), "s"((p).krot), "s"((p).w_tu), "s"((p).A), "s"((p).A2), "s"((p).W),      \
+               "s"((p).lda), "s"((p).lda2), "s"((p).ldw), "s"((p).w_kstep))
+#define PFD_ARG_BATCH_CONV(p)                                                                                             \
+  asm volatile("" ::"s"((p).tiles_m), "s"((p).tiles_n), "s"((p).nmajor), "s"((p).kt_per_split), "s"((p).K), "s"((p).M),      \
+               "s"((p).krot), "s"((p).w_tu), "s"((p).A), "s"((p).W), "s"((p).lda), "s"((p).ldw), "s"((p).w_kstep),           \
+               "s"((p).Cin), "s"((p).H), "s"((p).Wd), "s"((p).Ho), "s"((p).Wo), "s"((p).stride), "s"((p).pad), "s"((p).ups), \
+               "s"((p).ksize))
+#else
+#define PFD_ARG_BATCH_LIN(p) ((void)0)
+#define PFD_ARG_BATCH_CONV(p) ((void)0)
+#endif
+// address of 16-byte chunk c8 (in halfs) of row r of weight tile tile_n (BN rows) at K tile 0, in either layout, without a division
+template <int BN_>
+__device__ __forceinline__ const half_t* w_row_ptr_tile(const G160Params& p, int tile_n, int r, int c8) {
+  if (p.w_tu == 0) return p.W + (long)(tile_n * BN_ + r) * p.ldw + c8;
+  const int sub = (BN_ > 160 && r >= p.w_tu) ? 1 : 0;               // host: w_tu == BN_, or BN_ == 2 w_tu (the 320-wide tile)
+  const int tn = tile_n * (BN_ > 160 ? 2 : 1) + sub;
+  return p.W + ((long)tn * (p.K / BK) * p.w_tu + (r - sub * p.w_tu)) * BK + c8;
+}
+#ifdef PFD_FAST_PROLOGUE
+#define PFD_W_ROW_PTR(BN_, p, tile_n, n0, r, c8) w_row_ptr_tile<BN_>(p, tile_n, r, c8)
+#else
+#define PFD_W_ROW_PTR(BN_, p, tile_n, n0, r, c8) w_row_ptr(p, (n0) + (r), c8)
+#endif
+
 // Epilogue operands read LATE.  hipcc loads every kernel-argument field a kernel uses with one batch of s_load at the entry
 // and keeps it in SGPRs until its last use: the ~25 scalars only the epilogue needs (bias / row-vector / residual / output
 // pointers and strides, statistics pointers, M, N ...) then sit on top of the main loop's own scalars for the whole launch,
@@ -621,6 +657,8 @@ __global__ __launch_bounds__(WAVES_M * 128) void gemm160_kernel(const G160Params
   // second one would make hipcc drain the LDS-DMA queue in front of every fragment read (guide 5, trap (a))
   __shared__ __attribute__((aligned(1024))) char smem[SMEM + (CONV ? 0 : BM * 8)];
   float2* const lnstat = reinterpret_cast<float2*>(smem + SMEM);
+  if constexpr (CONV) PFD_ARG_BATCH_CONV(p);
+  else PFD_ARG_BATCH_LIN(p);
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -684,7 +722,7 @@ __global__ __launch_bounds__(WAVES_M * 128) void gemm160_kernel(const G160Params
     if (q >= B_INSTR) q = B_DUP ? q - NW : 0;
     const int r = q * 8 + srow;
     const int c = cpos ^ ((r >> 1) & 7);
-    b_ptr[j] = w_row_ptr(p, n0 + r, c * 8);
+    b_ptr[j] = PFD_W_ROW_PTR(BN, p, tile_n, n0, r, c * 8);
   }
   const int Hin = p.ups ? 2 * p.H : p.H;
   const int Win = p.ups ? 2 * p.Wd : p.Wd;
@@ -1167,6 +1205,8 @@ __global__ __launch_bounds__(768) void gemm160ws_kernel(const G160Params p) {
   static_assert(SMEM <= 160 * 1024, "LDS");
   static_assert(BM * stage_row_bytes(BN) <= SMEM, "the epilogue's staging image reuses the operand ring");
   __shared__ __attribute__((aligned(1024))) char smem[SMEM];
+  if constexpr (CONV) PFD_ARG_BATCH_CONV(p);
+  else PFD_ARG_BATCH_LIN(p);
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -1226,7 +1266,7 @@ __global__ __launch_bounds__(768) void gemm160ws_kernel(const G160Params p) {
     for (int j = 0; j < B_PL; ++j) {
       const int r = (lw + NLW * j) * 8 + srow;
       const int c = cpos ^ ((r >> 1) & 7);
-      b_ptr[j] = w_row_ptr(p, n0 + r, c * 8);
+      b_ptr[j] = PFD_W_ROW_PTR(BN, p, tile_n, n0, r, c * 8);
     }
     const int Hin = p.ups ? 2 * p.H : p.H;
     const int Win = p.ups ? 2 * p.Wd : p.Wd;
@@ -1580,6 +1620,7 @@ __global__ __launch_bounds__(768) void conv3x3_patch_ws_kernel(const G160Params 
   static_assert(SMEM <= 160 * 1024, "LDS");
   constexpr int P_INSTR = PATCH_ROWS / 8;          // 50 DMA pieces per patch
   __shared__ __attribute__((aligned(1024))) char smem[SMEM];
+  PFD_ARG_BATCH_CONV(p);
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -1655,7 +1696,7 @@ __global__ __launch_bounds__(768) void conv3x3_patch_ws_kernel(const G160Params 
     for (int j = 0; j < 5; ++j) {
       const int r = (lw + NLW * j) * 8 + srow;
       const int c = cpos ^ ((r >> 1) & 7);
-      wp[j] = w_row_ptr(p, n0 + r, c * 8);
+      wp[j] = PFD_W_ROW_PTR(BN, p, tile_n, n0, r, c * 8);
     }
     auto issue_w = [&](int stage, int tap, int cb) {
       const long k0 = (long)(tap * (p.Cin / BK) + cb) * p.w_kstep;
@@ -2013,6 +2054,7 @@ __global__ __launch_bounds__(768) void conv3x3_patch_fl_kernel(const G160Params 
   static_assert(SMEM <= 160 * 1024, "LDS");
   constexpr int P_INSTR = PATCH_ROWS / 8;          // 50 DMA pieces per patch
   __shared__ __attribute__((aligned(1024))) char smem[SMEM];
+  PFD_ARG_BATCH_CONV(p);
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -2083,7 +2125,7 @@ __global__ __launch_bounds__(768) void conv3x3_patch_fl_kernel(const G160Params 
     for (int j = 0; j < 5; ++j) {
       const int r = (lw + NLW * j) * 8 + srow;
       const int c = cpos ^ ((r >> 1) & 7);
-      wp[j] = w_row_ptr(p, n0 + r, c * 8);
+      wp[j] = PFD_W_ROW_PTR(BN, p, tile_n, n0, r, c * 8);
     }
     auto issue_w = [&](int stage, int tap, int cb) {
       const long k0 = (long)(tap * (p.Cin / BK) + cb) * p.w_kstep;

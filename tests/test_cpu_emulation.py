@@ -96,3 +96,14 @@ def test_areg_mask_redirects_the_automatic_choice(emu):
     assert picks(31) == {"ring23": True, "ring83": True, "two-stage22": True, "two-stage82": True}
     assert picks(7) == {"ring23": True, "ring83": True, "two-stage22": False, "two-stage82": False}
     assert picks(24) == {"ring23": False, "ring83": False, "two-stage22": True, "two-stage82": True}
+
+
+def test_fast_prologue_switch_changes_no_result(tmp_path_factory):
+    """-DPFD_FAST_PROLOGUE (compile-time round-5 candidate: one argument-load batch at kernel entry, weight row pointers without
+    a division per piece): the emulation built WITH the switch gives the same answers -- the K-tile-contiguous weight layout
+    through every kernel family is where the pointer form differs"""
+    out = str(tmp_path_factory.mktemp("pfd_cpu_emu_fast"))
+    env = dict(os.environ, EMU_DEFINES="-DPFD_FAST_PROLOGUE")
+    subprocess.run([sys.executable, os.path.join(REPO, "tools", "cpu_emu", "build.py"), out], check=True, stdout=subprocess.DEVNULL, env=env)
+    lines = _run(os.path.join(out, "emu_gemm"), "K-tile-contiguous", "variant 23 (", "variant 98", "variant 27 conv")
+    assert len(lines) == 8

@@ -2,7 +2,7 @@
 """Build the CPU emulation of csrc/gemm_glds.hip, csrc/norm.hip and csrc/attention.hip (tools/cpu_emu/emu_*.cpp): write
 <file>_emu.inc = the kernel file with its gfx950 inline-asm statements replaced by their C meaning, then compile the
 drivers for the host with clang++.
-usage: build.py [outdir]   (default /tmp/pfd_cpu_emu)  -> <outdir>/emu_gemm, <outdir>/emu_norm, <outdir>/emu_attn"""
+usage: [EMU_DEFINES="-DPFD_FAST_PROLOGUE ..."] build.py [outdir]   (default /tmp/pfd_cpu_emu)  -> <outdir>/emu_gemm, <outdir>/emu_norm, <outdir>/emu_attn"""
 import os
 import re
 import subprocess
@@ -33,7 +33,8 @@ def preprocess(name, out, required=True):
     src = open(os.path.join(CSRC, name + ".hip")).read()
     for pat, rep in SUBST:
         src, n = re.subn(pat, rep, src)
-    left = [l for l in src.splitlines() if "asm volatile" in l and 'asm volatile("" :::' not in l]
+    # (the PFD_ARG_BATCH_* macro bodies are compiled only outside the emulation: #if ... && !defined(PFD_CPU_EMU))
+    left = [l for l in src.splitlines() if "asm volatile" in l and 'asm volatile("" :::' not in l and '"s"((p).tiles_m)' not in l]
     if left:
         sys.exit(f"build.py: inline asm in {name}.hip the emulation does not translate:\n" + "\n".join(left))
     with open(os.path.join(out, name + "_emu.inc"), "w") as f:
@@ -48,7 +49,7 @@ def main():
         preprocess(name, out)
         exe = os.path.join(out, driver)
         cmd = [CXX, "-std=c++17", "-O1", "-pthread", "-w", f"-I{HERE}", f"-I{out}", f"-I{REPO}/include", f"-I{CSRC}",
-               os.path.join(HERE, driver + ".cpp"), "-o", exe]
+               os.path.join(HERE, driver + ".cpp"), "-o", exe] + os.environ.get("EMU_DEFINES", "").split()
         procs.append((exe, cmd, subprocess.Popen(cmd)))     # the three drivers compile side by side
     for exe, cmd, p in procs:
         if p.wait() != 0:

@@ -236,6 +236,8 @@ int main(int argc, char** argv) {
   // the barrier forms of the patch kernel (sanity of the emulation on the hardware-validated kernels)
   conv("variant 98 patch conv 16x16 (loader waves, barrier per tap), 2 channel blocks", 160, 98, 1, 3, 1, 1, 0, 1, 16, 16, 128, true, -1);
   conv("variant 96 patch conv 16x16 (3-stage weight ring), 2 channel blocks", 160, 96, 1, 3, 1, 1, 0, 1, 16, 16, 128, true, 98);
+  { auto c = conv("variant 96 patch conv 16x16, K-tile-contiguous weights, two column tiles", 320, 96, 1, 3, 1, 1, 0, 1, 16, 16, 128, true, -1); c->w_tiled = true; }
+  { auto c = conv("variant 83 implicit-GEMM conv, K-tile-contiguous weights, two column tiles", 320, 83, 1, 3, 1, 1, 0, 1, 8, 8, 128, false, -1); c->w_tiled = true; }
   conv("variant 99 patch conv 16x16 (8-wave form), 2 channel blocks", 160, 99, 1, 3, 1, 1, 0, 1, 16, 16, 128, true, 98);
   // the patch kernel that hands over through LDS progress words (95) against the barrier form (98)
   conv("variant 95 patch conv 16x16, 2 channel blocks", 160, 95, 1, 3, 1, 1, 0, 1, 16, 16, 128, true, 98);

@@ -38,6 +38,22 @@ except Exception as e:
     print("$f", "no result:", e)
 P
 done
+# compile-time candidate: the same source built with -DPFD_FAST_PROLOGUE into a second library (PFD_HIP_LIB selects it)
+( cd prompt-free-diffusion_amd/csrc && mkdir -p build_fast && for f in capi gemm_conv gemm_glds attention swin_attn norm elementwise; do
+    /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -I../../include -I. -Wno-unused-result -mllvm -amdgpu-mfma-vgpr-form -DPFD_FAST_PROLOGUE -c $f.hip -o build_fast/$f.o & done; wait
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC build_fast/*.o -o build_fast/libpfd_hip_fast.so ) > $O/build_fast.log 2>&1
+for rep in 1 2; do
+  run base2_$rep PFD_AREG=0
+  run fastpro_$rep PFD_HIP_LIB=$PWD/prompt-free-diffusion_amd/csrc/build_fast/libpfd_hip_fast.so
+done
+for f in base2_1 fastpro_1 base2_2 fastpro_2; do python - <<P
+import json
+try:
+    d = json.load(open("$O/$f.json")); print("%-10s %7.1f ms per batch  %.3f images/s" % ("$f", d["ms_per_step"], d["value"]))
+except Exception as e:
+    print("$f", "no result:", e)
+P
+done
 # parity under the switches (kernel-level suite + the C2 trajectory on the fixture-backed oracle)
 PFD_AREG=31 PFD_ATTN=7 PFD_GN_PAR=1 PFD_GN_SMALL_FAST=1 timeout 400 python -m pytest tests/test_hip_parity.py tests/test_hip_kernels_fullsize.py -m gpu -q -x > $O/pytest_switches.log 2>&1
 echo "pytest (all four switches) rc=$? after $(( $(date +%s) - T0 )) s"; tail -3 $O/pytest_switches.log
