@@ -103,7 +103,7 @@ def test_fast_prologue_switch_changes_no_result(tmp_path_factory):
     a division per piece): the emulation built WITH the switch gives the same answers -- the K-tile-contiguous weight layout
     through every kernel family is where the pointer form differs"""
     out = str(tmp_path_factory.mktemp("pfd_cpu_emu_fast"))
-    env = dict(os.environ, EMU_DEFINES="-DPFD_FAST_PROLOGUE")
+    env = dict(os.environ, EMU_DEFINES="-DPFD_FAST_PROLOGUE", EMU_ONLY="emu_gemm")
     subprocess.run([sys.executable, os.path.join(REPO, "tools", "cpu_emu", "build.py"), out], check=True, stdout=subprocess.DEVNULL, env=env)
     lines = _run(os.path.join(out, "emu_gemm"), "K-tile-contiguous", "variant 23 (", "variant 98", "variant 27 conv")
     assert len(lines) == 8

@@ -45,7 +45,10 @@ def main():
     out = sys.argv[1] if len(sys.argv) > 1 else "/tmp/pfd_cpu_emu"
     os.makedirs(out, exist_ok=True)
     procs = []
+    only = os.environ.get("EMU_ONLY", "").split()     # e.g. EMU_ONLY=emu_gemm: just that driver
     for name, driver in (("gemm_glds", "emu_gemm"), ("norm", "emu_norm"), ("attention", "emu_attn")):
+        if only and driver not in only:
+            continue
         preprocess(name, out)
         exe = os.path.join(out, driver)
         cmd = [CXX, "-std=c++17", "-O1", "-pthread", "-w", f"-I{HERE}", f"-I{out}", f"-I{REPO}/include", f"-I{CSRC}",
