@@ -44,13 +44,16 @@ def _run(emu, *filters):
 
 def test_emulation_reproduces_the_hardware_validated_kernels(emu):
     lines = _run(emu, "variant 23 (", "variant 83 (", "variant 98", "variant 96", "variant 99")
-    assert len(lines) == 5
+    assert len(lines) == 6                                               # (96 also with K-tile-contiguous weights)
     assert sum("== variant 98 bitwise" in l for l in lines) == 2      # 3-stage ring and 8-wave forms of the patch kernel
 
 
 def test_register_operand_ring_kernels_match_the_lds_ring_kernels_bit_for_bit(emu):
-    lines = _run(emu, "variant 27", "variant 45", "variant 85", "variant 29", "variant 86", "variant 28", "variant 26", "variant 46")
-    assert len(lines) == 21
+    # (a subset of tools/cpu_emu/emu_gemm's list -- run the binary without arguments for all of it)
+    lines = _run(emu, "variant 27 seven", "variant 27 two-source", "variant 27 zero rows", "variant 27 K-tile", "variant 45 (8",
+                 "variant 85 (128", "variant 29", "variant 86", "variant 28", "variant 26", "variant 85 conv 3x3 s1",
+                 "variant 45 conv", "variant 27 conv 3x3 +", "variant 85 conv 3x3 split")
+    assert len(lines) == 14
     assert all("bitwise" in l for l in lines), "\n".join(lines)
 
 
@@ -105,5 +108,5 @@ def test_fast_prologue_switch_changes_no_result(tmp_path_factory):
     out = str(tmp_path_factory.mktemp("pfd_cpu_emu_fast"))
     env = dict(os.environ, EMU_DEFINES="-DPFD_FAST_PROLOGUE", EMU_ONLY="emu_gemm")
     subprocess.run([sys.executable, os.path.join(REPO, "tools", "cpu_emu", "build.py"), out], check=True, stdout=subprocess.DEVNULL, env=env)
-    lines = _run(os.path.join(out, "emu_gemm"), "K-tile-contiguous", "variant 23 (", "variant 98", "variant 27 conv")
-    assert len(lines) == 8
+    lines = _run(os.path.join(out, "emu_gemm"), "K-tile-contiguous", "variant 98")
+    assert len(lines) == 5

@@ -51,7 +51,7 @@ def main():
             continue
         preprocess(name, out)
         exe = os.path.join(out, driver)
-        cmd = [CXX, "-std=c++17", "-O1", "-pthread", "-w", f"-I{HERE}", f"-I{out}", f"-I{REPO}/include", f"-I{CSRC}",
+        cmd = [CXX, "-std=c++17", os.environ.get("EMU_OPT", "-O0"), "-pthread", "-w", f"-I{HERE}", f"-I{out}", f"-I{REPO}/include", f"-I{CSRC}",
                os.path.join(HERE, driver + ".cpp"), "-o", exe] + os.environ.get("EMU_DEFINES", "").split()
         procs.append((exe, cmd, subprocess.Popen(cmd)))     # the three drivers compile side by side
     for exe, cmd, p in procs:
