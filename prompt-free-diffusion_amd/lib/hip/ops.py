@@ -154,14 +154,48 @@ _TRACE = os.environ.get("PFD_TRACE_GEMM")
 LN_FOLD = os.environ.get("PFD_LN_FOLD", "1") != "0"
 
 
+# One record per GEMM / conv launch: THE field list of profiles/unet_c2_gemm_shapes.txt.  The writer below, the readers in
+# tests/test_hip_kernels_fullsize.py (parse_launch_records) and csrc/selftest.cpp (--replay: 19 or 22 integers per line) follow
+# it; tests/test_host.py parses the tracked file with it on CPU, so a regenerated file cannot break a GPU-only test unseen.
+TRACE_FIELDS = ("M", "N", "K", "act", "has_bias", "has_rowvec", "has_res", "bias_per_row",
+                "ksize", "stride", "pad", "ups", "B", "H", "W", "Cin", "Ho", "Wo", "rows_per_rv",
+                "k_split", "zero_rows", "gn_out")
+TRACE_FIELDS_ABI7 = 19      # rounds 1-3 wrote the first 19 (k_split = zero_rows = gn_out = 0)
+
+
+def trace_record(d):
+    """the TRACE_FIELDS of a PfdGemmDesc, as ints"""
+    return tuple(int(v) for v in (
+        d.M, d.N, d.K, d.act, d.bias is not None, d.rowvec is not None, d.R is not None, d.bias_per_row,
+        d.ksize, d.stride, d.pad, d.ups, d.B, d.H, d.Wd, d.Cin, d.Ho, d.Wo, d.rows_per_rv,
+        d.k_split, d.zero_rows, bool(d.gn_out)))
+
+
+def parse_launch_records(path, distinct=True):
+    """[LaunchRecord] of a PFD_TRACE_GEMM file (19-field lines of older rounds are padded with zeros)"""
+    import collections
+    Rec = collections.namedtuple("LaunchRecord", TRACE_FIELDS)
+    seen, out = set(), []
+    for ln, line in enumerate(open(path), 1):
+        v = tuple(int(t) for t in line.split())
+        if not v:
+            continue
+        if len(v) == TRACE_FIELDS_ABI7:
+            v = v + (0,) * (len(TRACE_FIELDS) - TRACE_FIELDS_ABI7)
+        if len(v) != len(TRACE_FIELDS):
+            raise ValueError(f"{path}:{ln}: {len(v)} fields, expected {len(TRACE_FIELDS)} ({' '.join(TRACE_FIELDS)})")
+        if distinct and v in seen:
+            continue
+        seen.add(v)
+        out.append(Rec(*v))
+    return out
+
+
 def _trace(d):
     """PFD_TRACE_GEMM=<file>: append one line per GEMM/conv launch (shape replay for tools/selftest --replay,
     used to measure HBM traffic with rocprofv3 --pmc on a torch-free process)"""
     with open(_TRACE, "a") as f:
-        f.write(" ".join(str(int(v)) for v in (
-            d.M, d.N, d.K, d.act, d.bias is not None, d.rowvec is not None, d.R is not None, d.bias_per_row,
-            d.ksize, d.stride, d.pad, d.ups, d.B, d.H, d.Wd, d.Cin, d.Ho, d.Wo, d.rows_per_rv,
-            d.k_split, d.zero_rows, bool(d.gn_out))) + "\n")
+        f.write(" ".join(str(v) for v in trace_record(d)) + "\n")
 
 
 def _chk16(t, what):

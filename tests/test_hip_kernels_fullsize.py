@@ -49,42 +49,74 @@ def _rand(shape, scale, seed):
 
 
 def _records():
-    seen, out = set(), []
-    for line in open(SHAPES):
-        v = tuple(int(t) for t in line.split())
-        if v not in seen:
-            seen.add(v)
-            out.append(v)
-    return out
+    from lib.hip import ops
+    return ops.parse_launch_records(SHAPES)
+
+
+def gn_partials_ref(y, N):
+    """PfdGemmDesc.gn_out of a stored [M, N] f16 tensor, from its own values in fp32/fp64: float2 [M / 64][N / 160][16]
+    = (sum x, sum x^2) per 64-row slab and group of N / 32 channels; 160 / (N / 32) slots of a tile are used"""
+    M = y.shape[0]
+    cpg = N // 32
+    used = 160 // cpg
+    v = y.double().view(M // 64, 64, N // 160, used, cpg)
+    return torch.stack([v.sum(dim=(1, 4)), (v * v).sum(dim=(1, 4))], dim=-1), used     # [M/64, N/160, used, 2]
+
+
+def check_gn_partials(name, y, stats):
+    """the statistics a gn_out launch emitted vs the sums of the tensor it stored (include/pfd_hip.h, ABI 8)"""
+    M, N = y.shape
+    assert stats is not None, f"{name}: the record says gn_out but the launch emitted no statistics"
+    assert tuple(stats.shape) == (M // 64, N // 160, 16, 2) and stats.dtype == torch.float32
+    ref, used = gn_partials_ref(y, N)
+    got = stats[:, :, :used].double()
+    # sums of 64 * N/32 f16 values in fp32: relative to the slab's sum of squares / its root
+    scale_s = ref[..., 1].sqrt().clamp_min(1.0) * (64 * (N // 32)) ** 0.5
+    e_sum = float(((got[..., 0] - ref[..., 0]).abs() / scale_s).max())
+    e_sq = float(((got[..., 1] - ref[..., 1]).abs() / ref[..., 1].clamp_min(1.0)).max())
+    assert e_sum <= 3e-4 and e_sq <= 3e-4, (name, "gn_out partials", e_sum, e_sq)
+    return max(e_sum, e_sq)
 
 
 class Problem:
-    """one recorded launch rebuilt with seeded operands; `.run(tile)` -> HIP result, `.ref` -> fp32 formula"""
+    """one recorded launch rebuilt with seeded operands; `.run(tile)` -> HIP result, `.ref` -> fp32 formula.
+    ABI-8 fields: k_split -> two-source operand [x | x2] (openaimodel.py:274 after pfd.py:356); zero_rows -> that many
+    all-zero operand rows in front (app.py:236 zero unconditional context: result epi(0)); gn_out -> the launch also emits
+    GroupNorm partials of what it stored (openaimodel.py:200-226), checked by check_gn_partials"""
 
     def __init__(self, rec, seed):
         from lib.hip import layers as L
         from lib.model_zoo.attention import GEGLU
-        (M, N, K, act, has_b, has_rv, has_r, bpr, ks, st, pad, ups, B, H, W, Cin, Ho, Wo, rpr) = rec
-        assert not bpr
+        M, N, K, act, ks, rpr = rec.M, rec.N, rec.K, rec.act, rec.ksize, rec.rows_per_rv
+        B, H, W, Cin, Ho, Wo = rec.B, rec.H, rec.W, rec.Cin, rec.Ho, rec.Wo
+        assert not rec.bias_per_row
         self.rec, self.M, self.N, self.K, self.act, self.ks = rec, M, N, K, act, ks
-        self.bias = _rand((N,), 0.5, seed + 1) if has_b else None
+        self.bias = _rand((N,), 0.5, seed + 1) if rec.has_bias else None
         self.rows_per_rv = rpr
-        n_rv = (M + rpr - 1) // rpr if has_rv else 0
-        self.rowvec = _rand((max(n_rv, 1), N), 0.5, seed + 2) if has_rv else None
+        n_rv = (M + rpr - 1) // rpr if rec.has_rowvec else 0
+        self.rowvec = _rand((max(n_rv, 1), N), 0.5, seed + 2) if rec.has_rowvec else None
         n_out = N // 2 if act == ACT_GEGLU else N
-        self.res = _rand((M, n_out), 1.0, seed + 3) if has_r else None
+        self.res = _rand((M, n_out), 1.0, seed + 3) if rec.has_res else None
+        self.x2, self.zero_rows, self.gn_out = None, rec.zero_rows, bool(rec.gn_out)
         if ks > 0:
+            assert not rec.k_split and not rec.zero_rows
             self.x = _rand((B, H, W, Cin), 1.0, seed)                          # NHWC
             w4 = _rand((N, Cin, ks, ks), K ** -0.5, seed + 4)                   # torch conv layout
             self.w = L.pack_conv_weight(w4)
-            self.geom = (st, pad, bool(ups), B, Ho, Wo)
+            self.geom = (rec.stride, rec.pad, bool(rec.ups), B, Ho, Wo)
             xr = self.x.float().permute(0, 3, 1, 2)
-            if ups:
+            if rec.ups:
                 xr = F.interpolate(xr, scale_factor=2, mode="nearest")
-            cols = F.unfold(xr, ks, padding=pad, stride=st)                     # [B, Cin*ks*ks, Ho*Wo], c-major
+            cols = F.unfold(xr, ks, padding=rec.pad, stride=rec.stride)         # [B, Cin*ks*ks, Ho*Wo], c-major
             y = cols.transpose(1, 2).reshape(M, K) @ w4.float().reshape(N, K).t()
         else:
-            self.x = _rand((M, K), 1.0, seed)
+            rows = M - rec.zero_rows
+            xfull = _rand((rows, K), 1.0, seed)
+            if rec.k_split:
+                self.x = xfull[:, :rec.k_split].contiguous()
+                self.x2 = xfull[:, rec.k_split:].contiguous()
+            else:
+                self.x = xfull
             w = _rand((N, K), K ** -0.5, seed + 4)
             if act == ACT_GEGLU:      # logical rows: x half then gate half; packed by the module that owns the layout
                 m = GEGLU(K, N // 2).half().cuda()
@@ -94,7 +126,9 @@ class Problem:
                 self.w, self.bias_packed = m._pk()
             else:
                 self.w = w
-            y = self.x.float() @ w.float().t()
+            y = xfull.float() @ w.float().t()
+            if rec.zero_rows:
+                y = torch.cat([torch.zeros((rec.zero_rows, N), device="cuda"), y])
         if self.bias is not None:
             y = y + self.bias.float()
         if self.rowvec is not None:
@@ -111,37 +145,49 @@ class Problem:
             y = y + self.res.float()
         self.ref = y
 
-    def run(self, tile=0):
+    def run(self, tile=0, check_stats=True):
         from lib.hip import ops
         if self.ks > 0:
             st, pad, ups, B, Ho, Wo = self.geom
             r4 = None if self.res is None else self.res.view(B, Ho, Wo, -1)
             y = ops.conv(self.x, self.w, self.ks, stride=st, pad=pad, ups=ups, bias=self.bias, rowvec=self.rowvec,
-                         res=r4, act=self.act, tile=tile, rows_per_rv=self.rows_per_rv if self.rowvec is not None else None)
-            return y.view(self.M, -1)
-        bias = self.bias_packed if self.act == ACT_GEGLU else self.bias
-        return ops.gemm(self.x, self.w, bias=bias, rowvec=self.rowvec, rows_per_rv=self.rows_per_rv, res=self.res,
-                        act=self.act, tile=tile)
+                         res=r4, act=self.act, tile=tile, gn_out=self.gn_out,
+                         rows_per_rv=self.rows_per_rv if self.rowvec is not None else None)
+            stats = ops.get_gn_stats(y)
+            y = y.view(self.M, -1)
+        else:
+            bias = self.bias_packed if self.act == ACT_GEGLU else self.bias
+            y = ops.gemm(self.x, self.w, bias=bias, rowvec=self.rowvec, rows_per_rv=self.rows_per_rv, res=self.res,
+                         act=self.act, tile=tile, a2=self.x2, zero_rows=self.zero_rows, gn_out=self.gn_out)
+            stats = ops.get_gn_stats(y)
+        self.stats_err = check_gn_partials(_name(self.rec), y, stats) if (self.gn_out and check_stats) else None
+        return y
 
 
 def _name(rec):
-    M, N, K, act, _, rv, r, _, ks, st, _, ups = rec[:12]
-    kind = f"conv{ks}x{ks}/s{st}{'/ups' if ups else ''}" if ks else "linear"
-    return f"{kind} M{M} N{N} K{K} act{act}{' +emb' if rv else ''}{' +res' if r else ''}"
+    kind = f"conv{rec.ksize}x{rec.ksize}/s{rec.stride}{'/ups' if rec.ups else ''}" if rec.ksize else "linear"
+    return (f"{kind} M{rec.M} N{rec.N} K{rec.K} act{rec.act}{' +emb' if rec.has_rowvec else ''}{' +res' if rec.has_res else ''}"
+            f"{' k_split%d' % rec.k_split if rec.k_split else ''}{' zero_rows%d' % rec.zero_rows if rec.zero_rows else ''}"
+            f"{' +gn_out' if rec.gn_out else ''}")
 
 
 def test_unet_c2_launch_list_vs_torch():
-    """every distinct launch of a C2 UNet pass, heuristic tile choice (what the bench runs)"""
+    """every distinct launch of a C2 UNet pass, heuristic tile choice (what the bench runs) -- including the ABI-8 forms:
+    the two-source skip GEMMs, the zero-row out-projections and the GroupNorm partials of every gn_out launch"""
     recs = _records()
     assert len(recs) >= 55
-    worst = 0.0
+    assert sum(1 for r in recs if r.k_split) >= 5 and sum(1 for r in recs if r.zero_rows) >= 3 and \
+        sum(1 for r in recs if r.gn_out) >= 10, "the tracked launch list lost its ABI-8 records"
+    worst, worst_st = 0.0, 0.0
     for i, rec in enumerate(recs):
         p = Problem(rec, 1000 + 17 * i)
         e, l2 = rel(p.run(), p.ref)
         worst = max(worst, e, l2)
-        print(f"[fullsize] {_name(rec)}: scaled max-abs {e:.2e}, rel-L2 {l2:.2e}")
+        worst_st = max(worst_st, p.stats_err or 0.0)
+        print(f"[fullsize] {_name(rec)}: scaled max-abs {e:.2e}, rel-L2 {l2:.2e}"
+              + (f", gn_out partials {p.stats_err:.1e}" if p.stats_err is not None else ""))
         assert e <= 4e-3 and l2 <= 4e-3, (_name(rec), e, l2)
-    print(f"[fullsize] {len(recs)} distinct launches, worst error {worst:.2e}")
+    print(f"[fullsize] {len(recs)} distinct launches, worst error {worst:.2e}, worst gn_out partial error {worst_st:.1e}")
 
 
 def _tile(variant, splits=0):
@@ -171,22 +217,33 @@ FORCED = [
 ]
 
 
+FORCED_ABI8 = [   # the two-source skip GEMMs, the zero-row out-projections and a gn_out linear under the forced tiles
+    (dict(M=32768, N=320, K=960, ksize=0, k_split=640), [(44, 1), (24, 1), (22, 1)]),
+    (dict(M=8192, N=640, K=1920, ksize=0, k_split=1280), [(44, 1), (24, 2), (22, 1)]),
+    (dict(M=2048, N=1280, K=2560, ksize=0, k_split=1280), [(24, 4), (22, 2)]),
+    (dict(M=32768, N=320, K=320, ksize=0, zero_rows=16384), [(44, 1), (24, 1), (22, 1)]),
+    (dict(M=2048, N=1280, K=1280, ksize=0, zero_rows=1024), [(24, 2), (22, 1), (22, 4)]),
+    (dict(M=8192, N=640, K=640, ksize=0, gn_out=1), [(44, 1), (24, 1), (22, 1)]),
+]
+
+
 def test_unet_c2_forced_tile_variants_and_split_k():
     """the same full-size problems under every tile variant / split-K factor the heuristic may pick"""
     recs = _records()
-    keys = ("M", "N", "K", "act", "b", "rv", "R", "bpr", "ks", "st", "pad", "ups")
+    alias = {"ks": "ksize", "st": "stride"}
     n = 0
-    for i, (flt, variants) in enumerate(FORCED):
-        match = [r for r in recs if all(dict(zip(keys, r))[k] == v for k, v in flt.items())]
+    for i, (flt, variants) in enumerate(FORCED + FORCED_ABI8):
+        match = [r for r in recs if all(getattr(r, alias.get(k, k)) == v for k, v in flt.items())]
         assert match, flt
-        # prefer the richest epilogue (residual / embedding row vector) among the matching records
-        rec = max(match, key=lambda r: (r[6], r[5], r[4]))
+        # prefer the richest epilogue (residual / embedding row vector / statistics) among the matching records
+        rec = max(match, key=lambda r: (r.has_res, r.has_rowvec, r.has_bias, r.gn_out))
         p = Problem(rec, 5000 + 31 * i)
         base = p.run()
         for variant, splits in variants:
             y = p.run(_tile(variant, splits))
             e, l2 = rel(y, p.ref)
-            print(f"[fullsize] {_name(rec)} variant {variant} splits {splits}: max-abs {e:.2e}, rel-L2 {l2:.2e}")
+            print(f"[fullsize] {_name(rec)} variant {variant} splits {splits}: max-abs {e:.2e}, rel-L2 {l2:.2e}"
+                  + (f", gn_out partials {p.stats_err:.1e}" if p.stats_err is not None else ""))
             assert e <= 4e-3 and l2 <= 4e-3, (_name(rec), variant, splits, e, l2)
             assert float((y.float() - base.float()).abs().max()) <= 4e-3 * max(1.0, float(p.ref.abs().max()))
             n += 1

@@ -413,3 +413,49 @@ def test_weight_prefetch_bookkeeping_with_fake_streams(monkeypatch):
         ops._prefetch_mark()
     assert sum(1 for e in log if e[0] == "wait" and e[1] == "main") == 2
     ops._PF.st = None
+
+
+def test_tracked_launch_list_parses_under_the_gpu_tests_reader():
+    """profiles/unet_c2_gemm_shapes.txt is read by GPU-only tests (tests/test_hip_kernels_fullsize.py) and by
+    `selftest --replay`: run the SAME reader and the same record filters here, so a regenerated file (new fields, lost
+    shapes) fails the CPU suite instead of silently breaking the GPU one (round 4: 19-field unpack of a 22-field file)."""
+    import test_hip_kernels_fullsize as FS
+    from lib.hip import ops
+    recs = FS._records()
+    assert len(recs) >= 55 and all(len(r) == len(ops.TRACE_FIELDS) for r in recs)
+    raw_widths = {len(line.split()) for line in open(FS.SHAPES) if line.strip()}
+    assert raw_widths <= {ops.TRACE_FIELDS_ABI7, len(ops.TRACE_FIELDS)}, raw_widths
+    src = open(os.path.join(REPO, "prompt-free-diffusion_amd", "csrc", "selftest.cpp")).read()
+    assert f"std::array<long, {len(ops.TRACE_FIELDS)}>" in src and f"n != {len(ops.TRACE_FIELDS)}" in src, \
+        "selftest --replay reads a different number of fields than ops.TRACE_FIELDS"
+    for r in recs:     # geometry the rebuilt problems rely on
+        assert r.M > 0 and r.N > 0 and r.K % 64 == 0 and not r.bias_per_row
+        if r.ksize:
+            assert r.M == r.B * r.Ho * r.Wo and r.K == r.ksize * r.ksize * r.Cin and not r.k_split and not r.zero_rows
+        if r.k_split:
+            assert r.k_split % 64 == 0 and 0 < r.k_split < r.K
+        assert 0 <= r.zero_rows < r.M
+        if r.gn_out:
+            assert r.N in (320, 640, 1280) and r.M % 64 == 0 and r.act != FS.ACT_GEGLU
+    assert sum(1 for r in recs if r.k_split) >= 5 and sum(1 for r in recs if r.zero_rows) >= 3 and \
+        sum(1 for r in recs if r.gn_out) >= 10
+    alias = {"ks": "ksize", "st": "stride"}
+    for flt, variants in FS.FORCED + FS.FORCED_ABI8:    # every forced-variant filter still finds its record
+        assert any(all(getattr(r, alias.get(k, k)) == v for k, v in flt.items()) for r in recs), flt
+        assert variants
+    assert all(FS._name(r) for r in recs)
+
+
+def test_gn_partials_reference_layout():
+    """the fp32 restatement of PfdGemmDesc.gn_out the GPU test compares against (include/pfd_hip.h, ABI 8): slot
+    [(slab * (N / 160) + n / 160) * 16 + (n % 160) / (N / 32)] over 64-row slabs"""
+    import test_hip_kernels_fullsize as FS
+    for N in (320, 640, 1280):
+        y = torch.randn(128, N, generator=torch.Generator().manual_seed(N)).half()
+        ref, used = FS.gn_partials_ref(y, N)
+        assert used == 160 // (N // 32) and tuple(ref.shape) == (2, N // 160, used, 2)
+        slab, n = 1, N - 1
+        g0 = n - n % (N // 32)
+        blk = y[64:128, g0:g0 + N // 32].double()
+        got = ref[slab, n // 160, (n % 160) // (N // 32)]
+        assert abs(float(got[0] - blk.sum())) < 1e-9 and abs(float(got[1] - (blk * blk).sum())) < 1e-9
