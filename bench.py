@@ -161,8 +161,6 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-prof", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="launch the DDIM loop eagerly instead of one hipGraph")
-    ap.add_argument("--lanes", type=int, default=None,
-                    help="sub-batch lanes of the sampler (concurrent hipGraphs on their own streams); default: PFD_LANES / the sampler's default")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help='"nccl" is RCCL on ROCm; gloo: CPU tests')
     ap.add_argument("--launch-timeout", type=float, default=float(os.environ.get("PFD_BENCH_TIMEOUT", "3000")),
                     help="seconds before a self-started multi-rank job is killed")
@@ -226,8 +224,6 @@ def main():
                 torch.nn.init.normal_(pe.mlp[-1].weight, std=768 ** -0.5)
                 net.ctx['image'].qtransformer.pe_layer = pe.half().to(dev)
         pipe = PromptFreePipeline(net, rank=rank, world_size=world)
-        if args.lanes is not None:
-            pipe.sampler.lanes = args.lanes
         pipe.enable_graph(not args.no_graph)
     image = torch.rand((args.batch if args.per_sample_image else 1, 3, args.height, args.width),
                        generator=torch.Generator().manual_seed(1234))
@@ -304,8 +300,7 @@ def main():
                                    f"batch={args.batch}/GPU, {args.batch if args.per_sample_image else 1} SeeCoder encode(s) + VAE decode per batch",
                        "global_batch": n_global, "parallelism": f"dp{world}",
                        "world_size_reported_by_backend": dist.get_world_size() if world > 1 else 1,
-                       "backend": (args.backend + (" (RCCL)" if args.backend == "nccl" else "")) if world > 1 else None,
-                       "sampler_lanes": getattr(pipe.sampler, "lanes", None)},
+                       "backend": (args.backend + (" (RCCL)" if args.backend == "nccl" else "")) if world > 1 else None},
         }
         if args.stub:
             res["data"] = "stub (CPU stand-ins for the GPU compute: launcher / collective test only, not a measurement)"

@@ -10,8 +10,9 @@ oracle/weights.py -- 13 to 18 minutes of host time (8 to 64 threads), which is w
 suite 21 minutes long, and run next to it they starve the suite's other CPU-oracle checks (the GPU boxes give a container
 about 64 threads' worth of CPU).  The oracle itself is pinned to the reference by tests/golden/golden.npz
 (oracle/make_golden.py imports the reference); THESE fixtures are pinned to the oracle by
-tests/test_oracle_golden.py::test_trajectory_fixture_first_step, which recomputes the first DDIM step of every case on
-the CPU in the `-m "not gpu"` suite, and `PFD_ORACLE_LIVE=1 pytest -m gpu` recomputes the whole trajectories instead of
+tests/test_oracle_golden.py::test_trajectory_fixture_first_and_last_step, which recomputes the first DDIM step of every case
+and the LAST step from the stored penultimate latent on the CPU in the `-m "not gpu"` suite and asserts the digest of the
+oracle sources stored in the meta (a changed oracle means: regenerate), and `PFD_ORACLE_LIVE=1 pytest -m gpu` recomputes the whole trajectories instead of
 reading them.
 
     python oracle/make_trajectory_golden.py [--threads N] [--from-dir DIR]     (DIR: <case>.pt files oracle_worker.py wrote)
@@ -38,8 +39,11 @@ def main():
     ap.add_argument("--from-dir", default=None)
     args = ap.parse_args()
     d = args.from_dir or tempfile.mkdtemp(prefix="pfd_traj_")
+    sys.path.insert(0, os.path.join(REPO, "tests"))
+    import oracle_worker as OW
     out, meta = {}, {"script": "oracle/make_trajectory_golden.py", "torch": torch.__version__,
-                     "host_cpus": os.cpu_count(), "written": time.strftime("%Y-%m-%d"), "cases": {}}
+                     "host_cpus": os.cpu_count(), "written": time.strftime("%Y-%m-%d"), "cases": {},
+                     "oracle_sources": list(OW.ORACLE_SOURCES), "oracle_sha256": OW.oracle_digest()}
     for c in CASES:
         pt = os.path.join(d, c + ".pt")
         if not os.path.exists(pt):

@@ -14,6 +14,8 @@
 #include <random>
 #include <string>
 #include <array>
+#include <atomic>
+#include <thread>
 #include <vector>
 
 #include "pfd_hip.h"
@@ -99,6 +101,20 @@ static double act_ref(double v, int act) {
 }
 
 
+
+// the host references are plain fp64 loops: rows are independent, so they run on the box's host threads (the round-5
+// candidate list took > 400 s single-threaded -- 6 s per case -- and was cut off by its GPU-call limit)
+template <class F>
+static void parallel_rows(int M, F&& body) {
+  unsigned nt = std::thread::hardware_concurrency();
+  nt = std::max(1u, std::min(nt ? nt : 1u, 48u));
+  if (M < 64 || nt == 1) { for (int m = 0; m < M; ++m) body(m); return; }
+  std::vector<std::thread> th;
+  std::atomic<int> next{0};
+  for (unsigned t = 0; t < nt; ++t)
+    th.emplace_back([&]() { for (int m; (m = next.fetch_add(8)) < M;) for (int i = m; i < std::min(M, m + 8); ++i) body(i); });
+  for (auto& t : th) t.join();
+}
 
 // ------------------------------------------------------------------ GEMM / conv
 struct GemmCase {
@@ -194,7 +210,7 @@ static void run_gemm_case(const GemmCase& c) {
   auto got = dC.get();
   // CPU reference
   std::vector<double> pre((size_t)M * N);
-  for (int m = 0; m < M; ++m) {
+  parallel_rows(M, [&](int m) {
     int b = 0, oy = 0, ox = 0;
     if (conv) { b = m / (Ho * Wo); oy = (m % (Ho * Wo)) / Wo; ox = m % Wo; }
     for (int n = 0; n < N; ++n) {
@@ -217,7 +233,7 @@ static void run_gemm_case(const GemmCase& c) {
       if (c.rowvec) s += (double)rv[(m / rows_per_rv) * ldrv + n];
       pre[(size_t)m * N + n] = s;
     }
-  }
+  });
   std::vector<double> ref((size_t)M * ldc, 0.0);
   std::vector<h16> gotc((size_t)M * ldc, (h16)0);
   if (c.n_split > 0) {  // transposed tail: [N - n_split, ldct], pad columns untouched

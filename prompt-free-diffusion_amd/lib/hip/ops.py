@@ -119,33 +119,12 @@ _WS = {}
 _WS_BYTES = 96 << 20
 
 
-# Launch sequences that run CONCURRENTLY on different streams (the sub-batch lanes of DDIMSampler, lib/model_zoo/ddim.py)
-# must not share the split-K slabs: each lane selects its own slot while it enqueues (or captures) its launches.
-_WS_SLOT = threading.local()
-
-
-class workspace_slot:
-    """`with workspace_slot(i):` -- the split-K scratch used by the launches enqueued inside is slot i's"""
-
-    def __init__(self, slot):
-        self.slot = int(slot)
-
-    def __enter__(self):
-        self.prev = getattr(_WS_SLOT, "v", 0)
-        _WS_SLOT.v = self.slot
-        return self
-
-    def __exit__(self, *exc):
-        _WS_SLOT.v = self.prev
-        return False
-
-
 def _workspace(device):
-    """per-(device, slot) fp32 scratch for split-K GEMMs (one stream per slot; stable address for hipGraphs)"""
-    key = (device, getattr(_WS_SLOT, "v", 0))
-    ws = _WS.get(key)
+    """per-device fp32 scratch for split-K GEMMs (stable address for hipGraphs; launch sequences are serialised by
+    DEVICE_LOCK and run on one stream, so one slab per device suffices)"""
+    ws = _WS.get(device)
     if ws is None:
-        ws = _WS[key] = torch.empty(_WS_BYTES, dtype=torch.uint8, device=device)
+        ws = _WS[device] = torch.empty(_WS_BYTES, dtype=torch.uint8, device=device)
     return ws
 
 
@@ -277,6 +256,17 @@ def get_gn_stats(t):
     return ent[0]
 
 
+def _written(out, stats=None):
+    """every op that writes into a caller-provided `out` goes through here: the tensor object carries the statistics of
+    THIS write or none (stale producer statistics would be normalised with silently).  Writing through a VIEW of a
+    statistics-carrying tensor is not tracked: the object that holds the statistics must be the one written."""
+    if stats is not None:
+        set_gn_stats(out, stats)
+    elif out is not None and getattr(out, "_pfd_gn", None) is not None:
+        out._pfd_gn = None
+    return out
+
+
 def cat_pair(t):
     """torch.cat([t, t]) of a CFG pair, statistics included (per-sample slabs: the copy's are the original's)"""
     out = torch.cat([t, t])
@@ -385,8 +375,7 @@ def gemm(a, w, *, bias=None, rowvec=None, rows_per_rv=1, res=None, act=ACT_NONE,
     _b.check(rc, f"pfd_gemm_f16 M{M} N{N} K{K}")
     if WPREFETCH:
         _prefetch_mark()
-    if gst is not None:
-        set_gn_stats(out, gst)
+    _written(out, gst)
     return out if stats is None else (out, stats)
 
 
@@ -471,9 +460,7 @@ def conv(x, w, ksize, *, stride=1, pad=None, ups=False, bias=None, rowvec=None, 
     _b.check(rc, f"pfd_gemm_f16(conv) M{M} N{N} K{K}" + (" with GroupNorm prologue" if gn is not None else ""))
     if WPREFETCH:
         _prefetch_mark()
-    if gst is not None:
-        set_gn_stats(out, gst)
-    return out
+    return _written(out, gst)
 
 
 def im2col(x, ksize, stride, pad, kpad, ho=None, wo=None):
@@ -501,9 +488,7 @@ def conv_narrow(x, w, ksize, *, stride=1, pad=None, bias=None, rowvec=None, res=
     gn_out = bool(gn_out) and gn_stats_wanted(B, Ho * Wo, N) and wide_tile_ok(N, w.shape[1])
     y = gemm(col, w, bias=bias, rowvec=rowvec, rows_per_rv=Ho * Wo, res=res, act=act, out=o2, gn_out=gn_out)
     r = y.view(B, Ho, Wo, N) if out is None else out
-    if gn_out:
-        set_gn_stats(r, get_gn_stats(y))
-    return r
+    return _written(r, get_gn_stats(y) if gn_out else None)
 
 
 # ----------------------------------------------------------------------------------------------
@@ -558,14 +543,14 @@ def groupnorm(x, gamma, beta, groups, eps, *, x2=None, silu=False, out=None):
                                           out.data_ptr(), out.stride(-2), B, HW, groups, eps,
                                           ACT_SILU if silu else ACT_NONE, _stream())
         _b.check(rc, f"pfd_groupnorm_pstats_f16 B{B} HW{HW} C{C1}+{C2}")
-        return out
+        return _written(out)
     wsb = lib.pfd_groupnorm_ws_bytes(B, C1 + C2, HW)
     ws = torch.empty(wsb, dtype=torch.uint8, device=x.device)
     rc = lib.pfd_groupnorm_f16(x.data_ptr(), C1, x.stride(-2), _ptr(x2), C2, 0 if x2 is None else x2.stride(-2),
                                gamma.data_ptr(), beta.data_ptr(), out.data_ptr(), out.stride(-2), B, HW, groups,
                                eps, ACT_SILU if silu else ACT_NONE, ws.data_ptr(), wsb, _stream())
     _b.check(rc, f"pfd_groupnorm_f16 B{B} HW{HW} C{C1}+{C2}")
-    return out
+    return _written(out)
 
 
 def groupnorm_table(x, gamma, beta, groups, eps, *, x2=None):
@@ -597,7 +582,7 @@ def layernorm(x, gamma, beta, eps=1e-5, out=None):
     rc = _lib().pfd_layernorm_f16(x.data_ptr(), ldx, gamma.data_ptr(), beta.data_ptr(), out.data_ptr(),
                                   _rows(out)[2], M, Cdim, eps, 0, 0, 0, 0, _stream())
     _b.check(rc, f"pfd_layernorm_f16 M{M} C{Cdim}")
-    return out
+    return _written(out)
 
 
 def layernorm_patch_merge(x, gamma, beta, eps=1e-5):
@@ -701,7 +686,7 @@ def add(a, b, out=None):
     if out is None:
         out = torch.empty_like(a)
     _b.check(_lib().pfd_add_f16(a.data_ptr(), b.data_ptr(), out.data_ptr(), a.numel(), _stream()), "pfd_add_f16")
-    return out
+    return _written(out)
 
 
 def axpby(a, alpha, b=None, beta=0.0, out=None):
@@ -715,7 +700,7 @@ def axpby(a, alpha, b=None, beta=0.0, out=None):
         out = torch.empty_like(a)
     _b.check(_lib().pfd_axpby_f16(a.data_ptr(), float(alpha), _ptr(b), float(beta), out.data_ptr(), a.numel(),
                                   _stream()), "pfd_axpby_f16")
-    return out
+    return _written(out)
 
 
 def add_rowvec(x, v, out=None, ln_out=None):
@@ -730,10 +715,10 @@ def add_rowvec(x, v, out=None, ln_out=None):
             raise ValueError("add_rowvec: ln_out must be a contiguous float32 [R, C/160, 2]")
         _b.check(_lib().pfd_add_rowvec_lnstats_f16(x.data_ptr(), ldx, v.data_ptr(), out.data_ptr(), _rows(out)[2], R, Cc,
                                                    ln_out.data_ptr(), _stream()), "pfd_add_rowvec_lnstats_f16")
-        return out
+        return _written(out)
     _b.check(_lib().pfd_add_rowvec_f16(x.data_ptr(), ldx, v.data_ptr(), out.data_ptr(), _rows(out)[2], R, Cc,
                                        _stream()), "pfd_add_rowvec_f16")
-    return out
+    return _written(out)
 
 
 def activation(x, act, out=None):
@@ -743,4 +728,4 @@ def activation(x, act, out=None):
     if out is None:
         out = torch.empty_like(x)
     _b.check(_lib().pfd_act_f16(x.data_ptr(), out.data_ptr(), x.numel(), act, _stream()), "pfd_act_f16")
-    return out
+    return _written(out)

@@ -129,7 +129,7 @@ class DDIMSampler(object):
         coef = self._coef_table(scale)
         time_range = np.flip(timesteps)
         total_steps = timesteps.shape[0]
-        # all step timestamps at once on the device: [total_steps, 1] int64 (a lane repeats it over its nb * n samples)
+        # all step timestamps at once on the device: [total_steps, 1] int64 (repeated over the nb * n samples of a step)
         t_col = torch.as_tensor(np.ascontiguousarray(time_range), device=device).long()[:, None]
         x_type, c_type = x_info['type'], c_info['type']
         stochastic = bool(np.any(np.asarray(self.ddim_sigmas) != 0.))
@@ -175,51 +175,29 @@ class DDIMSampler(object):
 
         use_graph = self.use_graph and not stochastic and callback is None and x.is_cuda
         if use_graph:
-            # Lanes (round 4): samples are independent for the whole trajectory, so the batch is cut into `lanes`
-            # sub-batches, each captured as its own hipGraph and replayed on its own HIP stream.  The ~20 k dependent
-            # launches of a trajectory then overlap their launch boundaries, prologues and tails with the other lanes'
-            # kernels instead of serialising them (the chip is idle ~1.5-1.9 us at every boundary of a single stream).
-            lanes = self._lane_count(bs)
-            per = bs // lanes
-            cur = torch.cuda.current_stream()
-            streams = self._lane_streams(lanes) if lanes > 1 else [cur]
-            ents = []
-            for li in range(lanes):
-                sl = slice(li * per, (li + 1) * per)
-                x_l = x[sl]
-                c_l = torch.cat([uc[sl], cond[sl]]) if cfg else cond[sl]
-                key = (tuple(x_l.shape), tuple(c_l.shape), None if hint is None else tuple(hint.shape), total_steps,
-                       float(scale), nb, x_type, c_type, int(log_every_t), per if zero_lead else 0,
-                       bool(self.share_cfg_prefix), hash(np.asarray(timesteps).tobytes()),
-                       self._weights_signature(), li)
-                ent = self._graphs.pop(key, None)
-                if ent is None:
-                    while len(self._graphs) >= self.max_graphs * lanes:
-                        torch.cuda.synchronize()   # never drop a graph whose replay may still be in flight
-                        self._graphs.pop(next(iter(self._graphs)))   # least recently used (a server varies batch size and
-                    run_loop, t_table = make_loop(per)                # scale per request: keep the others)
-                    with ops.workspace_slot(li):                      # concurrent lanes must not share split-K slabs
-                        ent = self._capture(run_loop, x_l, c_l, hint, (coef, t_table))
-                self._graphs[key] = ent            # (re-)inserted last = most recently used
-                ents.append((ent, x_l, c_l))
-            for li, (ent, x_l, c_l) in enumerate(ents):
-                g, sx, sc, sh, outs, _keep = ent
-                st = streams[li]
-                if st is not cur:
-                    st.wait_stream(cur)
-                with torch.cuda.stream(st):
-                    sx.copy_(x_l)
-                    sc.copy_(c_l)
-                    if sh is not None:
-                        sh.copy_(hint)
-                    g.replay()
-            for st in streams:
-                if st is not cur:
-                    cur.wait_stream(st)
-            outs = [e[0][4] for e in ents]          # static output buffers of the graphs: copied out on the caller's stream
-            xf = torch.cat([o[0] for o in outs]) if lanes > 1 else outs[0][0].clone()
-            ixt = [torch.cat(ts) if lanes > 1 else ts[0].clone() for ts in zip(*[o[1] for o in outs])]
-            ix0 = [torch.cat(ts) if lanes > 1 else ts[0].clone() for ts in zip(*[o[2] for o in outs])]
+            # one hipGraph per (shape, schedule, weights version, flags); static input buffers, replayed per request.
+            # (Round 4 also cut the batch into concurrent sub-batch graphs on their own streams: 520 -> 646 ms per batch at
+            #  C2, profiles/r04_lanes_ab.log -- removed in round 5.)
+            key = (tuple(x.shape), tuple(c_in.shape), None if hint is None else tuple(hint.shape), total_steps,
+                   float(scale), nb, x_type, c_type, int(log_every_t), zero_lead,
+                   bool(self.share_cfg_prefix), hash(np.asarray(timesteps).tobytes()), self._weights_signature())
+            ent = self._graphs.pop(key, None)
+            if ent is None:
+                while len(self._graphs) >= self.max_graphs:
+                    torch.cuda.synchronize()   # never drop a graph whose replay may still be in flight
+                    self._graphs.pop(next(iter(self._graphs)))   # least recently used (a server varies batch size and
+                run_loop, t_table = make_loop(bs)                 # scale per request: keep the others)
+                ent = self._capture(run_loop, x, c_in, hint, (coef, t_table))
+            self._graphs[key] = ent            # (re-)inserted last = most recently used
+            g, sx, sc, sh, outs, _keep = ent
+            sx.copy_(x)
+            sc.copy_(c_in)
+            if sh is not None:
+                sh.copy_(hint)
+            g.replay()
+            xf = outs[0].clone()               # static output buffers of the graph
+            ixt = [t.clone() for t in outs[1]]
+            ix0 = [t.clone() for t in outs[2]]
         else:
             run_loop, _ = make_loop(bs)
             xf, ixt, ix0 = run_loop(x, c_in, hint)
@@ -332,23 +310,6 @@ class DDIMSampler(object):
     max_graphs = 6   # captured trajectories kept (each owns a private memory pool); least recently used goes first
     zero_uncond_shortcut = True
     share_cfg_prefix = True
-
-    # sub-batch lanes of the graph path (see ddim_sampling): PFD_LANES in the environment, or set `.lanes`
-    lanes = int(__import__("os").environ.get("PFD_LANES", "1"))
-    _streams = None
-
-    def _lane_count(self, bs):
-        n = max(1, min(int(self.lanes), bs))
-        while bs % n:
-            n -= 1
-        return n
-
-    def _lane_streams(self, n):
-        if self._streams is None:
-            self._streams = []
-        while len(self._streams) < n:
-            self._streams.append(torch.cuda.Stream())
-        return self._streams[:n]
 
     def enable_graph(self, on=True):
         """Replay the whole DDIM trajectory as one captured hipGraph (eta = 0 only).  The graph is

@@ -44,7 +44,7 @@ class _OracleJobs:
     """The fp32 CPU-oracle trajectories of tests/test_hip_trajectory.py (tests/oracle_worker.py: C2 50 steps, C5 31 steps,
     C3 10 steps; 18 minutes of host time).  Default: read from tests/golden/trajectories.npz, which
     oracle/make_trajectory_golden.py wrote from exactly these oracle runs and which the CPU suite pins to the oracle
-    (test_oracle_golden.py::test_trajectory_fixture_first_step).  PFD_ORACLE_LIVE=1: recompute them -- as CPU-only
+    (test_oracle_golden.py::test_trajectory_fixture_first_and_last_step).  PFD_ORACLE_LIVE=1: recompute them -- as CPU-only
     subprocesses started at session begin, joined by the test that needs them.  (Round 4 measured both other ways on the GPU
     boxes, whose containers get about 64 threads' worth of CPU: in line the suite is 21 minutes; next to the suite the three
     jobs starve the other CPU-oracle checks and it is slower still.)"""

@@ -16,7 +16,7 @@ weights, reference image and x_T:
 
 The three oracle trajectories (18 minutes of host time) are read from tests/golden/trajectories.npz -- written by
 oracle/make_trajectory_golden.py from tests/oracle_worker.py's cases, pinned to the oracle on the CPU by
-tests/test_oracle_golden.py::test_trajectory_fixture_first_step; PFD_ORACLE_LIVE=1 recomputes them during the session.
+tests/test_oracle_golden.py::test_trajectory_fixture_first_and_last_step; PFD_ORACLE_LIVE=1 recomputes them during the session.
 
 Errors are printed both scaled (relative L2 / max-abs over max(1, max|ref|)) and as the plain max-abs.
 """

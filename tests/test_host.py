@@ -459,3 +459,18 @@ def test_gn_partials_reference_layout():
         blk = y[64:128, g0:g0 + N // 32].double()
         got = ref[slab, n // 160, (n % 160) // (N // 32)]
         assert abs(float(got[0] - blk.sum())) < 1e-9 and abs(float(got[1] - (blk * blk).sum())) < 1e-9
+
+
+def test_stale_groupnorm_statistics_are_dropped_on_rewrite():
+    """producer statistics ride on the tensor OBJECT (ops.set_gn_stats); any op that writes into that object again
+    without fresh ones must drop them (ops._written), or groupnorm() would normalise with the previous tensor's sums"""
+    from lib.hip import ops
+    t = torch.zeros(64, 320, dtype=torch.float16)
+    st = torch.zeros(1, 2, 16, 2)
+    ops.set_gn_stats(t, st)
+    assert ops.get_gn_stats(t) is st
+    assert ops._written(t) is t and ops.get_gn_stats(t) is None            # rewritten without statistics
+    st2 = torch.ones(1, 2, 16, 2)
+    assert ops.get_gn_stats(ops._written(t, st2)) is st2                   # rewritten with fresh ones
+    assert ops.get_gn_stats(t[:32]) is None                                # views do not inherit
+    assert ops._written(None) is None

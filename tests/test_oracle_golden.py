@@ -152,22 +152,29 @@ def test_multicontext_sampling(golden, param_shapes):
 
 
 @pytest.mark.parametrize("case", ["c2", "c3", "c5"])
-def test_trajectory_fixture_first_step(case):
+def test_trajectory_fixture_first_and_last_step(case):
     """tests/golden/trajectories.npz (the oracle trajectories the GPU suite compares whole DDIM runs with at the BASELINE
     shapes, oracle/make_trajectory_golden.py) is what THIS oracle computes: the first DDIM step of every case -- context
     encode (SeeCoder / SeeCoder-PA at 512x512 / 768x768), one CFG UNet evaluation (64x64 / 96x96 latent; with the
-    ControlNet residuals for c3), the DDIM update -- is recomputed here from the same seeds and compared.  (The remaining
-    steps repeat the same code on the result; PFD_ORACLE_LIVE=1 in a GPU session recomputes them all.)"""
+    ControlNet residuals for c3), the DDIM update -- is recomputed here from the same seeds and compared, and so is the LAST
+    step from the stored penultimate latent (the end of the schedule: a late indexing / schedule change in the oracle
+    cannot hide behind a correct first step).  The fixture's meta carries the digest of the oracle sources it was
+    written from: a changed oracle fails here until oracle/make_trajectory_golden.py is re-run.
+    (PFD_ORACLE_LIVE=1 in a GPU session recomputes the whole trajectories.)"""
     import oracle_worker as OW
     fx = dict(np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "trajectories.npz"), allow_pickle=False))
     meta = json.loads(str(fx["meta"]))
+    assert meta.get("oracle_sha256") == OW.oracle_digest(), \
+        f"tests/golden/trajectories.npz was written from other oracle sources ({meta.get('oracle_sources')}): re-run oracle/make_trajectory_golden.py"
     want_steps = {"c2": 50, "c3": 10, "c5": 31}[case]
     assert meta["cases"][case]["steps"] == want_steps
     with torch.no_grad():
         got = OW.CASES[case](OW._param_shapes(), stop_after=1)
-    assert got["steps"] == want_steps
+        last = OW.CASES[case](OW._param_shapes(), last_from=T(fx[f"{case}.penultimate"]))
+    assert got["steps"] == last["steps"] == want_steps
     ref = T(fx[f"{case}.first_step"])
     assert got["first_step"].shape == ref.shape == fx[f"{case}.latent"].shape
     # same arithmetic on another host / thread count: summation-order noise only
     assert rel_err(got["first_step"], ref) < 1e-4
+    assert rel_err(last["latent"], fx[f"{case}.latent"]) < 1e-4
     assert np.isfinite(fx[f"{case}.latent"]).all() and float(np.abs(fx[f"{case}.latent"]).max()) > 1.0
