@@ -34,7 +34,7 @@ extern "C" {
 #define PFD_ESHAPE (-2)   /* shape outside what the kernels are built for           */
 #define PFD_ELAUNCH (-3)  /* hipGetLastError() != hipSuccess after the launch       */
 
-#define PFD_ABI_VERSION 8
+#define PFD_ABI_VERSION 9
 
 typedef void* pfd_stream_t; /* hipStream_t */
 
@@ -173,6 +173,28 @@ typedef struct PfdGemmDesc {
    * Wide-tile kernels only: N % 160 == 0, N / 32 >= 8 and a divisor of 160 (N = 320 | 640 | 1280), M % 64 == 0,
    * act != GEGLU, no Ct / ln_out / bias_per_row; anything else is PFD_ESHAPE. */
   void* gn_out;
+  /* GroupNorm(32 groups)(+SiLU) of the OUTPUT inside the split-K reduction (ABI 9).  At the 8^2 / 16^2 UNet levels every
+   * 3x3 convolution splits its contraction (M <= 2048 rows cannot fill 256 CUs otherwise) and a reduction launch sums the
+   * fp32 slabs, applies the epilogue and stores the f16 result -- which a single-launch GroupNorm then reads once more to
+   * normalise it (`h = in_layers(x) + emb_out; h = out_layers(h)`: GroupNorm32 -> SiLU -> conv, openaimodel.py:254-272;
+   * eps 1e-5).  With gnf_y != NULL the reduction is done by blocks that own one (sample, group) slab of the output
+   * (gnf_rows rows x N / 32 channels): they form the epilogue's f16 values, their statistics and
+   *     gnf_y[m, n] = act((out[m, n] - mean) * rstd * gnf_gamma[n] + gnf_beta[n])      (act = NONE | SILU)
+   * in one launch; the raw result is ALSO stored to C unless gnf_skip_raw != 0 (a tensor only its GroupNorm reads: the
+   * first convolution of a ResBlock).  Same arithmetic, in the same order, as the plain reduction followed by
+   * pfd_groupnorm_f16 on its output: the same bits.  Served only where the library splits K (it decides; M small) and
+   * N % 160 == 0, (N / 32) % 4 == 0, gnf_rows * (N / 128) <= 8192, M % gnf_rows == 0, rowvec == NULL or one row vector per
+   * sample (rows_per_rv % gnf_rows == 0 or rows_per_rv >= M), act != GEGLU, no Ct / ln_stats / ln_out / gn_out; anything
+   * else -- including a problem the library would not split -- is PFD_ESHAPE with NOTHING launched: callers then run the
+   * two-call form (there is no slow path behind this one). */
+  const void* gnf_gamma; /* f16 [N] */
+  const void* gnf_beta;  /* f16 [N] */
+  void* gnf_y;           /* f16 [M, gnf_ldy] */
+  int64_t gnf_ldy;
+  float gnf_eps;
+  int32_t gnf_act;
+  int32_t gnf_rows;      /* rows per sample (Ho * Wo of a convolution) */
+  int32_t gnf_skip_raw;
 } PfdGemmDesc;
 int pfd_gemm_f16(const PfdGemmDesc* d, pfd_stream_t stream);
 /* Same, with the kernel variant forced (tests and tuning only); 0 = the library's heuristic.
@@ -326,10 +348,6 @@ int pfd_timestep_embedding_f16(const int64_t* t, void* out, int32_t B, int32_t d
 int pfd_cfg_ddim_step(const void* eps, int32_t nb, const float* x, const float* noise,
                       const float* coef, float* x_prev, float* pred_x0, void* xin_next, int32_t rep,
                       int32_t B, int32_t C, int32_t h, int32_t w, pfd_stream_t stream);
-/* Read `bytes` (ptr 16-byte aligned) and discard them: warms the memory-side cache / L2 for a launch that streams the same
- * data shortly afterwards.  No counterpart in the reference (torch leaves weight residency to the hardware); used for the
- * layer weights under PFD_WPREFETCH=1 (round-5 candidate, off by default).  No functional effect. */
-int pfd_prefetch(const void* ptr, size_t bytes, pfd_stream_t stream);
 /* y = a + b (f16, fp32 add), n elements; b may be NULL (copy). */
 int pfd_add_f16(const void* a, const void* b, void* y, int64_t n, pfd_stream_t stream);
 /* y = alpha*a + beta*b (f16 storage, fp32 math), n elements; b may be NULL (y = alpha*a).  The

@@ -31,10 +31,6 @@
 
 namespace {
 
-#ifndef ATT_ABL
-#define ATT_ABL 0   // measurement-only ablation bits: 1 no exp, 2 no PV MFMAs, 4 no K/V loads + staging, 8 no QK MFMAs
-#endif
-
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 struct AttnParams {
@@ -52,258 +48,10 @@ struct AttnParams {
 // allocation fits 128 without scratch and self-attention at N = 4096 gains 4.6 % (452 -> 473 TF), the 148-key
 // cross-attention 16 % (profiles/r02_attention_ablation.log).  A 128-key tile (half the barriers, 62 KB LDS,
 // 184 VGPRs) measured 2 % slower.  Larger head dims keep their natural allocation.
-template <int D, int KV_TILE>
-__global__ __launch_bounds__(256, (D <= 40 ? 4 : 1)) void attention_kernel(const AttnParams p) {
-  constexpr int NU = KV_TILE / 32;    // 32-key halves per tile
-  constexpr int VT_LD = KV_TILE + 4;  // halfs; 136-B rows: conflict-free ds_read_b64 over 32 rows
-  constexpr int DQK = (D + 15) / 16 * 16;
-  constexpr int DV = (D + 31) / 32 * 32;
-  constexpr int K_LD = DQK + 8;  // halfs; (DQK+8)*2 B is an odd multiple of 16 B for D in {40,80,96,160}
-  constexpr int NS = DQK / 16;
-  constexpr int ND = DV / 32;
-  constexpr bool SUM_MFMA = DV > D;       // a spare V^T row carries the softmax denominator
-  constexpr int KCH = D / 8;              // 16-B chunks per K row
-  constexpr int K_CHUNKS = KV_TILE * KCH; // per tile
-  constexpr int V_CHUNKS = D * (KV_TILE / 8);
-  constexpr int K_PT = (K_CHUNKS + 255) / 256;
-  constexpr int V_PT = (V_CHUNKS + 255) / 256;
-  constexpr int K_TILE_HALFS = KV_TILE * K_LD;
-  constexpr int V_TILE_HALFS = DV * VT_LD;
-  __shared__ __attribute__((aligned(16))) half_t Ks[2 * K_TILE_HALFS];
-  __shared__ __attribute__((aligned(16))) half_t Vts[2 * V_TILE_HALFS];
-
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int l31 = lane & 31, hi = lane >> 5;
-  // 1-D grid, XCD-aware: block id -> (sample*head, q block) such that all q blocks of one head run
-  // on ONE XCD (block b lands on XCD b % 8) and share that L2's copy of the head's K/V.  Without
-  // it every XCD fetches its own copy: 357 MB instead of 63 MB per launch at N = 4096 (PMC
-  // FETCH_SIZE, profiles/r01_pmc_traffic_per_shape.md).  Placement is speed only.
-  const int nqb = (p.Nq + 127) / 128;
-  const int lin = xcd_remap(blockIdx.x, gridDim.x);
-  const int bh = lin / nqb;
-  const int qb = lin - bh * nqb;
-  const int b = bh / p.H, h = bh - b * p.H;
-  const int q_row = qb * 128 + wave * 32 + l31;
-
-  // zero the LDS padding once (columns D..DQK of K, rows D..DV of V^T); row D of V^T = 1 (row sums)
-  for (int i = tid; i < 2 * K_TILE_HALFS; i += 256) Ks[i] = (half_t)0.f;
-  for (int i = tid; i < 2 * V_TILE_HALFS; i += 256) Vts[i] = (half_t)0.f;
-  __syncthreads();
-  if (SUM_MFMA) {
-    for (int i = tid; i < 2 * KV_TILE; i += 256)
-      Vts[(i / KV_TILE) * V_TILE_HALFS + D * VT_LD + (i % KV_TILE)] = (half_t)1.f;
-  }
-
-  // Q fragments: B operand, col = q = lane&31, k = d
-  half8_t qf[NS];
-  {
-    const half_t* qp = p.Q + (long)b * p.q_bs + (long)q_row * p.ldq + h * D;
-#pragma unroll
-    for (int s = 0; s < NS; ++s) {
-      const int d = s * 16 + hi * 8;
-      Pack16 t;
-      t.u = make_uint4(0, 0, 0, 0);
-      if (q_row < p.Nq && d < D) t.u = *reinterpret_cast<const uint4*>(qp + d);
-      qf[s] = t.h;
-    }
-  }
-
-  float16_t o_acc[ND];
-#pragma unroll
-  for (int i = 0; i < ND; ++i)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) o_acc[i][r] = 0.f;
-  float m_run = -INFINITY, l_run = 0.f;  // m_run: running max of the RAW scores
-
-  const half_t* kbase = p.K + (long)b * p.k_bs + h * D;
-  const half_t* vbase = p.Vt + (long)h * D * p.ldvt + (long)b * p.vt_bs;
-  const float c = p.scale_log2;
-
-  // one staging register set: tile t+1 is loaded (global -> registers) while tile t is computed and is
-  // written to the other LDS stage afterwards.  Rows / key chunks past Nk are CLAMPED to valid
-  // addresses rather than predicated per row (their scores are masked to -inf, so P = 0).
-  uint4 kregA[K_PT], vregA[V_PT];
-  const int v_last = max(0, ((p.Nk + 7) & ~7) - 8);
-  auto load_tile = [&](uint4* kreg, uint4* vreg, int kv0) {
-#pragma unroll
-    for (int j = 0; j < K_PT; ++j) {
-      const int ch = tid + 256 * j;
-      const int row = ch / KCH, cc = ch - row * KCH;
-      kreg[j] = make_uint4(0, 0, 0, 0);
-      if (ch < K_CHUNKS)
-        kreg[j] = *reinterpret_cast<const uint4*>(kbase + (long)min(kv0 + row, p.Nk - 1) * p.ldk + cc * 8);
-    }
-#pragma unroll
-    for (int j = 0; j < V_PT; ++j) {
-      const int ch = tid + 256 * j;
-      const int d = ch / (KV_TILE / 8), cc = ch % (KV_TILE / 8);
-      vreg[j] = make_uint4(0, 0, 0, 0);
-      if (ch < V_CHUNKS)   // key chunks past Nk are clamped (their P is 0); the ragged tile zeroes them below
-        vreg[j] = *reinterpret_cast<const uint4*>(vbase + (long)d * p.ldvt + min(kv0 + cc * 8, v_last));
-    }
-  };
-  // (the ragged-tile masking lives HERE, after the MFMAs of the current tile: touching the freshly loaded
-  //  registers inside load_tile made the compiler wait for the global loads before the MFMAs they are
-  //  supposed to overlap with)
-  auto store_tile = [&](const uint4* kreg, uint4* vreg, int stage, int kv0) {
-    half_t* Kd = Ks + stage * K_TILE_HALFS;
-    half_t* Vd = Vts + stage * V_TILE_HALFS;
-    if (kv0 + KV_TILE > p.Nk) {  // ragged last tile only (wave-uniform)
-#pragma unroll
-      for (int j = 0; j < V_PT; ++j) {
-        const int valid = p.Nk - (kv0 + ((tid + 256 * j) % (KV_TILE / 8)) * 8);  // valid halfs in this 8-chunk
-        unsigned w[4] = {vreg[j].x, vreg[j].y, vreg[j].z, vreg[j].w};
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const int v2 = valid - 2 * q;
-          w[q] = v2 >= 2 ? w[q] : (v2 == 1 ? (w[q] & 0xFFFFu) : 0u);
-        }
-        vreg[j] = make_uint4(w[0], w[1], w[2], w[3]);
-      }
-    }
-#pragma unroll
-    for (int j = 0; j < K_PT; ++j) {
-      const int ch = tid + 256 * j;
-      const int row = ch / KCH, cc = ch - row * KCH;
-      if (ch < K_CHUNKS) *reinterpret_cast<uint4*>(Kd + row * K_LD + cc * 8) = kreg[j];
-    }
-#pragma unroll
-    for (int j = 0; j < V_PT; ++j) {
-      const int ch = tid + 256 * j;
-      const int d = ch / (KV_TILE / 8), cc = ch % (KV_TILE / 8);
-      if (ch < V_CHUNKS) {
-        uint2* dst = reinterpret_cast<uint2*>(Vd + d * VT_LD + cc * 8);
-        dst[0] = make_uint2(vreg[j].x, vreg[j].y);
-        dst[1] = make_uint2(vreg[j].z, vreg[j].w);
-      }
-    }
-  };
-
-  const int ntiles = (p.Nk + KV_TILE - 1) / KV_TILE;
-  auto compute_tile = [&](int t, int stage) {
-    const int kv0 = t * KV_TILE;
-    const half_t* Kt = Ks + stage * K_TILE_HALFS;
-    const half_t* Vt = Vts + stage * V_TILE_HALFS;
-
-    // ---- S^T = K . Q^T for the two 32-key halves of the tile ----
-    float16_t st[NU];
-#pragma unroll
-    for (int u = 0; u < NU; ++u) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) st[u][r] = 0.f;
-      const half_t* kp = Kt + (u * 32 + l31) * K_LD + hi * 8;
-#pragma unroll
-      for (int s = 0; s < NS; ++s) {
-        const half8_t kf = *reinterpret_cast<const half8_t*>(kp + s * 16);
-        if (!(ATT_ABL & 8)) st[u] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[s], st[u], 0, 0, 0);
-        else st[u][s] += (float)kf[0] * (float)qf[s][0];
-      }
-    }
-    // ---- online softmax over this tile's 64 keys ----
-    if (kv0 + KV_TILE > p.Nk) {  // ragged last tile: keys past Nk never win the max nor add weight
-#pragma unroll
-      for (int u = 0; u < NU; ++u)
-#pragma unroll
-        for (int r = 0; r < 16; ++r)
-          if (kv0 + u * 32 + mfma32_row(r, hi) >= p.Nk) st[u][r] = -INFINITY;
-    }
-    float mx = st[0][0];
-#pragma unroll
-    for (int u = 0; u < NU; ++u)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) mx = fmaxf(mx, st[u][r]);
-    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-    const float m_new = fmaxf(m_run, mx);  // finite: every tile holds at least one valid key
-    if (__any(m_new > m_run)) {            // wave-uniform: rescale only when some row's max moved
-      const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c);
-      l_run *= alpha;
-#pragma unroll
-      for (int i = 0; i < ND; ++i)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) o_acc[i][r] *= alpha;
-      m_run = m_new;
-    }
-    const float mc = m_run * c;
-    float rs = 0.f;
-    half8_t pf[NU][2];
-#pragma unroll
-    for (int u = 0; u < NU; ++u)
-#pragma unroll
-      for (int bb = 0; bb < 2; ++bb)
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          const float e = (ATT_ABL & 1) ? fmaf(st[u][bb * 8 + j], c, -mc) : __builtin_amdgcn_exp2f(fmaf(st[u][bb * 8 + j], c, -mc));
-          if (!SUM_MFMA) rs += e;
-          pf[u][bb][j] = (half_t)e;
-        }
-    if (!SUM_MFMA) {
-      rs += __shfl_xor(rs, 32, 64);
-      l_run += rs;
-    }
-
-    // ---- O^T += V^T . P^T ----
-#pragma unroll
-    for (int i = 0; i < ND; ++i) {
-      const half_t* vp = Vt + (i * 32 + l31) * VT_LD + 4 * hi;
-#pragma unroll
-      for (int u = 0; u < NU; ++u)
-#pragma unroll
-        for (int bb = 0; bb < 2; ++bb) {
-          const half4_t lo4 = *reinterpret_cast<const half4_t*>(vp + u * 32 + bb * 16);
-          const half4_t hi4 = *reinterpret_cast<const half4_t*>(vp + u * 32 + bb * 16 + 8);
-          half8_t vf;
-          vf[0] = lo4[0]; vf[1] = lo4[1]; vf[2] = lo4[2]; vf[3] = lo4[3];
-          vf[4] = hi4[0]; vf[5] = hi4[1]; vf[6] = hi4[2]; vf[7] = hi4[3];
-          if (!(ATT_ABL & 2)) o_acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf[u][bb], o_acc[i], 0, 0, 0);
-          else o_acc[i][0] += (float)pf[u][bb][0] + (float)vf[0];
-        }
-    }
-  };
-
-  load_tile(kregA, vregA, 0);
-  store_tile(kregA, vregA, 0, 0);
-  // vmcnt(0) on EVERY path into the loop (the waits above sit inside exec-masked blocks): otherwise the
-  // compiler must assume the Q fragments may still be in flight at the first MFMA of each tile and, vmcnt
-  // being an in-order counter, drains the just-issued K/V prefetch there as well
-  __builtin_amdgcn_s_waitcnt(0x0F70);
-  __syncthreads();
-  for (int t = 0; t < ntiles; ++t) {
-    const int stage = t & 1;
-    if (t + 1 < ntiles && !(ATT_ABL & 4)) load_tile(kregA, vregA, (t + 1) * KV_TILE);  // in flight during this tile's MFMAs
-    compute_tile(t, stage);
-    if (t + 1 < ntiles && !(ATT_ABL & 4)) store_tile(kregA, vregA, stage ^ 1, (t + 1) * KV_TILE);
-    __syncthreads();
-  }
-
-  // ---- epilogue: O[q, d] = O^T[d, q] / l ----
-  if (SUM_MFMA) {
-    // row D of O^T = sum_kv P: tile D/32, local row D%32 -> register r with mfma32_row(r, hi') = D%32
-    constexpr int lr = D % 32;
-    constexpr int src_hi = (lr >> 2) & 1;
-    constexpr int reg = (lr & 3) + 4 * (lr >> 3);
-    const float v = o_acc[D / 32][reg];
-    l_run = __shfl(v, src_hi * 32 + l31, 64);
-  }
-  if (q_row < p.Nq) {
-    const float inv = 1.0f / l_run;
-    half_t* op = p.O + (long)b * p.o_bs + (long)q_row * p.ldo + h * D;
-#pragma unroll
-    for (int i = 0; i < ND; ++i)
-#pragma unroll
-      for (int rq = 0; rq < 4; ++rq) {
-        const int d0 = i * 32 + 8 * rq + 4 * hi;
-        if (d0 < D) {
-          half4_t o;
-#pragma unroll
-          for (int e = 0; e < 4; ++e) o[e] = (half_t)(o_acc[i][rq * 4 + e] * inv);
-          *reinterpret_cast<half4_t*>(op + d0) = o;
-        }
-      }
-  }
-}
-
+// (The round-2 kernel this describes -- attention_kernel<D, 64>, PFD_ATTN=0 -- and the intermediate stages PFD_ATTN=1..5 were
+//  removed in round 5; git history and profiles/r03_attention_modes.log hold their measurements.)
 // ------------------------------------------------------------------------------------------------
-// Round-3 form of the kernel above (same math, same LDS K image, same transposed formulation):
+// The attention kernel (round 3 on; same math, same LDS K image, same transposed formulation as the round-2 kernel):
 //  * the ragged last KV tile is PEELED: the loop over full tiles has no key masking, no clamped row indices and no
 //    64-bit address arithmetic (per-thread source pointers advance by a constant per tile).  The ISA of the old loop
 //    spent ~60 of its ~200 VALU instructions per tile on that, and the softmax path is VALU bound at d = 40.
@@ -327,14 +75,11 @@ __global__ __launch_bounds__(256, (D <= 40 ? 4 : 1)) void attention_kernel(const
 //    accumulator rescale -- sees the same rounded number, so the rounding cancels in O / l exactly like any other
 //    common factor.  The maximum is only RAISED when a row's tile maximum exceeds the folded one by more than 6 (P <= 64
 //    in f16; the guide's T13 deferred rescale), or on the first tile; that path subtracts the increment explicitly.
-// PRIO (round-5 candidate, PFD_ATTN=7, never the default and not yet run on hardware): s_setprio(1) around the two MFMA
-// clusters of a tile (the guide's T5: +4-7 % on attention kernels whose waves are in different phases -- here the two
-// 8-wave blocks of a CU are not synchronised with each other, so a wave in its softmax competes with a wave in its MFMAs)
-// ZF (round-5 candidate, PFD_ATTN=8 = the default mode + ZF, never run on hardware): the LDS image is cleared with 16-byte
-// stores.  The plain form is a rolled loop of ds_write_b16 -- 7 instructions and a branch per HALF: 169 trips per thread at
-// d = 160 (43 KB of tiles on 256 threads), ~2 us of an 18 us launch, 95 trips at d = 80 -- on the launches whose whole K / V
-// fits in a handful of tiles.  Same bytes cleared, nothing else changes: the same bits as mode 6.
-template <int D, int NWAVES, bool PV16, bool FOLD = false, bool PRIO = false, bool ZF = false>
+// The LDS image (K / V^T tiles incl. padding) is cleared with 16-byte stores before the first tile (round 5: the rolled loop of
+// ds_write_b16 it replaces was 169 trips per thread at d = 160, ~2 us of an 18 us launch; -0.95 % per batch, same bits --
+// profiles/r05_e2e_ab_candidates.log.  s_setprio(1) around the two MFMA clusters of a tile, the guide's T5, measured +0.2 %
+// here and is not compiled in.)
+template <int D, int NWAVES, bool PV16, bool FOLD = false>
 __global__ __launch_bounds__(NWAVES * 64, (D <= 40 ? 4 : 1)) void attention2_kernel(const AttnParams p) {
   static_assert(!PV16 || D == 40, "the 16x16x32 PV path is laid out for d = 40 (48 padded rows, row 40 = ones)");
   static_assert(!FOLD || D == 40, "the folded maximum uses contraction slot 40 of the d = 40 build (DQK = 48)");
@@ -369,13 +114,9 @@ __global__ __launch_bounds__(NWAVES * 64, (D <= 40 ? 4 : 1)) void attention2_ker
   const int b = bh / p.H, h = bh - b * p.H;
   const int q_row = qb * QB + wave * 32 + l31;
 
-  if constexpr (ZF) {
-    static_assert((2 * K_TILE_HALFS + 2 * V_TILE_HALFS) % 8 == 0, "16-byte clears");
-    for (int i = tid; i < (2 * K_TILE_HALFS + 2 * V_TILE_HALFS) / 8; i += NTHR)
-      reinterpret_cast<uint4*>(lds)[i] = make_uint4(0, 0, 0, 0);
-  } else {
-    for (int i = tid; i < 2 * K_TILE_HALFS + 2 * V_TILE_HALFS; i += NTHR) lds[i] = (half_t)0.f;
-  }
+  static_assert((2 * K_TILE_HALFS + 2 * V_TILE_HALFS) % 8 == 0, "16-byte clears");
+  for (int i = tid; i < (2 * K_TILE_HALFS + 2 * V_TILE_HALFS) / 8; i += NTHR)
+    reinterpret_cast<uint4*>(lds)[i] = make_uint4(0, 0, 0, 0);
   __syncthreads();
   if (SUM_MFMA) {   // row D of V^T = 1: O^T[D, q] accumulates sum_kv P (every slot of the row, so the swizzle is moot)
     for (int i = tid; i < 2 * KV_TILE; i += NTHR)
@@ -528,7 +269,6 @@ __global__ __launch_bounds__(NWAVES * 64, (D <= 40 ? 4 : 1)) void attention2_ker
     const half_t* Kt = Ks + stage * K_TILE_HALFS;
     const half_t* Vt = Vts + stage * V_TILE_HALFS;
     float16_t st[NU];
-    if constexpr (PRIO) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
     for (int u = 0; u < NU; ++u) {
 #pragma unroll
@@ -540,7 +280,6 @@ __global__ __launch_bounds__(NWAVES * 64, (D <= 40 ? 4 : 1)) void attention2_ker
         st[u] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[s], st[u], 0, 0, 0);
       }
     }
-    if constexpr (PRIO) __builtin_amdgcn_s_setprio(0);
     if (RAG) {
 #pragma unroll
       for (int u = 0; u < NU; ++u)
@@ -638,8 +377,7 @@ __global__ __launch_bounds__(NWAVES * 64, (D <= 40 ? 4 : 1)) void attention2_ker
         pb[u][0] = r0.h;
         pb[u][1] = r1.h;
       }
-      if constexpr (PRIO) __builtin_amdgcn_s_setprio(1);
-#pragma unroll
+  #pragma unroll
       for (int i = 0; i < NDT; ++i)
 #pragma unroll
         for (int u = 0; u < NU; ++u) {
@@ -652,8 +390,7 @@ __global__ __launch_bounds__(NWAVES * 64, (D <= 40 ? 4 : 1)) void attention2_ker
           o16[i][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf, pb[u][0], o16[i][0], 0, 0, 0);
           o16[i][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf, pb[u][1], o16[i][1], 0, 0, 0);
         }
-      if constexpr (PRIO) __builtin_amdgcn_s_setprio(0);
-    } else {
+      } else {
 #pragma unroll
       for (int i = 0; i < ND; ++i) {
         const half_t* vp = Vt + (i * 32 + l31) * VT_LD + 4 * hi;
@@ -942,15 +679,7 @@ static int launch512(const AttnParams& p, hipStream_t s) {
   return pfd_check_launch("pfd_attention_f16");
 }
 
-// PFD_ATTN: 0 = round-2 kernel; 1 = peeled loop, 4 waves, PV on 32x32x16; 2 = + 8 waves per block (d = 40, big grids);
-// 3 = 4 waves + PV on 16x16x32 (d = 40); 4 = 8 waves + PV on 16x16x32 where 8-wave blocks apply, mode 1 elsewhere;
-// 5 = mode 2 + the maximum folded into the QK^T MFMA; 6 (default) = mode 4 + fold; 7 = mode 6 + s_setprio around the MFMA
-// clusters (round-5 candidate, unmeasured); 8 = mode 6 + 16-byte clears of the LDS image in every head dim (round-5 candidate, unmeasured).
-// PFD_ATTN_FORCE8=1 takes the 8-wave form for every d = 40 problem (tests).
-static int attn_mode() {
-  static const int m = getenv("PFD_ATTN") ? atoi(getenv("PFD_ATTN")) : 6;
-  return m;
-}
+// PFD_ATTN_FORCE8=1 takes the 8-wave form for every d = 40 problem (test hook: selftest --attn, tools/cpu_emu).
 static bool attn_force8() {
   static const bool f = getenv("PFD_ATTN_FORCE8") && atoi(getenv("PFD_ATTN_FORCE8")) != 0;
   return f;
@@ -962,28 +691,17 @@ int launch(const AttnParams& p, hipStream_t s) {
   if (prof)
     pfd_prof_begin(8, 4.0 * p.B * p.H * (double)p.Nq * p.Nk * D,
                    2.0 * p.B * p.H * D * (2.0 * p.Nq + 2.0 * p.Nk), s);
-  const int mode = attn_mode();
   // 8-wave blocks pay when a block has many queries to amortise the staging over and the grid still fills the chip twice
   const bool big = p.Nq >= 1024 && (long)p.B * p.H * ((p.Nq + 255) / 256) >= 512;
-  const bool w8 = (mode == 2 || mode == 4 || mode == 5 || mode == 6 || mode == 7 || mode == 8) && D == 40 && (big || attn_force8());
+  const bool w8 = D == 40 && (big || attn_force8());
   const int qb = w8 ? 256 : 128;
   dim3 grid(((p.Nq + qb - 1) / qb) * p.H * p.B);
-  if (mode == 0) {
-    hipLaunchKernelGGL((attention_kernel<D, 64>), grid, dim3(256), 0, s, p);
-  } else if constexpr (D == 40) {
-    const bool pv16 = mode == 3 || ((mode == 4 || mode == 6 || mode == 7 || mode == 8) && w8);   // (the 4-wave PV16 build spills 24 bytes at 128 VGPRs)
-    if (w8 && mode == 8) hipLaunchKernelGGL((attention2_kernel<D, 8, true, true, false, true>), grid, dim3(512), 0, s, p);
-    else if (mode == 8) hipLaunchKernelGGL((attention2_kernel<D, 4, false, false, false, true>), grid, dim3(256), 0, s, p);
-    else if (w8 && mode == 7) hipLaunchKernelGGL((attention2_kernel<D, 8, true, true, true>), grid, dim3(512), 0, s, p);
-    else if (w8 && mode == 6) hipLaunchKernelGGL((attention2_kernel<D, 8, true, true>), grid, dim3(512), 0, s, p);
-    else if (w8 && mode == 5) hipLaunchKernelGGL((attention2_kernel<D, 8, false, true>), grid, dim3(512), 0, s, p);
-    else if (w8 && pv16) hipLaunchKernelGGL((attention2_kernel<D, 8, true>), grid, dim3(512), 0, s, p);
-    else if (w8) hipLaunchKernelGGL((attention2_kernel<D, 8, false>), grid, dim3(512), 0, s, p);
-    else if (pv16) hipLaunchKernelGGL((attention2_kernel<D, 4, true>), grid, dim3(256), 0, s, p);
+  if constexpr (D == 40) {
+    // 8 waves: PV on 16x16x32 + the maximum folded into the QK^T MFMA (the 4-wave PV16 build spills 24 bytes at 128 VGPRs)
+    if (w8) hipLaunchKernelGGL((attention2_kernel<D, 8, true, true>), grid, dim3(512), 0, s, p);
     else hipLaunchKernelGGL((attention2_kernel<D, 4, false>), grid, dim3(256), 0, s, p);
   } else {
-    if (mode == 8) hipLaunchKernelGGL((attention2_kernel<D, 4, false, false, false, true>), grid, dim3(256), 0, s, p);
-    else hipLaunchKernelGGL((attention2_kernel<D, 4, false>), grid, dim3(256), 0, s, p);
+    hipLaunchKernelGGL((attention2_kernel<D, 4, false>), grid, dim3(256), 0, s, p);
   }
   if (prof) pfd_prof_end(s);
   return pfd_check_launch("pfd_attention_f16");

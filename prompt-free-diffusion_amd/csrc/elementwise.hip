@@ -302,35 +302,6 @@ extern "C" int pfd_cfg_ddim_step(const void* eps, int32_t nb, const float* x, co
   return pfd_check_launch("pfd_cfg_ddim_step");
 }
 
-// pfd_prefetch: read `bytes` of read-only data and throw it away -- the lines pass through the memory-side cache (and the L2
-// of the XCDs that run the blocks), so a launch that streams them a little later finds them warm.  The weights of a UNet step
-// (1.7 GB) pass through the 256 MB cache between two uses of a layer: every weight tile is an HBM miss when its GEMM asks
-// for it, and the chip-filling-once GEMMs are chains of such round trips.  Round-5 candidate, used by
-// lib/hip/ops.py under PFD_WPREFETCH=1 only (a side stream one or two launches ahead of the consumer); no functional effect.
-__global__ __launch_bounds__(256) void prefetch_kernel(const uint4* __restrict__ p, long n16, unsigned* __restrict__ sink) {
-  unsigned acc = 0;
-  long i = (long)blockIdx.x * 256 + threadIdx.x;
-  const long stride = (long)gridDim.x * 256;
-  for (; i + 3 * stride < n16; i += 4 * stride) {   // four independent 16-byte loads in flight per thread
-    const uint4 a = p[i], b = p[i + stride], c = p[i + 2 * stride], d = p[i + 3 * stride];
-    acc ^= a.x ^ b.y ^ c.z ^ d.w;
-  }
-  for (; i < n16; i += stride) acc ^= p[i].x;
-  if (acc == 0x9E3779B9u && sink) *sink = acc;      // (never: keeps the loads alive without a store)
-}
-
-extern "C" int pfd_prefetch(const void* ptr, size_t bytes, pfd_stream_t stream) {
-  if (!ptr || (reinterpret_cast<uintptr_t>(ptr) & 15)) return PFD_EINVAL;
-  const long n16 = (long)(bytes / 16);
-  if (n16 <= 0) return 0;
-  // 64 KB per block (16 loads of 16 bytes per thread), at most 512 blocks: a 29 MB conv weight is one wave of blocks
-  long blocks = (n16 + 4095) / 4096;
-  if (blocks > 512) blocks = 512;
-  hipLaunchKernelGGL(prefetch_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (const uint4*)ptr, n16,
-                     (unsigned*)nullptr);
-  return pfd_check_launch("pfd_prefetch");
-}
-
 extern "C" int pfd_add_f16(const void* a, const void* b, void* y, int64_t n, pfd_stream_t stream) {
   if (!a || !y || n <= 0) return PFD_EINVAL;
   if ((reinterpret_cast<uintptr_t>(a) & 15) || (reinterpret_cast<uintptr_t>(y) & 15) ||

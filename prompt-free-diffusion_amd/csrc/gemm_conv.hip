@@ -346,6 +346,10 @@ extern "C" int pfd_gemm_f16_ex(const PfdGemmDesc* d, int32_t tile, pfd_stream_t 
     pfd_set_error("pfd_gemm_f16: GroupNorm statistics of the output are emitted by the wide-tile kernels only (see PfdGemmDesc.gn_out)");
     return PFD_ESHAPE;
   }
+  if (d->gnf_y) {
+    pfd_set_error("pfd_gemm_f16: the fused GroupNorm lives in the split-K reduction of the wide-tile kernels only (see PfdGemmDesc.gnf_y)");
+    return PFD_ESHAPE;
+  }
   if (d->k_split > 0 || d->zero_rows > 0) {
     pfd_set_error("pfd_gemm_f16: k_split / zero_rows are served by the wide-tile linear kernels only (see PfdGemmDesc.k_split)");
     return PFD_ESHAPE;

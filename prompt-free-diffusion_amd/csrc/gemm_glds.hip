@@ -100,15 +100,14 @@ __device__ __forceinline__ const half_t* w_row_ptr(const G160Params& p, int n, i
   return p.W + ((long)tn * (p.K / BK) * p.w_tu + (n - tn * p.w_tu)) * BK + c8;
 }
 
-// PFD_FAST_PROLOGUE (compile-time switch, OFF in the shipped build: `make EXTRA=-DPFD_FAST_PROLOGUE`; round-5 candidate, never
-// run on hardware, emulation-validated).  The ISA of these kernels runs 460-980 instructions before the FIRST operand load is
-// issued (DESIGN work queue 4c); two mechanical causes are removed under the switch:
-//   * the kernel arguments arrive in 3-5 dependent s_load -> s_waitcnt batches because hipcc sinks each argument load into the
+// Kernel prologues (round 5).  The ISA of these kernels ran 460-980 instructions before the FIRST operand load was issued;
+// two mechanical causes are removed (linears: 462-639 -> 361-515 instructions, 3-5 -> 2-3 argument waits; -0.5 % per batch on
+// MI355X, profiles/r05_e2e_ab_candidates.log, same results bit for bit):
+//   * the kernel arguments arrived in 3-5 dependent s_load -> s_waitcnt batches because hipcc sinks each argument load into the
 //     branch that first uses it: PFD_ARG_BATCH names the scalars of the setup in one statement at entry (one batch);
-//   * w_row_ptr divides by the weight layout's tile width once per weight piece, although that width is the kernel's own tile
+//   * w_row_ptr divided by the weight layout's tile width once per weight piece, although that width is the kernel's own tile
 //     width (or half of it, for the 320-wide GEGLU tile): w_row_ptr_tile forms the same address from the tile index.
-// With the switch off every kernel compiles to the instruction stream of the GPU-validated library (tools/isa_diff.py).
-#if defined(PFD_FAST_PROLOGUE) && !defined(PFD_CPU_EMU)
+#if !defined(PFD_CPU_EMU)
 #define PFD_ARG_BATCH_LIN(p)                                                                                              \
   asm volatile("" ::"s"((p).tiles_m), "s"((p).tiles_n), "s"((p).nmajor), "s"((p).kt_per_split), "s"((p).K), "s"((p).M),      \
                "s"((p).zero_rows), "s"((p).k_split), "s"((p).krot), "s"((p).w_tu), "s"((p).A), "s"((p).A2), "s"((p).W),      \
@@ -130,11 +129,7 @@ __device__ __forceinline__ const half_t* w_row_ptr_tile(const G160Params& p, int
   const int tn = tile_n * (BN_ > 160 ? 2 : 1) + sub;
   return p.W + ((long)tn * (p.K / BK) * p.w_tu + (r - sub * p.w_tu)) * BK + c8;
 }
-#ifdef PFD_FAST_PROLOGUE
 #define PFD_W_ROW_PTR(BN_, p, tile_n, n0, r, c8) w_row_ptr_tile<BN_>(p, tile_n, r, c8)
-#else
-#define PFD_W_ROW_PTR(BN_, p, tile_n, n0, r, c8) w_row_ptr(p, (n0) + (r), c8)
-#endif
 
 // Epilogue operands read LATE.  hipcc loads every kernel-argument field a kernel uses with one batch of s_load at the entry
 // and keeps it in SGPRs until its last use: the ~25 scalars only the epilogue needs (bias / row-vector / residual / output
@@ -899,276 +894,6 @@ __global__ __launch_bounds__(WAVES_M * 128) void gemm160_kernel(const G160Params
 }
 
 // ------------------------------------------------------------------------------------------------
-// Round-5 candidate, forced only (variants 27 / 45 / 85; never the automatic choice, not yet run on hardware): the ring
-// kernel of the linear layers with the ACTIVATION fragments loaded global -> VGPR and only the weights on the LDS ring.
-// Why: the chip-filling-once linears (16^2 / 8^2 levels, ff-out, cond-half projections) are a chain of K-tile round
-// trips (nk / DEPTH x ~1.9 us cold); K tiles in flight are capped by the 160 KiB of LDS -- 3 of 28 KB on the
-// 64-row tile (variant 23), 4 with the 5-stage ring (26).  A wave's own A fragments are exactly what the MFMA's B slot
-// wants -- lane (l15, g) holds halfs [32 ks + 8 g, + 8) of row l15 = one 16-byte load per fragment -- and only the two
-// waves of a row block share them, so they need not go through LDS at all: a stage is then the 20 KB weight tile alone,
-// 7 stages = 6 K tiles in flight in 140 KB, and the A fragments of those 6 tiles wait in registers (WMB x 2 x 4 VGPRs
-// per tile; a 4-wave block owns the CU's whole register file).  Same K walk, same fragment values, same MFMA order per
-// accumulator, same epilogue as gemm160_kernel<., ., false, ., 5>: results must be bit-identical to variants 23 / 43 / 83
-// (selftest --r5 compares them launch by launch).
-// The A loads are asm statements hipcc does not count (guide 5.7, form (iii)): written as plain loads, the waitcnt pass
-// merges the conditional issues of prologue and loop conservatively and drains the whole queue (vmcnt(0)) in front of the
-// MFMAs of slot 0, once per trip round the ring.  They are issued BEFORE the weight pieces of their K tile, so the
-// counted wait in front of the barrier -- the only VM wait of the loop -- covers them; an empty "+v" statement per
-// register behind the barrier keeps every consumer below it.
-// ------------------------------------------------------------------------------------------------
-typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ u32x4_t gld16_uncounted(const void* src) {
-  u32x4_t d;
-  asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(d) : "v"((const __attribute__((address_space(1))) void*)src) : "memory");
-  return d;
-}
-// MINW = waves per SIMD the register allocation must leave room for: 1 for the 7-stage forms (one 140 KB block per CU), 4 for
-// the 3-stage form of the 128-row tile (variant 86: two 60 KB blocks of 8 waves per CU, as the 2-stage kernel it replaces)
-template <int WAVES_M, int WMB, int NBUF, bool CONV = false, int MINW = 1>
-__global__ __launch_bounds__(WAVES_M * 128, MINW) void gemm160ar_kernel(const G160Params p) {
-  constexpr int NT = 5;
-  constexpr int BN = 32 * NT;
-  constexpr int NW = WAVES_M * 2;
-  constexpr int BM = WAVES_M * WMB * 16;
-  constexpr int B_INSTR = BN / 8;                  // 20 weight pieces of 1 KiB per K tile
-  constexpr int B_PER_WAVE = (B_INSTR + NW - 1) / NW;
-  constexpr bool B_DUP = B_INSTR % NW != 0;        // surplus slots re-issue the piece NW below: same count in every wave
-  constexpr int STAGE = BN * ROWB;                 // weights only
-  constexpr int MAIN_BYTES = NBUF * STAGE;
-  constexpr int DEPTH = NBUF - 1;
-  static_assert(NBUF >= 3, "ring kernel");
-  static_assert(MAIN_BYTES + BM * 8 <= 160 * 1024, "weight ring exceeds the 160 KiB LDS");
-  static_assert(BM * stage_row_bytes(BN) <= MAIN_BYTES, "the epilogue's staging image reuses the weight ring");
-  static_assert(WAVES_M * 128 >= BM, "one thread per row forms the LayerNorm statistics");
-  __shared__ __attribute__((aligned(1024))) char smem[MAIN_BYTES + (CONV ? 0 : BM * 8)];
-  float2* const lnstat = reinterpret_cast<float2*>(smem + MAIN_BYTES);
-
-  // ONE batch of argument loads.  hipcc sinks each kernel-argument load into the branch that first uses it, so the setup below
-  // ran four dependent s_load -> s_waitcnt lgkmcnt(0) round trips (the argument block spans five cache lines) before the
-  // first operand load could be issued; naming the scalars the setup needs in one asm statement puts all their loads here.
-  asm volatile("" ::"s"(p.tiles_m), "s"(p.tiles_n), "s"(p.nmajor), "s"(p.kt_per_split), "s"(p.K), "s"(p.M), "s"(p.zero_rows),
-               "s"(p.k_split), "s"(p.krot), "s"(p.w_tu), "s"(p.A), "s"(p.A2), "s"(p.W), "s"(p.lda), "s"(p.lda2), "s"(p.ldw),
-               "s"(p.w_kstep));
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave >> 1, wn = wave & 1;
-  const int l15 = lane & 15, g = lane >> 4;
-
-  const int nblk = p.tiles_m * p.tiles_n;
-  const int t = xcd_remap(blockIdx.x, nblk);
-  const int tile_m = p.nmajor ? t % p.tiles_m : t / p.tiles_n;
-  const int tile_n = p.nmajor ? t / p.tiles_m : t - tile_m * p.tiles_n;
-  const int m0 = tile_m * BM;
-  const int n0 = tile_n * BN;
-  const int split = blockIdx.z;
-  const int kt_begin = split * p.kt_per_split;
-  const int nk_total = p.K / BK;
-  const int kt_end = min(nk_total, kt_begin + p.kt_per_split);
-
-  // A fragments: this lane's 16-byte chunk g of row (wm WMB + i) 16 + l15; rows past M / below zero_rows read the zero
-  // page (their K offset is held at 0: the page is 256 bytes).  Convolutions: the row is an output pixel, its source
-  // pixel changes with the tap (tap outer, channel block inner -- the K walk of gemm160_kernel<., ., true>), padding
-  // reads the zero page.
-  const half_t* a_ptr[WMB];
-  const half_t* a2_ptr[WMB];
-  int a_adv[WMB];
-  int a_oy[WMB], a_ox[WMB];
-  long a_img[WMB];
-  bool a_ok[WMB];
-#pragma unroll
-  for (int i = 0; i < WMB; ++i) {
-    const int m = m0 + (wm * WMB + i) * 16 + l15;
-    if constexpr (CONV) {
-      const int hw = p.Ho * p.Wo;
-      const int b = m / hw;
-      const int rem = m - b * hw;
-      const int oy = rem / p.Wo;
-      a_ok[i] = m < p.M;
-      a_oy[i] = oy * p.stride - p.pad;
-      a_ox[i] = (rem - oy * p.Wo) * p.stride - p.pad;
-      a_img[i] = (long)b * p.H * p.Wd * p.lda;
-      a_ptr[i] = a2_ptr[i] = p.A;
-      a_adv[i] = 1;
-    } else {
-      const int mz = m - p.zero_rows;
-      const bool ok = m < p.M && mz >= 0;
-      a_ptr[i] = ok ? p.A + (long)mz * p.lda + g * 8 : g_zero_page + g * 8;
-      a2_ptr[i] = ok ? p.A2 + (long)mz * p.lda2 + g * 8 : g_zero_page + g * 8;
-      a_adv[i] = ok ? 1 : 0;
-      a_ok[i] = ok;
-      a_oy[i] = a_ox[i] = 0;
-      a_img[i] = 0;
-    }
-  }
-  const int Hin = p.ups ? 2 * p.H : p.H;
-  const int Win = p.ups ? 2 * p.Wd : p.Wd;
-  const int srow = lane >> 3;
-  const int cpos = lane & 7;
-  const half_t* b_ptr[B_PER_WAVE];
-#pragma unroll
-  for (int j = 0; j < B_PER_WAVE; ++j) {
-    int q = wave + NW * j;
-    if (q >= B_INSTR) q = B_DUP ? q - NW : 0;
-    const int r = q * 8 + srow;
-    const int c = cpos ^ ((r >> 1) & 7);
-    // (w_row_ptr without its division: this kernel's tile IS the weight layout's tile, so row n0 + r of the K-tile-contiguous
-    //  layout is row r of tile tile_n -- the ten v_rcp divisions were a quarter of the ~590 instructions in front of the first load)
-    b_ptr[j] = p.w_tu == 0 ? p.W + (long)(n0 + r) * p.ldw + c * 8 : p.W + ((long)tile_n * nk_total * BN + r) * BK + c * 8;
-  }
-
-  const int nsteps = (!CONV && m0 + BM <= p.zero_rows) ? 0 : kt_end - kt_begin;
-  int kt_issue = kt_begin + k_rotation(p.krot, tile_m, p.tiles_m, nsteps);
-  int tap_ky = 0, tap_kx = 0, ci0 = 0;
-  const half_t* a_tap[WMB];   // conv: this lane's source chunk for the current tap at channel 0 (nullptr = padding)
-  auto set_tap = [&]() {
-#pragma unroll
-    for (int i = 0; i < WMB; ++i) {
-      int iy = a_oy[i] + tap_ky, ix = a_ox[i] + tap_kx;
-      const bool ok = a_ok[i] && iy >= 0 && iy < Hin && ix >= 0 && ix < Win;
-      if (p.ups) {
-        iy >>= 1;
-        ix >>= 1;
-      }
-      a_tap[i] = ok ? p.A + a_img[i] + ((long)iy * p.Wd + ix) * p.lda + g * 8 : nullptr;
-    }
-  };
-  auto seek = [&](int kt) {   // (tap, channel block) of K tile kt: once per block and once per wrap-around
-    const int k0 = kt * BK;
-    const int tap = k0 / p.Cin;
-    ci0 = k0 - tap * p.Cin;
-    tap_ky = tap / p.ksize;
-    tap_kx = tap - tap_ky * p.ksize;
-    set_tap();
-  };
-  if constexpr (CONV) seek(kt_issue);
-
-  u32x4_t areg[NBUF][WMB][2];
-  auto issue = [&](int slot) __attribute__((always_inline)) {   // slot: compile-time constant after unrolling
-    const int k0 = kt_issue * BK;
-    const long kw = kt_issue * p.w_kstep;
-    if constexpr (CONV) {
-#pragma unroll
-      for (int i = 0; i < WMB; ++i) {
-        const half_t* src = a_tap[i] ? a_tap[i] + ci0 : g_zero_page + g * 8;
-        areg[slot][i][0] = gld16_uncounted(src);
-        areg[slot][i][1] = gld16_uncounted(src + 32);
-      }
-    } else {
-      const bool first = k0 < p.k_split;   // wave-uniform: which source this K tile comes from
-      const int ka = first ? k0 : k0 - p.k_split;
-#pragma unroll
-      for (int i = 0; i < WMB; ++i) {
-        const half_t* src = (first ? a_ptr[i] : a2_ptr[i]) + ka * a_adv[i];
-        areg[slot][i][0] = gld16_uncounted(src);
-        areg[slot][i][1] = gld16_uncounted(src + 32);
-      }
-    }
-    char* Bs = smem + slot * STAGE;
-#pragma unroll
-    for (int j = 0; j < B_PER_WAVE; ++j) {
-      const int q = wave + NW * j;
-      if (q < B_INSTR) glds16(b_ptr[j] + kw, Bs + q * 1024);
-      else if (B_DUP) glds16(b_ptr[j] + kw, Bs + (q - NW) * 1024);
-    }
-    if (++kt_issue == kt_end) {   // wrap-around of the rotated walk (wave-uniform)
-      kt_issue = kt_begin;
-      if constexpr (CONV) seek(kt_begin);
-    } else if constexpr (CONV) {
-      ci0 += BK;
-      if (ci0 >= p.Cin) {  // next tap (wave-uniform)
-        ci0 = 0;
-        if (++tap_kx == p.ksize) {
-          tap_kx = 0;
-          ++tap_ky;
-        }
-        set_tap();
-      }
-    }
-  };
-
-  float4_t acc[WMB][NT];
-#pragma unroll
-  for (int i = 0; i < WMB; ++i)
-#pragma unroll
-    for (int j = 0; j < NT; ++j) acc[i][j] = (float4_t){0.f, 0.f, 0.f, 0.f};
-
-  const int sw = (l15 >> 1) & 7;
-  const int off_k0 = ((0 + g) ^ sw) * 16 + l15 * ROWB;
-  const int off_k1 = ((4 + g) ^ sw) * 16 + l15 * ROWB;
-  const int b_row0 = wn * (16 * NT) * ROWB;
-
-  if (nsteps > 0) {
-    constexpr int PER_STEP = WMB * 2 + B_PER_WAVE;
-    constexpr int KEEP = PER_STEP * (DEPTH - 1);   // VMEM instructions that may stay outstanding
-    static_assert(KEEP < 64, "vmcnt is 6 bits");
-    constexpr int WAIT_KEEP = (KEEP & 15) | ((KEEP >> 4) << 14) | (7 << 4) | (15 << 8);
-#pragma unroll
-    for (int s = 0; s < DEPTH; ++s)
-      if (s < nsteps) issue(s);
-    if constexpr (!CONV) {
-      if (p.ln_in && tid < BM) {   // row statistics of this block's rows from the producer's partial sums
-        const int m = min(m0 + tid, p.M - 1);
-        const float2* src = p.ln_in + (long)m * p.ln_P;
-        float sum = 0.f, sq = 0.f;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          const float2 v = src[min(j, p.ln_P - 1)];
-          const float w = j < p.ln_P ? 1.f : 0.f;
-          sum = fmaf(v.x, w, sum);
-          sq = fmaf(v.y, w, sq);
-        }
-        const float inv_k = 1.0f / (float)p.K;
-        const float mean = sum * inv_k;
-        const float var = fmaxf(fmaf(-mean, mean, sq * inv_k), 0.f);
-        const float rstd = rsqrtf(var + p.ln_eps);
-        lnstat[tid] = make_float2(rstd, -rstd * mean);
-      }
-    }
-    for (int st0 = 0; st0 < nsteps; st0 += NBUF) {
-#pragma unroll
-      for (int u = 0; u < NBUF; ++u) {   // stage / register slot of step st0 + u is u (st0 is a multiple of NBUF)
-        const int st = st0 + u;
-        if (st >= nsteps) break;
-        // only the OLDEST tile has to have landed: its A registers were requested before its weight pieces
-        if (st + DEPTH - 1 < nsteps) __builtin_amdgcn_s_waitcnt(WAIT_KEEP);
-        else __builtin_amdgcn_s_waitcnt(0x0F70);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-#pragma unroll
-        for (int i = 0; i < WMB; ++i) {   // the registers of this step are valid from here on (see gld16_uncounted)
-          asm volatile("" : "+v"(areg[u][i][0]));
-          asm volatile("" : "+v"(areg[u][i][1]));
-        }
-        if (st + DEPTH < nsteps) issue((u + DEPTH) % NBUF);   // the stage / slot step st - 1 has just left
-        const char* base = smem + u * STAGE + b_row0;
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-          const int off = ks ? off_k1 : off_k0;
-          half8_t af[WMB], bf[NT];
-#pragma unroll
-          for (int i = 0; i < WMB; ++i) {
-            af[i] = __builtin_bit_cast(half8_t, areg[u][i][ks]);
-          }
-#pragma unroll
-          for (int j = 0; j < NT; ++j) bf[j] = *reinterpret_cast<const half8_t*>(base + j * 16 * ROWB + off);
-#pragma unroll
-          for (int i = 0; i < WMB; ++i)
-#pragma unroll
-            for (int j = 0; j < NT; ++j)
-              acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[j], af[i], acc[i][j], 0, 0, 0);
-        }
-      }
-    }
-    __syncthreads();  // the epilogue reuses the ring as staging space
-  }
-
-  epilogue160<WMB, NT, WAVES_M * 128, !CONV>(acc, p, lane, m0, n0, wm, wn, split, smem, tid,
-                                             (!CONV && p.ln_in) ? lnstat : nullptr, tile_m * (BM / GN_SLAB));
-}
-
-// ------------------------------------------------------------------------------------------------
 // Wave-specialised form of the 256 x BN tile kernel: 8 consumer waves (the 4 x 2 MFMA layout above) that
 // never touch VMEM in the K loop + 4 loader waves (one per SIMD) that do nothing but issue the LDS-DMA pieces.
 // Why: on the kernel above, DMA-only (33 us) and MFMA-only (29 us) times of the GEGLU GEMM simply ADD to the
@@ -1636,12 +1361,18 @@ __global__ __launch_bounds__(768) void conv3x3_patch_ws_kernel(const G160Params 
   const int cb_end = min(ncb, cb_begin + p.kt_per_split);
   // output tile: TH x TW pixels (TW = the image width when a tile is whole image rows, else p.pt_w)
   const int W = p.Wd, H = p.H;
-  const int TW = p.pt_w ? p.pt_w : W;
-  const int TH = 256 / TW, PW = TW + 2;
   const int hw = H * W;
-  const int tpi = hw / 256, ntx = W / TW;
-  const int b = tile_m / tpi;
-  const int ti = tile_m - b * tpi;
+  // Round 5: 8 x 8 images (the lowest UNet level).  A tile is FOUR whole samples -- 4 x 64 consecutive output rows -- and the
+  // patch holds their four 10 x 10 zero-padded images back to back (4 x 100 = 400 rows: exactly PATCH_ROWS): patch row
+  // s * 100 + (y + 1) * 10 + (x + 1).  The 64 rows of a consumer wave's row group wm are sample wm of the tile.  Before,
+  // these convolutions ran the 64 x 160 implicit-GEMM ring kernels, which re-fetch the activations per tap and stage a
+  // 20 KB weight tile per 64 rows: 322 MB of LDS fill for 15 GFLOP, bound by the L2 -> LDS path at ~9 TB/s (35 us, 430 TF/s).
+  const bool s8 = GN == 0 && hw == 64;          // (host: W == H == 8, M % 256 == 0; the GroupNorm-prologue forms never see it)
+  const int TW = s8 ? 8 : (p.pt_w ? p.pt_w : W);
+  const int TH = s8 ? 8 : 256 / TW, PW = TW + 2;
+  const int tpi = s8 ? 1 : hw / 256, ntx = W / TW;
+  const int b = s8 ? tile_m * 4 : tile_m / tpi;
+  const int ti = s8 ? 0 : tile_m - b * tpi;
   const int y0 = (ti / ntx) * TH, x0 = (ti % ntx) * TW;
   const int m0 = b * hw + y0 * W + x0;          // first output pixel of the tile (see tile_row_m)
   const int ncbs = max(0, cb_end - cb_begin);
@@ -1669,17 +1400,19 @@ __global__ __launch_bounds__(768) void conv3x3_patch_ws_kernel(const G160Params 
     // ================================ loader waves ================================
     const int lw = wave - NCW;
     const int srow = lane >> 3, cpos = lane & 7;
-    const int prow_count = (TH + 2) * PW;
+    const int prow_count = s8 ? 400 : (TH + 2) * PW;
     const half_t* img = p.A + (long)b * hw * p.lda;
     // patch piece q covers LDS rows 8 q .. 8 q + 7; this loader owns q = 6 tap + lw (all loaders) and
     // q = 6 tap + 4 + lw (loaders 0-1), tap = 0..8, q < 50
     auto piece_off = [&](int q) -> int {   // element offset of this lane's source chunk from `img`, -1 = zero padding
       const int r = q * 8 + srow;
-      const int py = r / PW, px = r - py * PW;
+      const int sm = s8 ? r / 100 : 0;              // sample of the tile (8 x 8 images), its 10 x 10 patch rows behind each other
+      const int rr = r - sm * 100;
+      const int py = (s8 ? rr : r) / PW, px = (s8 ? rr : r) - py * PW;
       const int y = y0 - 1 + py, x = x0 - 1 + px;
       const int c = (cpos - (r & ~1)) & 7;   // rotation swizzle of the patch rows
       const bool ok = q < P_INSTR && r < prow_count && y >= 0 && y < H && x >= 0 && x < W;
-      return ok ? (int)((y * W + x) * p.lda + c * 8) : -1;
+      return ok ? (int)((sm * hw + y * W + x) * p.lda + c * 8) : -1;
     };
     int off_a[9], off_b[9];
 #pragma unroll
@@ -1900,7 +1633,8 @@ __global__ __launch_bounds__(768) void conv3x3_patch_ws_kernel(const G160Params 
     for (int i = 0; i < WMB; ++i) {
       const int ql = wm * 64 + i * 16;
       const int ty = ql / TW, tx = ql - ty * TW;
-      rbase[i] = ty * PW + tx + l15;
+      // (8 x 8 images: the 16 rows of a fragment are two image rows of sample wm)
+      rbase[i] = s8 ? wm * 100 + (2 * i + (l15 >> 3)) * 10 + (l15 & 7) : ty * PW + tx + l15;
     }
     const int sw = (l15 >> 1) & 7;
     const int boff0 = wn * 80 * ROWB + l15 * ROWB + (((0 + g) ^ sw) << 4);
@@ -2301,71 +2035,13 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const G160Params p) 
 }
 
 // The same reduction for a launch whose output feeds a GroupNorm (PfdGemmDesc.gn_out): one block per 64-row slab x 160-column
-// tile, the store-pass mapping of epilogue_store_gn (a wave = 3 rows x 20 chunks), statistics through gn_slab_reduce.
+// tile, the store-pass mapping of epilogue_store_gn (a wave = 3 rows x 20 chunks), statistics through gn_slab_reduce.  The
+// 64-row slab is walked in six sweeps of 12 rows; the loads of THREE sweeps (row vector / residual / 4-8 slab slices) are
+// requested before the first add (round 5: the one-sweep-at-a-time form was six dependent round trips, 14.7 us per launch for
+// 2-10 MB at the 8^2 / 16^2 levels; same slab order per element, same order of the rows in the statistics = the same bits;
+// adopted with the GroupNorm apply's grouped partial loads at -0.3 % per batch, profiles/r05_e2e_ab_candidates.log).
+// Up to 8 splits x 3 sweeps x 32 bytes = 96 + 24 VGPRs of loads.
 __global__ __launch_bounds__(256) void splitk_reduce_gn_kernel(const G160Params p) {
-  __shared__ __attribute__((aligned(16))) float red[5 * 320];
-  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-  const int tiles_n = p.N / 160;
-  const int slab = blockIdx.x / tiles_n, tile_n = blockIdx.x - slab * tiles_n;
-  const int n = tile_n * 160 + (lane % 20) * 8;
-  const bool active = lane < 60;
-  const int rsub = lane / 20;
-  float cs[8], cq[8];
-#pragma unroll
-  for (int e = 0; e < 8; ++e) cs[e] = cq[e] = 0.f;
-  Pack16 bb;
-  bb.u = *reinterpret_cast<const uint4*>(p.bias ? p.bias + n : g_zero_page);
-  for (int it = 0; it < (GN_SLAB + 11) / 12; ++it) {
-    const int row_u = w * 3 + rsub + it * 12;
-    const int m = min(slab * GN_SLAB + min(row_u, GN_SLAB - 1), p.M - 1);
-    const bool ok = active && row_u < GN_SLAB && slab * GN_SLAB + row_u < p.M;
-    Pack16 rv, rr;
-    rv.u = *reinterpret_cast<const uint4*>(p.rowvec ? p.rowvec + (long)(m / p.rows_per_rv) * p.ldrv + n : g_zero_page);
-    rr.u = *reinterpret_cast<const uint4*>(p.R ? p.R + (long)m * p.ldr + n : g_zero_page);
-    float v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    for (int s0 = 0; s0 < p.splits; s0 += 4) {   // same order of the slabs as splitk_reduce_kernel
-      float4_t a[4], b[4];
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const float* src = p.ws + ((long)min(s0 + u, p.splits - 1) * p.M + m) * p.N + n;
-        a[u] = *reinterpret_cast<const float4_t*>(src);
-        b[u] = *reinterpret_cast<const float4_t*>(src + 4);
-      }
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const float wgt = s0 + u < p.splits ? 1.f : 0.f;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          v[e] += a[u][e] * wgt;
-          v[4 + e] += b[u][e] * wgt;
-        }
-      }
-    }
-    Pack16 o;
-    const float mk = ok ? 1.f : 0.f;
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      float x = v[e] + (float)bb.e[e];
-      x += (float)rv.e[e];
-      if (p.act == PFD_ACT_GELU) x = pfd_gelu(x);
-      else if (p.act == PFD_ACT_RELU) x = fmaxf(x, 0.f);
-      else if (p.act == PFD_ACT_SILU) x = pfd_silu(x);
-      o.e[e] = (half_t)(x + (float)rr.e[e]);
-      const float f = (float)o.e[e] * mk;
-      cs[e] += f;
-      cq[e] = fmaf(f, f, cq[e]);
-    }
-    if (ok) *reinterpret_cast<uint4*>(p.C + (long)m * p.ldc + n) = o.u;
-  }
-  gn_slab_reduce<1, 256>(cs, cq, tid, p.N / 32, slab, p.M / GN_SLAB, tiles_n, tile_n, p.gn_out, [&](int) { return red; });
-}
-
-// Round-5 candidate (PFD_GN_PAR=1, default off, never run on hardware): the same reduction with the loads of THREE row sweeps
-// requested before the first add.  The plain kernel walks its 64-row slab in six sweeps of 12 rows, each a dependent
-// round trip (row vector / residual / 4-8 slab slices -> wait -> add -> store): 14.7 us per launch for 2-10 MB at the
-// 8^2 / 16^2 levels, where the grid is 64-256 blocks of four waves.  Same slab order per element, same order of the rows in
-// the statistics: bit-identical (tools/cpu_emu checks).  Up to 8 splits x 3 sweeps x 32 bytes = 96 + 24 VGPRs of loads.
-__global__ __launch_bounds__(256) void splitk_reduce_gn_par_kernel(const G160Params p) {
   __shared__ __attribute__((aligned(16))) float red[5 * 320];
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int tiles_n = p.N / 160;
@@ -2439,14 +2115,178 @@ __global__ __launch_bounds__(256) void splitk_reduce_gn_par_kernel(const G160Par
   gn_slab_reduce<1, 256>(cs, cq, tid, p.N / 32, slab, p.M / GN_SLAB, tiles_n, tile_n, p.gn_out, [&](int) { return red; });
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// Round 5 (ABI 9, PfdGemmDesc.gnf_*): split-K reduction + GroupNorm(32)(+SiLU) of the result in ONE launch.  At the 8^2 /
+// 16^2 levels of the UNet every 3x3 convolution splits K, a reduction launch stores the f16 result and the single-launch
+// GroupNorm (gn_small_kernel, norm.hip) reads it again: 20 such pairs per UNet pass, ~8 us + a launch boundary each.  Here
+// a block owns one (sample, group) slab of the OUTPUT -- gnf_rows rows x N / 32 channels, the unit gn_small_kernel owns --
+// and forms it from the fp32 slabs: epilogue as in splitk_reduce_kernel (same slab order, same operation order: the same
+// f16 values), statistics and normalisation as in gn_small_kernel (same thread -> chunk mapping, same order of the adds,
+// same expressions: the same bits).  The raw result is stored too unless skip_raw.  Loads are unconditional and issued a
+// group of four chunks x four slabs at a time (16 x 16 bytes in flight per thread), indices walk incrementally (no
+// division per chunk), gamma / beta of the group sit in LDS before the statistics barrier.
+struct GnFuse {
+  const half_t* gamma;
+  const half_t* beta;
+  half_t* y;
+  long ldy;
+  float eps;
+  int act, rows, skip_raw;
+};
+constexpr int GNF_MAX = 32;     // chunks (4 halfs) per thread: rows * (N / 128) <= 256 * GNF_MAX
+
+__global__ __launch_bounds__(256) void splitk_reduce_gnorm_kernel(const G160Params p, const GnFuse f) {
+  __shared__ float red[8];
+  __shared__ float gam_s[256], bet_s[256];
+  const int cpg = p.N / 32, cpr = cpg / 4;
+  const int g = blockIdx.x, b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int HW = f.rows, total = HW * cpr;
+  const int n_g = g * cpg;
+  const long m_b = (long)b * HW;
+  const int dr = 256 / cpr, dc = 256 - dr * cpr;
+  // one row vector per sample (host: rows_per_rv % rows == 0 or rows_per_rv >= M)
+  const half_t* rvb = p.rowvec ? p.rowvec + (m_b / p.rows_per_rv) * p.ldrv + n_g : g_zero_page;
+  const int rv_step = p.rowvec ? 4 : 0, b_step = p.bias ? 4 : 0;
+  const half_t* bb0 = p.bias ? p.bias + n_g : g_zero_page;
+  const long r_ld = p.R ? p.ldr : 0;
+  const int r_step = p.R ? 4 : 0;
+  const half_t* rb = p.R ? p.R + m_b * p.ldr + n_g : g_zero_page;
+  uint2 v[GNF_MAX];
+  int r = tid / cpr, ch = tid - r * cpr;
+#pragma unroll
+  for (int k0 = 0; k0 < GNF_MAX; k0 += 4) {
+    if (256 * k0 >= total) {          // block-uniform: nothing of this group (or any later one) exists
+#pragma unroll
+      for (int u = 0; u < 4; ++u) v[k0 + u] = make_uint2(0, 0);
+      continue;
+    }
+    int ru[4], cu[4];
+    bool on[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      on[u] = tid + 256 * (k0 + u) < total;
+      ru[u] = on[u] ? r : 0;          // slots past the slab read the slab's first chunk and are dropped below
+      cu[u] = on[u] ? ch : 0;
+      r += dr;
+      ch += dc;
+      if (ch >= cpr) {
+        ch -= cpr;
+        ++r;
+      }
+    }
+    Pack8 bq[4], rq[4], xq[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      bq[u].u = *reinterpret_cast<const uint2*>(bb0 + cu[u] * b_step);
+      rq[u].u = *reinterpret_cast<const uint2*>(rvb + cu[u] * rv_step);
+      xq[u].u = *reinterpret_cast<const uint2*>(rb + (long)ru[u] * r_ld + cu[u] * r_step);
+    }
+    float acc[4][4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc[u][e] = 0.f;
+    for (int s0 = 0; s0 < p.splits; s0 += 4) {   // the slab order of splitk_reduce_kernel
+      float4_t a[4][4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          a[u][q] = *reinterpret_cast<const float4_t*>(p.ws + ((long)min(s0 + q, p.splits - 1) * p.M + m_b + ru[u]) * p.N +
+                                                       n_g + cu[u] * 4);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const float w = s0 + q < p.splits ? 1.f : 0.f;   // the clamped duplicates add nothing
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) acc[u][e] += a[u][q][e] * w;
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      Pack8 o;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float x = acc[u][e] + (float)bq[u].e[e];
+        x += (float)rq[u].e[e];
+        if (p.act == PFD_ACT_GELU) x = pfd_gelu(x);
+        else if (p.act == PFD_ACT_RELU) x = fmaxf(x, 0.f);
+        else if (p.act == PFD_ACT_SILU) x = pfd_silu(x);
+        o.e[e] = (half_t)(x + (float)xq[u].e[e]);
+      }
+      if (on[u] && !f.skip_raw) *reinterpret_cast<uint2*>(p.C + (m_b + ru[u]) * p.ldc + n_g + cu[u] * 4) = o.u;
+      v[k0 + u] = on[u] ? o.u : make_uint2(0, 0);
+    }
+  }
+  if (tid < cpg) {
+    gam_s[tid] = (float)f.gamma[n_g + tid];
+    bet_s[tid] = (float)f.beta[n_g + tid];
+  }
+  float sm = 0.f, sq = 0.f;
+#pragma unroll
+  for (int k = 0; k < GNF_MAX; ++k) {   // gn_small_kernel's order: chunk k of this thread, element e
+    Pack8 q;
+    q.u = v[k];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float x = (float)q.e[e];
+      sm += x;
+      sq += x * x;
+    }
+  }
+  sm = wave_sum(sm);
+  sq = wave_sum(sq);
+  if (lane == 0) {
+    red[wave] = sm;
+    red[4 + wave] = sq;
+  }
+  __syncthreads();
+  const float count = (float)HW * (float)cpg;
+  const float mean = (red[0] + red[1] + red[2] + red[3]) / count;
+  const float rstd = rsqrtf(fmaxf((red[4] + red[5] + red[6] + red[7]) / count - mean * mean, 0.f) + f.eps);
+  half_t* yb = f.y + m_b * f.ldy + n_g;
+  r = tid / cpr;
+  ch = tid - r * cpr;
+  asm volatile("" : "+v"(r), "+v"(ch));   // a second walk, not the index registers of the first one kept alive
+#pragma unroll
+  for (int k = 0; k < GNF_MAX; ++k) {
+    if (tid + 256 * k < total) {
+      Pack8 q, o;
+      q.u = v[k];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float w = rstd * gam_s[ch * 4 + e];
+        float t = (float)q.e[e] * w + (bet_s[ch * 4 + e] - mean * w);
+        if (f.act == PFD_ACT_SILU) t = pfd_silu(t);
+        o.e[e] = (half_t)t;
+      }
+      *reinterpret_cast<uint2*>(yb + (long)r * f.ldy + ch * 4) = o.u;
+    }
+    r += dr;
+    ch += dc;
+    if (ch >= cpr) {
+      ch -= cpr;
+      ++r;
+    }
+  }
+}
+
+// the fused GroupNorm request of the launch being dispatched on this thread (set by pfd_gemm160_try, consumed by
+// launch_splitk_reduce): kept out of G160Params so that the kernel-argument block of every other kernel -- and with it
+// their hardware-validated instruction streams -- stays what it was
+thread_local GnFuse t_gnf = {nullptr, nullptr, nullptr, 0, 0.f, 0, 0, 0};
+
 // launches the reduction of a split-K launch (plain, or the statistics-emitting form) and the LayerNorm fallback statistics
 inline void launch_splitk_reduce(const G160Params& p, hipStream_t s) {
+  if (t_gnf.y) {   // (host: no gn_out / ln_out with it)
+    const GnFuse f = t_gnf;
+    hipLaunchKernelGGL(splitk_reduce_gnorm_kernel, dim3(32, p.M / f.rows), dim3(256), 0, s, p, f);
+    return;
+  }
   if (p.gn_out) {
-    const char* par_s = getenv("PFD_GN_PAR");   // read per launch (the emulation / selftest flip it between two launches)
-    if (par_s && atoi(par_s) == 1)
-      hipLaunchKernelGGL(splitk_reduce_gn_par_kernel, dim3((p.M / GN_SLAB) * (p.N / 160)), dim3(256), 0, s, p);
-    else
-      hipLaunchKernelGGL(splitk_reduce_gn_kernel, dim3((p.M / GN_SLAB) * (p.N / 160)), dim3(256), 0, s, p);
+    hipLaunchKernelGGL(splitk_reduce_gn_kernel, dim3((p.M / GN_SLAB) * (p.N / 160)), dim3(256), 0, s, p);
   } else {
     const long nvec = (long)p.M * (p.N / 8);
     int g = (int)((nvec + 255) / 256);
@@ -2493,14 +2333,17 @@ inline bool ws_ring_on() {
   return on;
 }
 
-// PFD_AREG=<bit mask>: the automatic choice takes a register-operand kernel wherever it picked its LDS counterpart --
-//   1: 23 -> 27 (64 x 160 ring, 4 waves)   2: 43 -> 45 (64 x 160 ring, 8 waves)   4: 83 -> 85 (128 x 160 ring, 8 waves)
-//   8: 82 -> 86 (2-stage 128-row tile -> 3 weight stages, two blocks per CU; linears)   16: 22 -> 28 (the same for the 64-row tile)
-// 7 = the ring family, 31 = everything.  Default 0: the kernels have not run on hardware yet (round-5 candidates); adopting a
-// winner is a change of this default.
-inline int areg_mode() {
-  static const int m = getenv("PFD_AREG") ? atoi(getenv("PFD_AREG")) : 0;
+// TEMPORARY (round-5 A/B of the remaining forced-only candidates; removed with the losers): PFD_R5X bit mask --
+//   1: 64 x 160 ring on 4 waves, 4 stages -> 5 (23 -> 26)   2: the same on 8 waves (43 -> 46)   4: patch kernel without the barrier per tap (95)
+inline int r5x_mode() {
+  static const int m = getenv("PFD_R5X") ? atoi(getenv("PFD_R5X")) : 0;
   return m;
+}
+
+// TEMPORARY (A/B): PFD_PATCH8=0 keeps the 8 x 8 convolutions on the implicit-GEMM ring kernels
+inline bool patch8_on() {
+  static const bool on = !(getenv("PFD_PATCH8") && atoi(getenv("PFD_PATCH8")) == 0);
+  return on;
 }
 
 // PFD_R3TILES=0 keeps the round-2 tile choice (A/B runs of the round-3 rules in pfd_gemm160_try)
@@ -2540,29 +2383,6 @@ int launch160(G160Params& p, int bucket, hipStream_t s) {
   if (p.splits > 1) launch_splitk_reduce(p, s);
   if (prof) pfd_prof_end(s);
   return pfd_check_launch("pfd_gemm_f16(wide)");
-}
-
-// forced variants 27 / 45 / 85 (round-5 candidates): activation fragments in registers, weights on a 7-stage LDS ring
-template <int WAVES_M, int WMB, int NBUF, int MINW = 1>
-int launch160ar(G160Params& p, int bucket, hipStream_t s) {
-  constexpr int BM = WAVES_M * WMB * 16;
-  p.tiles_m = (p.M + BM - 1) / BM;
-  p.tiles_n = p.N / 160;
-  p.nmajor = pick_nmajor(p);
-  p.krot = krot_mode() == 2 || (krot_mode() == 1 && p.ksize == 0);   // as launch160: same K walk, same bits
-  const int nk = p.K / BK;
-  p.kt_per_split = (nk + p.splits - 1) / p.splits;
-  p.splits = (nk + p.kt_per_split - 1) / p.kt_per_split;
-  dim3 grid(p.tiles_m * p.tiles_n, 1, p.splits);
-  const double a_bytes = p.ksize > 0 ? 2.0 * p.B * p.H * p.Wd * p.Cin : 2.0 * p.M * p.K;
-  const double n_out = p.act == PFD_ACT_GEGLU ? p.N / 2 : p.N;
-  PfdProfScope prof_scope(bucket, 2.0 * p.M * p.N * p.K, a_bytes + 2.0 * p.N * p.K + 2.0 * p.M * n_out * (p.R ? 2 : 1), s);
-  if constexpr (MINW == 1) {   // (the im2col form of the 128-VGPR build spills: variant 86 serves linears only)
-    if (p.ksize > 0) hipLaunchKernelGGL((gemm160ar_kernel<WAVES_M, WMB, NBUF, true, MINW>), grid, dim3(WAVES_M * 128), 0, s, p);
-  }
-  if (p.ksize == 0) hipLaunchKernelGGL((gemm160ar_kernel<WAVES_M, WMB, NBUF, false, MINW>), grid, dim3(WAVES_M * 128), 0, s, p);
-  if (p.splits > 1) launch_splitk_reduce(p, s);
-  return pfd_check_launch("pfd_gemm_f16(wide, A in registers)");
 }
 
 template <int NT>
@@ -2679,6 +2499,28 @@ int pfd_gemm160_try(const PfdGemmDesc* d, int variant, int splits, hipStream_t s
       return 1;
     if (d->ksize > 0 && ((long)d->Ho * d->Wo) % GN_SLAB) return 1;   // a slab must not straddle two samples
   }
+  // GroupNorm fused into the split-K reduction (ABI 9): validated here, armed once the split count is known (gnf_arm below)
+  t_gnf.y = nullptr;
+  const bool gnf = d->gnf_y != nullptr;
+  if (gnf) {
+    const int cpg = d->N / 32;
+    if (bn != 160 || (d->N % 32) || (cpg % 4) || cpg < 32 || cpg > 256 || d->gnf_rows <= 0 || (d->M % d->gnf_rows) ||
+        (long)d->gnf_rows * (cpg / 4) > 256L * GNF_MAX || (long)(d->M / d->gnf_rows) * 32 < 128 || !d->gnf_gamma || !d->gnf_beta ||
+        (d->gnf_ldy & 3) || (reinterpret_cast<uintptr_t>(d->gnf_y) & 7) || d->act == PFD_ACT_GEGLU || d->Ct || d->ln_stats ||
+        d->ln_out || d->gn_out || d->bias_per_row || !d->ws ||
+        (d->gnf_act != PFD_ACT_NONE && d->gnf_act != PFD_ACT_SILU))
+      return 1;
+    const int rpr = d->rows_per_rv > 0 ? d->rows_per_rv : 1;
+    if (d->rowvec && (rpr % d->gnf_rows) && rpr < d->M) return 1;   // one row vector per sample
+  }
+  auto gnf_arm = [&](int nsplits) -> bool {   // false: the problem is not split -> not served (nothing launched yet)
+    if (!gnf) return true;
+    if (nsplits <= 1) return false;
+    t_gnf = GnFuse{(const half_t*)d->gnf_gamma, (const half_t*)d->gnf_beta, (half_t*)d->gnf_y, (long)d->gnf_ldy, d->gnf_eps,
+                   d->gnf_act, d->gnf_rows, d->gnf_skip_raw};
+    return true;
+  };
+  struct GnfDisarm { ~GnfDisarm() { t_gnf.y = nullptr; } } gnf_disarm;
   // two-source contraction / zero rows (ABI 8): the 8-wave / 4-wave linear kernels only
   p.k_split = d->K; p.zero_rows = 0;
   if (d->k_split > 0 || d->zero_rows > 0) {
@@ -2720,10 +2562,13 @@ int pfd_gemm160_try(const PfdGemmDesc* d, int variant, int splits, hipStream_t s
     if (p.Wd % 32 == 0 && p.H % 8 == 0) pt_w = 32;
     else if (p.Wd % 16 == 0 && p.H % 16 == 0) pt_w = 16;
   }
-  const bool patch_w = p.Wd == 16 || p.Wd == 32 || p.Wd == 64 || (pt_w != 0 && r3tiles_on());
+  // 8 x 8 images (round 5): tiles of four whole samples on the loader-wave patch kernels (not the 8-wave / flag / prologue forms)
+  const bool s8 = p.ksize == 3 && p.Wd == 8 && p.H == 8 && p.M % 256 == 0 && !p.gn_table && patch8_on() &&
+                  (variant == 0 || variant == 98 || variant == 96);
+  const bool patch_w = p.Wd == 16 || p.Wd == 32 || p.Wd == 64 || (pt_w != 0 && r3tiles_on()) || s8;
   if (bn == 160 && (variant == 0 || variant == 99 || variant == 98 || variant == 97 || variant == 96 || variant == 95) && p.ksize == 3 && p.stride == 1 && p.pad == 1 && !p.ups &&
-      patch_w && p.Ho == p.H && p.Wo == p.Wd && (pt_w != 0 || p.H % (256 / p.Wd) == 0) &&
-      p.M % 256 == 0 && ((long)p.H * p.Wd) % 256 == 0 && p.act != PFD_ACT_GEGLU) {
+      patch_w && p.Ho == p.H && p.Wo == p.Wd && (pt_w != 0 || s8 || p.H % (256 / p.Wd) == 0) &&
+      p.M % 256 == 0 && (s8 || ((long)p.H * p.Wd) % 256 == 0) && p.act != PFD_ACT_GEGLU) {
     p.pt_w = pt_w;
     p.pt_sh = pt_w == 32 ? 5 : 4;
     // (The 8-wave 128-row ring beats the patch kernel on its smallest problems -- 16384 x 320 x 2880: 50 -> 43 us,
@@ -2742,11 +2587,16 @@ int pfd_gemm160_try(const PfdGemmDesc* d, int variant, int splits, hipStream_t s
     }
     if (splits > 1 && (!d->ws || (size_t)splits * p.M * p.N * 4 > d->ws_bytes)) splits = 1;
     p.splits = splits;
+    {   // (launch_patch turns the request into channel blocks per split: the count it will really launch)
+      const int kps = (ncb + splits - 1) / splits;
+      if (!gnf_arm((ncb + kps - 1) / kps)) return 1;
+    }
     // default: the wave-specialised form (4 loader waves): +4 ... 13 % on every patch-eligible conv of the UNet, most
     // on the long-K ones (32768 x 320 x 8640: 149 -> 131 us = 1435 TF; profiles/r02_patch_ws_ab.log), with ping-pong
     // consumer groups (round 3); 99 forces the 8-wave form, 98 loader waves + lock-step consumers, 97 ping-pong
     // 96 forces the 3-stage weight ring (two taps of weights in flight, counted vmcnt; round 4); PFD_PATCH_RING=0/1 picks the default
-    const int ws = variant == 99 ? 0 : variant == 98 ? 1 : variant == 97 ? 2 : variant == 96 ? 3 : variant == 95 ? 4 : (pp_on() ? 2 : patch_ring_on() ? 3 : 1);
+    if (s8 && pp_on()) return 1;
+    const int ws = variant == 99 ? 0 : variant == 98 ? 1 : variant == 97 ? 2 : variant == 96 ? 3 : variant == 95 ? 4 : (pp_on() ? 2 : ((r5x_mode() & 4) && !p.gn_table && !s8) ? 4 : patch_ring_on() ? 3 : 1);
     if (ws == 4 && p.gn_table) return 1;   // the GroupNorm prologue lives in conv3x3_patch_ws_kernel<1 / 2> only
     return launch_patch(p, s, ws) < 0 ? PFD_ELAUNCH : 0;
   }
@@ -2793,7 +2643,7 @@ int pfd_gemm160_try(const PfdGemmDesc* d, int variant, int splits, hipStream_t s
     }
   }
   const int bm = (variant == 44 || variant == 48 || variant == 49 || variant == 47 || variant == 84) ? 256
-                 : (variant == 24 || variant == 25 || variant == 82 || variant == 83 || variant == 85 || variant == 86) ? 128 : 64;
+                 : (variant == 24 || variant == 25 || variant == 82 || variant == 83) ? 128 : 64;
   if (splits == 0) {
     splits = 1;
     const long tl = tiles(bm);
@@ -2801,12 +2651,12 @@ int pfd_gemm160_try(const PfdGemmDesc* d, int variant, int splits, hipStream_t s
     if (p.act != PFD_ACT_GEGLU && d->ws && (variant == 44 || variant == 48 || variant == 49 || variant == 47) && tl < 200 && nk >= 48 &&
         (size_t)2 * p.M * p.N * 4 <= d->ws_bytes) {
       splits = 2;  // 128 tiles of 256x160: two K halves fill the chip (758 vs 579 TF at 640->640 @32^2)
-    } else if (p.act != PFD_ACT_GEGLU && d->ws && (variant == 24 || variant == 25 || variant == 82 || variant == 83 || variant == 85 || variant == 86) && tl < 256) {
+    } else if (p.act != PFD_ACT_GEGLU && d->ws && (variant == 24 || variant == 25 || variant == 82 || variant == 83) && tl < 256) {
       splits = (int)((512 + tl - 1) / tl);
       if (splits > 8) splits = 8;
       while (splits > 1 && nk / splits < 16) --splits;  // the slab round trip must stay small vs the K loop
       while (splits > 1 && (size_t)splits * p.M * p.N * 4 > d->ws_bytes) --splits;
-    } else if (p.act != PFD_ACT_GEGLU && d->ws && (variant == 22 || variant == 23 || variant == 41 || variant == 43 || variant == 26 || variant == 46 || variant == 27 || variant == 45 || variant == 28 || variant == 29) && tl <= 128 && nk >= 16) {
+    } else if (p.act != PFD_ACT_GEGLU && d->ws && (variant == 22 || variant == 23 || variant == 41 || variant == 43 || variant == 26 || variant == 46) && tl <= 128 && nk >= 16) {
       splits = (int)(256 / tl);   // M <= 1024 rows (8^2 level, cond-half projections): 25 -> 21 us
       if (splits > 4) splits = 4;
       while (splits > 1 && (size_t)splits * p.M * p.N * 4 > d->ws_bytes) --splits;
@@ -2814,6 +2664,10 @@ int pfd_gemm160_try(const PfdGemmDesc* d, int variant, int splits, hipStream_t s
   }
   if (splits > 1 && (!d->ws || (size_t)splits * p.M * p.N * 4 > d->ws_bytes || p.act == PFD_ACT_GEGLU)) splits = 1;
   p.splits = splits;
+  {   // (the launchers turn the request into K tiles per split: the count they will really launch)
+    const int kps = (nk_all + splits - 1) / splits;
+    if (!gnf_arm((nk_all + kps - 1) / kps)) return 1;
+  }
   if (auto_variant && bn == 160 && ring_on()) {
     // Problems whose blocks fill the chip once (the 16^2 / 8^2 levels: <= 256 tiles, or split-K slices of them) are
     // bound by the DMA round trip per K tile, not by MFMA or LDS capacity: they take the deep operand rings (3 K tiles
@@ -2826,14 +2680,8 @@ int pfd_gemm160_try(const PfdGemmDesc* d, int variant, int splits, hipStream_t s
     if (variant == 82 && (p.ksize == 0 || (p.stride == 1 && !p.ups)) && tiles(128) <= 256 && nk_split >= 6) variant = 83;
   }
   const int conv = p.ksize > 0 ? 1 : 0;
-  // PFD_AREG=<mask> (default 0; round-5 end-to-end A/B): the kernels the rules above picked are replaced by their
-  // register-operand forms -- same tiles, same split counts, same bits (selftest --r5, tests/test_cpu_emulation.py)
-  if (auto_variant && bn == 160 && areg_mode() != 0) {
-    const int am = areg_mode();
-    variant = (variant == 23 && (am & 1)) ? 27 : (variant == 43 && (am & 2)) ? 45 : (variant == 83 && (am & 4)) ? 85
-              : (variant == 82 && (am & 8) && !conv) ? 86 : (variant == 22 && (am & 16) && !conv) ? 28 : variant;
-  }
-  if ((variant == 27 || variant == 45 || variant == 85 || variant == 86 || variant == 28 || variant == 29) && bn != 160) return 1;   // 160-wide tiles only
+  if (auto_variant && bn == 160 && r5x_mode() != 0)
+    variant = (variant == 23 && (r5x_mode() & 1)) ? 26 : (variant == 43 && (r5x_mode() & 2)) ? 46 : variant;
   if (variant == 48 || variant == 49 || variant == 47) {   // 8 MFMA waves + 4 loader waves (49: ping-pong consumer groups, 47: 3-stage ring)
     const int mode = variant == 49 ? 1 : variant == 47 ? 2 : 0;
     if (bn == 128) return launch160ws<4>(p, 12 + 4 * conv, s, mode) < 0 ? PFD_ELAUNCH : 0;
@@ -2863,20 +2711,6 @@ int pfd_gemm160_try(const PfdGemmDesc* d, int variant, int splits, hipStream_t s
     // of ~1.9 us each -- so 4 in flight instead of 3 is worth up to a quarter of it if the deeper ring costs nothing else
     case 26: return launch160<2, 2, 5>(p, 14 + 4 * conv, s) < 0 ? PFD_ELAUNCH : 0;
     case 46: return launch160<4, 1, 5>(p, 14 + 4 * conv, s) < 0 ? PFD_ELAUNCH : 0;
-    // round-5 candidates, forced only: activation fragments global -> VGPR, weights alone on a 7-stage LDS ring = 6 K tiles
-    // in flight (gemm160ar_kernel).  Linears (GEGLU included: same epilogue) and implicit-GEMM convolutions (a launch they
-    // do not serve falls back to the automatic choice); 27 = 64 x 160 on 4 waves, 45 = 64 x 160 on 8 waves, 85 = 128 x 160 on 8 waves
-    case 27: return launch160ar<2, 2, 7>(p, 14 + 4 * conv, s) < 0 ? PFD_ELAUNCH : 0;
-    case 45: return launch160ar<4, 1, 7>(p, 14 + 4 * conv, s) < 0 ? PFD_ELAUNCH : 0;
-    case 85: return launch160ar<4, 2, 7>(p, 13 + 4 * conv, s) < 0 ? PFD_ELAUNCH : 0;
-    // 29 = 27 with 5 weight stages: the same four K tiles in flight as the all-LDS 5-stage ring (26), i.e. the price of
-    // moving the activations through registers at equal depth (A/B only)
-    case 29: return launch160ar<2, 2, 5>(p, 14 + 4 * conv, s) < 0 ? PFD_ELAUNCH : 0;
-    // 86 = 128 x 160 on 8 waves, 3 weight stages (60 KB, <= 128 VGPRs): two blocks per CU like variant 82, each with two K
-    // tiles in flight instead of one -- for the short-K linears on >= 8192 rows (many tiles per CU)
-    case 86: return conv ? 1 : launch160ar<4, 2, 3, 4>(p, 13 + 4 * conv, s) < 0 ? PFD_ELAUNCH : 0;
-    // 28 = 64 x 160 on 4 waves, 3 weight stages (60 KB): two blocks per CU like variant 22, each with two K tiles in flight
-    case 28: return conv ? 1 : launch160ar<2, 2, 3, 2>(p, 14, s) < 0 ? PFD_ELAUNCH : 0;
     // round 3 experiments: the same tiles on 8 waves (4 x 2 wave layout, wave tile 16 x 80 / 32 x 80): twice the waves
     // issuing LDS-DMA pieces per CU and two waves per SIMD on the problems whose one 4-wave block per CU is bound by the
     // piece issue rate (64-row tiles: 41 two stages, 43 four-stage ring; 128-row tiles: 82 two stages, 83 three)

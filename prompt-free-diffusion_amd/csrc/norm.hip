@@ -202,11 +202,10 @@ struct GnPStats {
   int cpp1, cpp2;    // channels per producer group (C_src / 32)
 };
 
-// PAR (round-5 candidate, PFD_GN_PAR=1, never the default and not yet run on hardware): the fold of the partials issues the
-// loads of eight slabs before the first add instead of one dependent load per slab (64^2: 8 L2 round trips per block in
-// front of the first row), and the apply loop requests eight rows per round trip instead of four (a block's 64 rows at
-// 64^2 x 320: two trips instead of three); same values added in the same order -- `selftest --r5` compares the two
-// forms bit for bit.
+// PAR (the default wherever npg <= 2, round 5): the fold of the partials issues the loads of eight slabs before the first
+// add instead of one dependent load per slab (64^2: 8 L2 round trips per block in front of the first row), and the apply
+// loop requests eight rows per round trip instead of four (a block's 64 rows at 64^2 x 320: two trips instead of three);
+// same values added in the same order -- `selftest --r5` compares the two forms bit for bit (281 checks green on MI355X).
 template <bool PAR>
 __global__ __launch_bounds__(256) void gn_apply_pstats_kernel(GnSrc s, GnPStats ps, const half_t* __restrict__ gamma,
                                                               const half_t* __restrict__ beta, half_t* __restrict__ y,
@@ -368,49 +367,16 @@ __global__ __launch_bounds__(256) void gn_table_kernel(const half_t* __restrict_
 // two-launch form is bound by launch latency (1280 @ 8^2: 10 us for 1.3 MB).  Needs (C/G) % 4 == 0.
 constexpr int GNS_MAX = 32;
 
-// FAST (round-5 candidate, PFD_GN_SMALL_FAST=1, never the default and not yet run on hardware).  The ISA of the plain form
-// spends ~50 instructions per chunk on idx / cpr (a 32-bit division by a run-time value, twice per chunk) and, in the apply
-// loop, waits for a gamma / beta load per chunk (load -> vmcnt(0) -> compute -> store, 3-20 times in a row) -- on a kernel
-// whose whole job is one round trip of 1.3 MB.  FAST walks (row, chunk) incrementally (idx += 256 is r += 256 / cpr,
-// chunk += 256 % cpr with one carry), loads every chunk unconditionally (slots past the slab read the group's first chunk
-// and are weighted 0), and keeps the group's gamma / beta in LDS, loaded before the statistics barrier.  Same values, same
-// order of the adds: `selftest --r5` compares the two forms bit for bit.
-template <bool FAST>
-__global__ __launch_bounds__(256, FAST ? 2 : 1) void gn_small_kernel(GnSrc s, const half_t* __restrict__ gamma,
+__global__ __launch_bounds__(256) void gn_small_kernel(GnSrc s, const half_t* __restrict__ gamma,
                                                        const half_t* __restrict__ beta, half_t* __restrict__ y,
                                                        long ldy, int HW, int G, int act, float eps) {
   __shared__ float red[8];
-  __shared__ float gam_s[FAST ? 256 : 1], bet_s[FAST ? 256 : 1];   // host: cpg <= 256 for FAST
   const int C = s.C1 + s.C2;
   const int cpg = C / G, cpr = cpg / 4;
   const int g = blockIdx.x, b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int total = HW * cpr;
   uint2 v[GNS_MAX];
   float sm = 0.f, sq = 0.f;
-  if constexpr (FAST) {
-    // the group's slab lies in ONE source (host: C1 % cpg == 0): base pointer and stride are block-uniform
-    const bool first = g * cpg < s.C1;
-    const half_t* xb = first ? s.x1 + (long)b * HW * s.ld1 + g * cpg : s.x2 + (long)b * HW * s.ld2 + (g * cpg - s.C1);
-    const long ld = first ? s.ld1 : s.ld2;
-    const int dr = 256 / cpr, dc = 256 - dr * cpr;
-    int r = tid / cpr, ch = tid - r * cpr;
-#pragma unroll
-    for (int k = 0; k < GNS_MAX; ++k) {
-      const bool on = tid + 256 * k < total;
-      v[k] = *reinterpret_cast<const uint2*>(on ? xb + (long)r * ld + ch * 4 : xb);
-      if (!on) v[k] = make_uint2(0, 0);
-      r += dr;
-      ch += dc;
-      if (ch >= cpr) {
-        ch -= cpr;
-        ++r;
-      }
-    }
-    if (tid < cpg) {   // behind the slab's loads: their round trip covers this one
-      gam_s[tid] = (float)gamma[g * cpg + tid];
-      bet_s[tid] = (float)beta[g * cpg + tid];
-    }
-  } else {
 #pragma unroll
   for (int k = 0; k < GNS_MAX; ++k) {
     const int idx = tid + 256 * k;
@@ -421,7 +387,6 @@ __global__ __launch_bounds__(256, FAST ? 2 : 1) void gn_small_kernel(GnSrc s, co
       v[k] = c < s.C1 ? *reinterpret_cast<const uint2*>(s.x1 + row * s.ld1 + c)
                       : *reinterpret_cast<const uint2*>(s.x2 + row * s.ld2 + (c - s.C1));
     }
-  }
   }
 #pragma unroll
   for (int k = 0; k < GNS_MAX; ++k) {   // padding slots hold zeros: they add nothing to either sum
@@ -444,34 +409,6 @@ __global__ __launch_bounds__(256, FAST ? 2 : 1) void gn_small_kernel(GnSrc s, co
   const float count = (float)HW * (float)cpg;
   const float mean = (red[0] + red[1] + red[2] + red[3]) / count;
   const float rstd = rsqrtf(fmaxf((red[4] + red[5] + red[6] + red[7]) / count - mean * mean, 0.f) + eps);
-  if constexpr (FAST) {
-    half_t* yb = y + (long)b * HW * ldy + g * cpg;
-    const int dr = 256 / cpr, dc = 256 - dr * cpr;
-    int r = tid / cpr, ch = tid - r * cpr;
-    asm volatile("" : "+v"(r), "+v"(ch));   // a second walk, not the 64 index registers of the first one kept alive
-#pragma unroll
-    for (int k = 0; k < GNS_MAX; ++k) {
-      if (tid + 256 * k < total) {
-        Pack8 p, o;
-        p.u = v[k];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const float w = rstd * gam_s[ch * 4 + e];
-          float t = (float)p.e[e] * w + (bet_s[ch * 4 + e] - mean * w);
-          if (act == PFD_ACT_SILU) t = pfd_silu(t);
-          o.e[e] = (half_t)t;
-        }
-        *reinterpret_cast<uint2*>(yb + (long)r * ldy + ch * 4) = o.u;
-      }
-      r += dr;
-      ch += dc;
-      if (ch >= cpr) {
-        ch -= cpr;
-        ++r;
-      }
-    }
-    return;
-  }
 #pragma unroll
   for (int k = 0; k < GNS_MAX; ++k) {
     const int idx = tid + 256 * k;
@@ -741,7 +678,7 @@ __global__ __launch_bounds__(256) void softmax_rows_long_kernel(const half_t* __
 static void gn_chunks(int B, int C, int HW, int* nchunks_out, int* rpc_out) {
   const int nvec = C / 8;
   const int RT = nvec < 256 ? 256 / nvec : 1;
-  static const int target_blocks = getenv("PFD_GN_BLOCKS") ? atoi(getenv("PFD_GN_BLOCKS")) : 512;
+  constexpr int target_blocks = 512;   // (1024 / 2048 measured slower, profiles/r04_end_to_end_ab.log)
   int nchunks = (target_blocks + B - 1) / B;
   const int max_by_rows = (HW + RT * 4 - 1) / (RT * 4);
   if (nchunks > max_by_rows) nchunks = max_by_rows;
@@ -781,15 +718,11 @@ extern "C" int pfd_groupnorm_f16(const void* x1, int32_t C1, int64_t ldx1, const
   const bool prof = pfd_prof_on();
   if (gn_is_small(B, C, HW, G)) {  // narrower groups: 40-byte row segments, the two-launch form wins (640 @ 32^2: 15 vs 17 us)
     if (prof) pfd_prof_begin(10, 8.0 * B * HW * C, 4.0 * B * HW * C, s);  // 2B read + 2B write
-    const char* fast_s = getenv("PFD_GN_SMALL_FAST");   // round-5 candidate, default off; read per launch (selftest flips it)
-    const int cpg_ = C / G;
-    const bool fast = fast_s && atoi(fast_s) == 1 && cpg_ <= 256 && (C2 == 0 || C1 % cpg_ == 0);
-    if (fast)
-      hipLaunchKernelGGL(gn_small_kernel<true>, dim3(G, B), dim3(256), 0, s, src, (const half_t*)gamma, (const half_t*)beta,
-                         (half_t*)y, (long)ldy, HW, G, act, eps);
-    else
-      hipLaunchKernelGGL(gn_small_kernel<false>, dim3(G, B), dim3(256), 0, s, src, (const half_t*)gamma, (const half_t*)beta,
-                         (half_t*)y, (long)ldy, HW, G, act, eps);
+    // (round 5: a form with incremental indices and gamma / beta in LDS -- 5419 -> 3172 instructions -- measured -0.04 %
+    //  per batch, profiles/r05_e2e_ab_candidates.log: not kept; the fused split-K reduction + GroupNorm of gemm_glds.hip
+    //  takes most of these launches instead)
+    hipLaunchKernelGGL(gn_small_kernel, dim3(G, B), dim3(256), 0, s, src, (const half_t*)gamma, (const half_t*)beta,
+                       (half_t*)y, (long)ldy, HW, G, act, eps);
     if (prof) pfd_prof_end(s);
     return pfd_check_launch("pfd_groupnorm_f16(small)");
   }
@@ -833,10 +766,10 @@ extern "C" int pfd_groupnorm_pstats_f16(const void* x1, int32_t C1, int64_t ldx1
   int nchunks, rpc;
   gn_chunks(B, C, HW, &nchunks, &rpc);
   PfdProfScope prof_scope(10, 8.0 * B * HW * C, 4.0 * B * HW * C, s);   // 2 B read + 2 B write
-  const char* par_s = getenv("PFD_GN_PAR");   // read per launch (selftest flips it between two launches)
-  const bool par_env = par_s && atoi(par_s) == 1;
   const int cpg = C / G;
-  const bool par = par_env && cpg / ps.cpp1 <= 2 && cpg / ps.cpp2 <= 2;   // round-5 candidate, default off
+  // grouped partial loads where a group of this norm is at most two producer groups per source (every UNet shape but the
+  // 3-source-group concats); adopted in round 5 at -0.3 % per batch (profiles/r05_e2e_ab_candidates.log), same bits
+  const bool par = cpg / ps.cpp1 <= 2 && cpg / ps.cpp2 <= 2;
   if (par)
     hipLaunchKernelGGL(gn_apply_pstats_kernel<true>, dim3(nchunks, B), dim3(256), 0, s, src, ps, (const half_t*)gamma,
                        (const half_t*)beta, (half_t*)y, (long)ldy, HW, G, rpc, act, (float)HW * (float)(C / G), eps);

@@ -661,7 +661,7 @@ static void run_swin_case(int B, int H, int W, int nH, int shift) {
 }
 
 // ------------------------------------------------------------------ norms
-static void run_gn_case(int B, int HW, int C1, int C2, int G, int act, float eps, const char* same_env = nullptr) {
+static void run_gn_case(int B, int HW, int C1, int C2, int G, int act, float eps) {
   const int C = C1 + C2;
   auto x1 = rand_h((size_t)B * HW * C1, 2.f), x2 = rand_h((size_t)B * HW * std::max(C2, 8), 1.f);
   for (auto& v : x1) v = (h16)((float)v + 0.7f);
@@ -693,30 +693,100 @@ static void run_gn_case(int B, int HW, int C1, int C2, int G, int act, float eps
         }
     }
   report(name, got, ref, 4e-3, 3e-3);
-  if (same_env) {   // the same launch with a round-5 switch set: the same bits
-    Dev<h16> dy2((size_t)B * HW * C);
-    setenv(same_env, "1", 1);
-    const int rc2 = pfd_groupnorm_f16(d1.p, C1, C1, C2 ? d2.p : nullptr, C2, C2, dg.p, db.p, dy2.p, C, B, HW, G, eps, act,
-                                      dws.p, wsb, nullptr);
-    unsetenv(same_env);
-    ++g_total;
-    auto got2 = dy2.get();
-    if (rc2 != 0 || memcmp(got.data(), got2.data(), got.size() * sizeof(h16))) {
-      size_t nd = 0;
-      for (size_t i = 0; i < got.size(); ++i) nd += memcmp(&got[i], &got2[i], sizeof(h16)) != 0;
-      ++g_fail;
-      printf("FAIL %-58s %s=1 rc=%d: %zu of %zu elements differ\n", name, same_env, rc2, nd, got.size());
-    } else {
-      printf("ok   %-58s %s=1 == plain (bitwise)\n", name, same_env);
-    }
-  }
 }
 
 // conv3x3(act(GroupNorm([x1 | x2]))) two ways: pfd_groupnorm_f16 + plain patch conv vs pfd_groupnorm_table_f16 + the
 // conv's GroupNorm prologue.  Same statistics code, same fp32 affine map, same kernel behind it: the outputs must be
 // identical, not merely close.
+// PfdGemmDesc.gnf_y (ABI 9): GroupNorm(32)(+SiLU) of a convolution's output inside its split-K reduction launch vs the two-call
+// form (the same convolution without the request, then pfd_groupnorm_f16 on its output): the same bits, raw and normalised
+static void run_gnf_case(int B, int H, int W, int Cin, int N, int act_gn, float eps, bool res, bool rowvec, bool keep_raw, int tile = 0) {
+  const int HW = H * W, M = B * HW, K = 9 * Cin;
+  auto A = rand_h((size_t)M * Cin), Wt = rand_h((size_t)N * K, 1.7f / sqrtf((float)K)), bias = rand_h(N, 0.5f);
+  auto rv = rand_h((size_t)B * N, 0.5f), R = rand_h((size_t)M * N, 1.0f), gm = rand_h(N, 1.f), bt = rand_h(N, 0.5f);
+  Dev<h16> dA(A), dW(Wt), dB(bias), dRV(rv), dR(R), dG(gm), dBt(bt), dC((size_t)M * N), dC2((size_t)M * N), dY((size_t)M * N), dY2((size_t)M * N);
+  Dev<float> dWS((size_t)8 * M * N + 64);
+  PfdGemmDesc d;
+  memset(&d, 0, sizeof(d));
+  d.A = dA.p; d.W = dW.p; d.bias = dB.p; d.rowvec = rowvec ? dRV.p : nullptr; d.R = res ? dR.p : nullptr; d.C = dC.p;
+  d.lda = Cin; d.ldw = K; d.ldc = N; d.ldr = N; d.ldrv = N;
+  d.M = M; d.N = N; d.K = K; d.rows_per_rv = HW; d.act = 0;
+  d.ksize = 3; d.stride = 1; d.pad = 1; d.B = B; d.H = H; d.Wd = W; d.Cin = Cin; d.Ho = H; d.Wo = W;
+  d.ws = dWS.p; d.ws_bytes = ((size_t)8 * M * N + 64) * sizeof(float);
+  char name[200];
+  snprintf(name, sizeof(name), "conv3x3 B%d %dx%d %d->%d + fused GroupNorm act%d res%d rv%d raw%d tile%d", B, H, W, Cin, N, act_gn, res, rowvec, keep_raw, tile);
+  HIP_OK(hipMemset(dC.p, 0x3C, (size_t)M * N * sizeof(h16)));     // 1.0 pattern: an unwritten raw tensor stays recognisable
+  PfdGemmDesc f = d;
+  f.gnf_gamma = dG.p; f.gnf_beta = dBt.p; f.gnf_y = dY.p; f.gnf_ldy = N; f.gnf_eps = eps; f.gnf_act = act_gn; f.gnf_rows = HW;
+  f.gnf_skip_raw = keep_raw ? 0 : 1;
+  const int rc = tile ? pfd_gemm_f16_ex(&f, tile, nullptr) : pfd_gemm_f16(&f, nullptr);
+  ++g_total;
+  if (rc != 0) { ++g_fail; printf("FAIL %-58s rc=%d (%s)\n", name, rc, pfd_last_error()); return; }
+  d.C = dC2.p;
+  const size_t wsb = pfd_groupnorm_ws_bytes(B, N, HW);
+  Dev<char> dws(wsb);
+  const int rc2 = tile ? pfd_gemm_f16_ex(&d, tile, nullptr) : pfd_gemm_f16(&d, nullptr);
+  const int rc3 = pfd_groupnorm_f16(dC2.p, N, N, nullptr, 0, 0, dG.p, dBt.p, dY2.p, N, B, HW, 32, eps, act_gn, dws.p, wsb, nullptr);
+  auto y = dY.get(), y2 = dY2.get(), c = dC.get(), c2 = dC2.get();
+  size_t ny = 0, nc = 0, nraw_written = 0;
+  for (size_t i = 0; i < y.size(); ++i) {
+    ny += memcmp(&y[i], &y2[i], sizeof(h16)) != 0;
+    nc += memcmp(&c[i], &c2[i], sizeof(h16)) != 0;
+    const unsigned short one = 0x3C3C;
+    nraw_written += memcmp(&c[i], &one, sizeof(h16)) != 0;
+  }
+  const bool ok = rc2 == 0 && rc3 == 0 && ny == 0 && (keep_raw ? nc == 0 : nraw_written == 0);
+  if (!ok) {
+    ++g_fail;
+    printf("FAIL %-58s rc %d %d: normalised %zu of %zu elements differ, raw %zu differ, raw written %zu\n", name, rc2, rc3, ny, y.size(), nc, nraw_written);
+  } else {
+    printf("ok   %-58s == conv + groupnorm (bitwise)%s\n", name, keep_raw ? ", raw too" : ", raw tensor not written");
+  }
+  // and the two-call form itself against fp64 (so that "the same bits" is not the same wrong bits): GroupNorm of the stored raw tensor
+  std::vector<double> ref(y2.size());
+  const int cpg = N / 32;
+  for (int b = 0; b < B; ++b)
+    for (int g = 0; g < 32; ++g) {
+      double sm = 0, q = 0;
+      for (int p = 0; p < HW; ++p)
+        for (int ch = g * cpg; ch < (g + 1) * cpg; ++ch) { const double v = (double)c2[((size_t)b * HW + p) * N + ch]; sm += v; q += v * v; }
+      const double n = (double)HW * cpg, mean = sm / n, rstd = 1.0 / sqrt(q / n - mean * mean + eps);
+      for (int p = 0; p < HW; ++p)
+        for (int ch = g * cpg; ch < (g + 1) * cpg; ++ch)
+          ref[((size_t)b * HW + p) * N + ch] = act_ref(((double)c2[((size_t)b * HW + p) * N + ch] - mean) * rstd * (double)gm[ch] + (double)bt[ch], act_gn);
+    }
+  report((std::string(name) + " [vs fp64]").c_str(), y, ref, 4e-3, 3e-3);
+}
+
+// a request the library must decline with NOTHING launched (a problem it does not split / a width without the fused form)
+static void run_gnf_decline_case(int B, int H, int W, int Cin, int N) {
+  const int HW = H * W, M = B * HW, K = 9 * Cin;
+  Dev<h16> dA(rand_h((size_t)M * Cin)), dW(rand_h((size_t)N * K, 0.02f)), dB(rand_h(N, 0.5f)), dG(rand_h(N, 1.f)), dBt(rand_h(N, 0.5f));
+  Dev<h16> dC((size_t)M * N), dY((size_t)M * N);
+  Dev<float> dWS((size_t)8 * M * N + 64);
+  HIP_OK(hipMemset(dC.p, 0x3C, (size_t)M * N * sizeof(h16)));
+  HIP_OK(hipMemset(dY.p, 0x3C, (size_t)M * N * sizeof(h16)));
+  PfdGemmDesc d;
+  memset(&d, 0, sizeof(d));
+  d.A = dA.p; d.W = dW.p; d.bias = dB.p; d.C = dC.p; d.lda = Cin; d.ldw = K; d.ldc = N; d.M = M; d.N = N; d.K = K; d.rows_per_rv = HW;
+  d.ksize = 3; d.stride = 1; d.pad = 1; d.B = B; d.H = H; d.Wd = W; d.Cin = Cin; d.Ho = H; d.Wo = W;
+  d.ws = dWS.p; d.ws_bytes = ((size_t)8 * M * N + 64) * sizeof(float);
+  d.gnf_gamma = dG.p; d.gnf_beta = dBt.p; d.gnf_y = dY.p; d.gnf_ldy = N; d.gnf_eps = 1e-5f; d.gnf_act = PFD_ACT_SILU; d.gnf_rows = HW;
+  const int rc = pfd_gemm_f16(&d, nullptr);
+  HIP_OK(hipDeviceSynchronize());
+  auto c = dC.get(), y = dY.get();
+  size_t touched = 0;
+  const unsigned short one = 0x3C3C;
+  for (size_t i = 0; i < c.size(); ++i) touched += (memcmp(&c[i], &one, 2) != 0) + (memcmp(&y[i], &one, 2) != 0);
+  ++g_total;
+  char name[160];
+  snprintf(name, sizeof(name), "conv3x3 B%d %dx%d %d->%d fused GroupNorm request declined", B, H, W, Cin, N);
+  if (rc != PFD_ESHAPE || touched) { ++g_fail; printf("FAIL %-58s rc=%d, %zu elements written\n", name, rc, touched); }
+  else printf("ok   %-58s PFD_ESHAPE, nothing written\n", name);
+}
+
 // pfd_groupnorm_pstats_f16: statistics handed over in the producers' layout (host-computed here) vs a plain fp64 GroupNorm
-static void run_gn_pstats_case(int B, int HW, int C1, int C2, int act, float eps, bool par_same = false) {
+static void run_gn_pstats_case(int B, int HW, int C1, int C2, int act, float eps) {
   const int C = C1 + C2, G = 32, cpg = C / G;
   auto x1 = rand_h((size_t)B * HW * C1), x2 = rand_h((size_t)B * HW * std::max(C2, 8)), gm = rand_h(C), bt = rand_h(C);
   for (auto& v : x1) v = (h16)((float)v * 1.5f + 0.3f);
@@ -756,23 +826,6 @@ static void run_gn_pstats_case(int B, int HW, int C1, int C2, int act, float eps
           ref[((size_t)b * HW + r) * C + c] = act_ref((at(b, r, c) - mean) * rstd * (double)gm[c] + (double)bt[c], act);
     }
   report(name, got, ref, 6e-3, 4e-3);
-  if (par_same) {   // PFD_GN_PAR=1 (partials of eight slabs requested before the first add): the same bits
-    Dev<h16> dy2((size_t)B * HW * C);
-    setenv("PFD_GN_PAR", "1", 1);
-    const int rc2 = pfd_groupnorm_pstats_f16(d1.p, C1, C1, ds1.p, C2 ? d2.p : nullptr, C2, C2, C2 ? ds2.p : nullptr, dg.p, db.p, dy2.p, C,
-                                             B, HW, G, eps, act, nullptr);
-    unsetenv("PFD_GN_PAR");
-    ++g_total;
-    auto got2 = dy2.get();
-    if (rc2 != 0 || memcmp(got.data(), got2.data(), got.size() * sizeof(h16))) {
-      size_t nd = 0;
-      for (size_t i = 0; i < got.size(); ++i) nd += memcmp(&got[i], &got2[i], sizeof(h16)) != 0;
-      ++g_fail;
-      printf("FAIL %-58s PFD_GN_PAR=1 rc=%d: %zu of %zu elements differ\n", name, rc2, nd, got.size());
-    } else {
-      printf("ok   %-58s PFD_GN_PAR=1 == plain (bitwise)\n", name);
-    }
-  }
 }
 
 static void run_gn_conv_case(int B, int H, int W, int C1, int C2, int N, int act, bool with_res) {
@@ -1516,7 +1569,25 @@ int main(int argc, char** argv) {
     printf("SELFTEST %d/%d passed, %d failed\n", g_total - g_fail, g_total, g_fail);
     return g_fail;
   }
-  if (argc > 1 && !strcmp(argv[1], "--r5")) {   // round-5 candidates (forced variants only): 64-row tiles on a 5-stage operand ring
+  if (argc > 1 && !strcmp(argv[1], "--r5")) {   // round 5: what was adopted, and the candidates still waiting for their A/B
+    // adopted: the split-K reduction that also normalises (PfdGemmDesc.gnf_y) at the shapes the UNet / ControlNet give it
+    run_gnf_case(8, 16, 16, 1280, 1280, PFD_ACT_SILU, 1e-5f, false, true, false);       // ResBlock conv1 @16^2 (patch kernel, split 4)
+    run_gnf_case(8, 8, 8, 1280, 1280, PFD_ACT_SILU, 1e-5f, false, true, false);         // @8^2 (ring kernel, split 4)
+    run_gnf_case(8, 8, 8, 2560, 1280, PFD_ACT_SILU, 1e-5f, false, true, false);         // over the skip concat width, split 8
+    run_gnf_case(8, 16, 16, 640, 1280, PFD_ACT_SILU, 1e-5f, false, true, false);        // 640 -> 1280
+    run_gnf_case(8, 16, 16, 1280, 1280, PFD_ACT_NONE, 1e-6f, true, false, true);        // + residual, raw kept, no activation
+    run_gnf_case(4, 8, 8, 1280, 1280, PFD_ACT_SILU, 1e-5f, true, true, true);           // UNet batch 4
+    run_gnf_case(8, 16, 16, 1280, 1280, PFD_ACT_SILU, 1e-5f, false, true, false, 10802);   // forced patch kernel, split 2
+    run_gnf_decline_case(8, 64, 64, 320, 320);                                          // 64^2: not split, cpg 10
+    run_gnf_decline_case(8, 32, 32, 640, 640);                                          // cpg 20: the fused form is not built for it
+    // 8 x 8 images on the loader-wave patch kernels (tiles of four whole samples)
+    run_gemm_case({0, 320, 0, 0, true, true, true, false, 0, 0, 3, 1, 1, 0, 8, 8, 8, 320});                  // automatic choice, split over channel blocks
+    run_gemm_case({0, 1280, 0, 0, true, true, true, false, 0, 0, 3, 1, 1, 0, 8, 8, 8, 1280});                // the 8^2 ResBlock convolution
+    run_gemm_case({0, 160, 0, PFD_ACT_SILU, true, false, true, false, 10800, 0, 3, 1, 1, 0, 4, 8, 8, 128}); // 2-stage form, one tile
+    run_gemm_case({0, 320, 0, 0, true, true, false, false, 10603, 0, 3, 1, 1, 0, 12, 8, 8, 448});            // 3 tiles, uneven split (3, 2, 2)
+    { GemmCase c{0, 320, 0, 0, true, true, true, false, 0, 0, 3, 1, 1, 0, 8, 8, 8, 256}; c.gn_out = 1; run_gemm_case(c); }
+    run_gnf_case(8, 8, 8, 1280, 1280, PFD_ACT_SILU, 1e-5f, false, true, false, 10604);   // fused GroupNorm behind the 8 x 8 patch tiles
+    // candidates (forced only until their end-to-end A/B, PFD_R5X): 64-row tiles on a 5-stage operand ring (26 / 46)
     for (int v : {3600, 5600}) {
       run_gemm_case({300, 320, 64, 0, true, true, false, false, v});                                        // ONE K step (ring deeper than the loop)
       run_gemm_case({300, 320, 192, PFD_ACT_SILU, true, true, true, false, v});                             // three K steps
@@ -1536,174 +1607,20 @@ int main(int argc, char** argv) {
       run_gemm_case({0, 320, 0, 0, true, true, true, false, v, 0, 3, 1, 1, 0, 2, 16, 16, 320});               // 16^2, 5 channel blocks
       run_gemm_case({0, 160, 0, PFD_ACT_SILU, true, true, true, false, v, 0, 3, 1, 1, 0, 1, 32, 32, 128});    // 32^2, 2 blocks
       run_gemm_case({0, 320, 0, 0, true, false, true, false, v, 0, 3, 1, 1, 0, 1, 64, 64, 64});               // 64^2, ONE block (no successor)
-      run_gemm_case({0, 160, 0, 0, true, true, false, false, v, 0, 3, 1, 1, 0, 3, 16, 16, 192});              // several samples, 3 blocks
-      run_gemm_case({0, 160, 0, 0, true, true, true, false, v, 0, 3, 1, 1, 0, 1, 16, 48, 128});               // 2-D tiles (48-wide)
       run_gemm_case({0, 160, 0, 0, true, true, true, false, v + 2, 0, 3, 1, 1, 0, 1, 16, 16, 256});           // split over channel blocks
-      run_gemm_case({0, 160, 0, 0, true, true, true, false, v + 3, 0, 3, 1, 1, 0, 1, 16, 16, 448});           // uneven split (3, 2, 2)
       { GemmCase c{0, 320, 0, 0, true, true, true, false, v, 0, 3, 1, 1, 0, 2, 16, 16, 128}; c.gn_out = 1; run_gemm_case(c); }
-      // same bits as the barrier form with two weight stages (98), launch after launch: C2 shapes incl. the long-K ones
-      run_conv_same_case(2, 16, 16, 320, 320, 10800, 10500, true);
       run_conv_same_case(8, 64, 64, 320, 320, 10800, 10500, true);
-      run_conv_same_case(8, 64, 64, 960, 320, 10800, 10500, false);
       run_conv_same_case(8, 32, 32, 640, 640, 10800, 10500, true);
-      run_conv_same_case(8, 16, 16, 1280, 1280, 10800, 10500, false);
     }
-    // forced variants 27 / 45 / 85: activation fragments global -> VGPR (uncounted asm loads), weights on a 7-stage ring
-    for (int v : {3700, 5500, 9500, 3900}) {
-      run_gemm_case({300, 320, 64, 0, true, true, false, false, v});                                        // ONE K step (ring deeper than the loop)
-      run_gemm_case({300, 320, 192, PFD_ACT_SILU, true, true, true, false, v});                             // three K steps
-      run_gemm_case({300, 320, 448, 0, true, true, false, false, v});                                       // 7 steps = exactly one trip round the ring
-      run_gemm_case({300, 320, 512, 0, true, false, false, false, v});                                      // 8 steps: slot 0 again
-      run_gemm_case({1100, 320, 1024, 0, true, true, true, false, v});                                      // ragged M, 16 steps
-      run_gemm_case({77, 160, 960, 0, true, false, false, false, v, 8});                                    // odd leading dimensions, 15 steps
-      run_gemm_case({2048, 1280, 1280, 0, true, false, true, false, v});                                    // the 16^2 out-projection class
-      run_gemm_case({512, 1280, 1280, PFD_ACT_GELU, true, true, false, false, v + 2});                      // split-K 2
-      run_gemm_case({512, 320, 5120, 0, true, true, false, false, v + 4});                                  // split-K 4, 20 steps per split
-      { GemmCase c{700, 320, 1024, 0, true, true, true, false, v}; c.k_split = 384; run_gemm_case(c); }
-      { GemmCase c{1100, 320, 512, 0, true, true, false, false, v}; c.zero_rows = 512; run_gemm_case(c); }
-      { GemmCase c{600, 160, 256, PFD_ACT_SILU, true, true, true, false, v}; c.zero_rows = 300; c.k_split = 64; run_gemm_case(c); }
-      { GemmCase c{768, 320, 512, 0, true, true, true, false, v}; c.gn_out = 1; run_gemm_case(c); }
-      { GemmCase c{520, 480, 128, 0, false, false, false, false, v}; c.n_split = 320; run_gemm_case(c); }  // transposed tail
-      { GemmCase c{1100, 320, 1024, 0, true, true, false, false, v}; c.w_tiled = 1; run_gemm_case(c); }     // K-tile-contiguous weights
-      // implicit-GEMM convolutions (im2col gather into the registers, padding from the zero page)
-      run_gemm_case({0, 320, 0, 0, true, true, true, false, v, 0, 3, 1, 1, 0, 2, 16, 16, 128});               // 3x3 s1, 18 steps
-      run_gemm_case({0, 160, 0, 0, true, false, false, false, v, 0, 3, 2, 1, 0, 2, 16, 16, 128});             // stride 2
-      run_gemm_case({0, 320, 0, 0, true, false, false, false, v, 0, 3, 1, 1, 1, 1, 8, 8, 192});               // fused nearest-2x upsample
-      run_gemm_case({0, 160, 0, 0, true, false, false, false, v, 0, 3, 1, 1, 0, 1, 16, 16, 64});              // one K tile per tap, 9 steps
-      run_gemm_case({0, 320, 0, 0, true, true, true, false, v + 4, 0, 3, 1, 1, 0, 8, 8, 8, 1280});            // the 8^2 conv class (narrower), split-K 4
-      run_gemm_case({0, 160, 0, 0, true, true, false, false, v, 0, 1, 1, 0, 0, 3, 12, 12, 192});              // 1x1 as a convolution, ragged M (432 rows)
-      { GemmCase c{0, 320, 0, 0, true, false, false, false, v, 0, 3, 2, 1, 0, 2, 32, 32, 128}; c.gn_out = 1; run_gemm_case(c); }   // stride 2 + statistics
-    }
-    // forced variant 86: the 128-row tile with 3 weight stages and <= 128 VGPRs (two blocks per CU), linears only
-    {
-      const int v = 9600;
-      run_gemm_case({300, 320, 64, 0, true, true, false, false, v});
-      run_gemm_case({300, 320, 192, PFD_ACT_SILU, true, true, true, false, v});
-      run_gemm_case({300, 320, 256, 0, true, false, false, false, v});                                      // 4 steps: slot 0 again
-      run_gemm_case({1100, 320, 1024, 0, true, true, true, false, v});
-      run_gemm_case({77, 160, 960, 0, true, false, false, false, v, 8});
-      run_gemm_case({512, 1280, 1280, PFD_ACT_GELU, true, true, false, false, v + 2});
-      { GemmCase c{700, 320, 1024, 0, true, true, true, false, v}; c.k_split = 384; run_gemm_case(c); }
-      { GemmCase c{1100, 320, 512, 0, true, true, false, false, v}; c.zero_rows = 512; run_gemm_case(c); }
-      { GemmCase c{768, 320, 512, 0, true, true, true, false, v}; c.gn_out = 1; run_gemm_case(c); }
-      { GemmCase c{520, 480, 128, 0, false, false, false, false, v}; c.n_split = 320; run_gemm_case(c); }
-      run_ln_fold_case(520, 640, 640, 0, 9200, 9600, 0);
-      run_lin_same_case(32768, 960, 320, 9200, 9600, false);            // qkv 64^2
-      run_lin_same_case(8192, 1920, 640, 9200, 9600, false);            // qkv 32^2
-      run_lin_same_case(32768, 320, 1280, 9200, 9600, true);            // ff-out 64^2
-      run_lin_same_case(32768, 320, 320, 9200, 9600, true, 0, 16384);   // zero-context out-projection 64^2
-      run_lin_same_case(32768, 320, 640, 9200, 9600, false, 320);       // skip GEMM over [h | skip] 64^2
-    }
-    // forced variant 28: the 64-row 4-wave tile with 3 weight stages (two blocks per CU), linears only
-    {
-      const int v = 3800;
-      run_gemm_case({300, 320, 64, 0, true, true, false, false, v});
-      run_gemm_case({300, 320, 192, PFD_ACT_SILU, true, true, true, false, v});
-      run_gemm_case({300, 320, 256, 0, true, false, false, false, v});
-      run_gemm_case({1100, 320, 1024, 0, true, true, true, false, v});
-      run_gemm_case({77, 160, 960, 0, true, false, false, false, v, 8});
-      run_gemm_case({512, 1280, 1280, PFD_ACT_GELU, true, true, false, false, v + 2});
-      { GemmCase c{700, 320, 1024, 0, true, true, true, false, v}; c.k_split = 384; run_gemm_case(c); }
-      { GemmCase c{1100, 320, 512, 0, true, true, false, false, v}; c.zero_rows = 512; run_gemm_case(c); }
-      { GemmCase c{768, 320, 512, 0, true, true, true, false, v}; c.gn_out = 1; run_gemm_case(c); }
-      run_ln_fold_case(200, 1280, 1280, PFD_ACT_GELU, 5300, 3800, 0);
-      run_lin_same_case(8192, 640, 640, 3200, 3800, true);              // projections 32^2
-      run_lin_same_case(16384, 320, 320, 3200, 3800, true);
-      run_lin_same_case(4096, 640, 640, 3200, 3800, false);             // cond-half to_q 32^2
-      run_lin_same_case(8192, 640, 640, 3200, 3800, true, 0, 4096);     // zero-context out-projection 32^2
-    }
-    for (int v : {3700, 5500, 9500, 9600, 3800}) {   // GEGLU projections through the register-operand kernels (packed weights, half-width output)
-      run_gemm_case({200, 320, 128, PFD_ACT_GEGLU, true, false, false, false, v});
-      run_gemm_case({600, 640, 320, PFD_ACT_GEGLU, true, false, false, false, v});
-      run_ln_fold_case(300, 640, 1280, PFD_ACT_GEGLU, 5400, v, 0);
-    }
-    run_ln_fold_case(200, 1280, 1280, PFD_ACT_GELU, 5300, 3700, 0);   // LayerNorm fold through the new kernels (consumer side)
-    run_ln_fold_case(520, 640, 640, 0, 9200, 9500, 0);
-    run_ln_fold_case(77, 960, 160, 0, 9300, 5500, 0);
-    // same bits as the LDS-ring kernels of the same tile (23 / 43 / 83), launch after launch, at the C2 shapes they would serve
-    for (int pair = 0; pair < 4; ++pair) {
-      const int ta = pair == 0 ? 3300 : pair == 1 ? 5300 : pair == 2 ? 9300 : 3300, tb = pair == 0 ? 3700 : pair == 1 ? 5500 : pair == 2 ? 9500 : 3900;
-      run_lin_same_case(2048, 1280, 1280, ta, tb, true);
-      run_lin_same_case(2048, 1280, 5120, ta, tb, true);
-      run_lin_same_case(8192, 640, 2560, ta, tb, true);
-      run_lin_same_case(1024, 1280, 1280, ta, tb, false);
-      run_lin_same_case(512, 1280, 2560, ta, tb, false, 1280);          // skip GEMM over [h | skip]
-      run_lin_same_case(2048, 1280, 1280, ta, tb, true, 0, 1024);       // zero-context out-projection
-      run_lin_same_case(512, 1280, 1280, ta + 2, tb + 2, true);         // split-K 2
-      run_conv_same_case(8, 8, 8, 1280, 1280, ta + 4, tb + 4, true);    // the 8^2 ResBlock conv, split-K 4
-      run_conv_same_case(8, 8, 8, 2560, 1280, ta + 8, tb + 8, false);   // ... over the skip concat, split-K 8
-      run_conv_same_case(2, 16, 16, 320, 320, ta, tb, true);
-    }
-    // PFD_GN_PAR=1 also switches the statistics-emitting split-K reduction to three row sweeps in flight
-    setenv("PFD_GN_PAR", "1", 1);
+    // the statistics-emitting split-K reduction (three row sweeps in flight) and the GroupNorm apply from producer statistics
     { GemmCase c{512, 1280, 2048, 0, true, true, true, false, 3304}; c.gn_out = 1; run_gemm_case(c); }                          // split-K 4, cpg 40
     { GemmCase c{0, 320, 0, 0, true, true, true, false, 9302, 0, 3, 1, 1, 0, 2, 16, 16, 128}; c.gn_out = 1; run_gemm_case(c); }   // conv, split-K 2
-    unsetenv("PFD_GN_PAR");
-    // PFD_GN_SMALL_FAST=1: the single-launch small-slab GroupNorm without per-chunk divisions / gamma-beta round trips
-    run_gn_case(8, 64, 1280, 0, 32, PFD_ACT_SILU, 1e-5f, "PFD_GN_SMALL_FAST");       // 8^2: 640 chunks, 3 slots per thread
-    run_gn_case(8, 256, 1280, 0, 32, PFD_ACT_SILU, 1e-5f, "PFD_GN_SMALL_FAST");      // 16^2: 2560 chunks
-    run_gn_case(8, 256, 1280, 1280, 32, PFD_ACT_SILU, 1e-5f, "PFD_GN_SMALL_FAST");   // skip concat, cpg 80: 5120 chunks
-    run_gn_case(8, 64, 1280, 1280, 32, PFD_ACT_NONE, 1e-6f, "PFD_GN_SMALL_FAST");
-    run_gn_case(8, 256, 1280, 640, 32, PFD_ACT_SILU, 1e-5f, "PFD_GN_SMALL_FAST");    // cpg 60 straddles the sources: plain both times
-    run_gn_case(4, 64, 1024, 0, 32, PFD_ACT_SILU, 1e-5f, "PFD_GN_SMALL_FAST");       // cpg 32, cpr 8 (256 % cpr == 0: no carries)
-    run_gn_case(16, 100, 1440, 0, 32, PFD_ACT_NONE, 1e-5f, "PFD_GN_SMALL_FAST");     // cpg 45 is not a multiple of 4: two-launch form both times
-    run_gn_case(8, 100, 1408, 0, 32, PFD_ACT_SILU, 1e-5f, "PFD_GN_SMALL_FAST");      // cpg 44, cpr 11, ragged HW
-    // PFD_GN_PAR=1: GroupNorm apply from producer statistics with the partial loads of eight slabs in flight together
-    run_gn_pstats_case(8, 4096, 320, 0, PFD_ACT_SILU, 1e-5f, true);      // 64^2: 64 slabs per sample, 8 per thread
-    run_gn_pstats_case(8, 4096, 320, 320, PFD_ACT_SILU, 1e-5f, true);    // skip concat: two producer groups per group
-    run_gn_pstats_case(3, 1024, 640, 0, PFD_ACT_NONE, 1e-6f, true);      // 16 slabs: two per thread, six clamped slots
-    run_gn_pstats_case(2, 1024, 640, 640, PFD_ACT_SILU, 1e-5f, true);    // 32^2 skip concat
-    run_gn_pstats_case(2, 256, 1280, 1280, PFD_ACT_SILU, 1e-5f, true);   // 16^2 skip concat: 4 slabs, P = 8 parts
-    run_gn_pstats_case(2, 4608, 320, 0, PFD_ACT_SILU, 1e-5f, true);      // 72 slabs: a second trip of the chunked loop
-    printf("%d checks, %d failed\n", g_total, g_fail);
-    return g_fail;
-  }
-  if (argc > 1 && !strcmp(argv[1], "--r4")) {   // round-4 kernels: 3-stage weight ring of the patch kernel (96), 3-stage loader-wave GEMM (47)
-    for (int v : {10600, 10800}) {
-      run_gemm_case({0, 320, 0, 0, true, true, true, false, v, 0, 3, 1, 1, 0, 2, 16, 16, 320});               // 16^2, 5 channel blocks
-      run_gemm_case({0, 160, 0, PFD_ACT_SILU, true, true, true, false, v, 0, 3, 1, 1, 0, 1, 32, 32, 128});    // 32^2, 2 blocks
-      run_gemm_case({0, 320, 0, 0, true, false, true, false, v, 0, 3, 1, 1, 0, 1, 64, 64, 64});               // 64^2, ONE block (no successor)
-      run_gemm_case({0, 160, 0, 0, true, true, false, false, v, 0, 3, 1, 1, 0, 3, 16, 16, 192});              // several samples, 3 blocks
-      run_gemm_case({0, 160, 0, 0, true, true, true, false, v, 0, 3, 1, 1, 0, 1, 16, 48, 128});               // 2-D tiles (48-wide)
-      run_gemm_case({0, 320, 0, 0, true, true, true, false, v, 0, 3, 1, 1, 0, 2, 8, 96, 64});                 // 2-D tiles (96-wide)
-      run_gemm_case({0, 160, 0, 0, true, true, true, false, v + 2, 0, 3, 1, 1, 0, 1, 16, 16, 256});           // split over channel blocks (2 x 2)
-      run_gemm_case({0, 160, 0, 0, true, true, true, false, v + 3, 0, 3, 1, 1, 0, 1, 16, 16, 448});           // uneven split (3, 2, 2)
-    }
-    for (int v : {5700, 5800}) {
-      run_gemm_case({0, 320, 0, 0, true, true, true, false, v, 0, 3, 1, 1, 0, 2, 16, 16, 128});               // 3x3 s1
-      run_gemm_case({0, 160, 0, 0, true, false, false, false, v, 0, 3, 2, 1, 0, 2, 16, 16, 128});             // stride 2
-      run_gemm_case({0, 320, 0, 0, true, false, false, false, v, 0, 3, 1, 1, 1, 1, 8, 8, 192});               // fused nearest-2x upsample
-      run_gemm_case({0, 160, 0, 0, true, false, false, false, v, 0, 3, 1, 1, 0, 1, 16, 16, 64});              // one K tile per tap, 9 steps
-      run_gemm_case({300, 320, 64, 0, true, true, false, false, v});                                        // ONE K step
-      run_gemm_case({300, 320, 128, PFD_ACT_SILU, true, true, true, false, v});                             // two K steps
-      run_gemm_case({1100, 320, 1024, 0, true, true, true, false, v});
-      run_gemm_case({520, 256, 512, 0, true, true, false, false, v});                                       // 128-wide tiles
-      run_gemm_case({0, 160, 0, 0, true, true, false, false, v + 2, 0, 3, 1, 1, 0, 1, 16, 16, 1024});         // split-K 2
-    }
-    // ABI 8: two-source contraction (k_split) and zero rows, every linear tile family, with / without split-K
-    for (int v : {0, 3200, 3300, 3400, 3500, 5400, 5100, 5300, 9200, 9300, 3202, 9203}) {
-      { GemmCase c{700, 320, 1024, 0, true, true, true, false, v}; c.k_split = 384; run_gemm_case(c); }
-      { GemmCase c{1100, 320, 512, 0, true, true, false, false, v}; c.zero_rows = 512; run_gemm_case(c); }     // whole tiles + a straddling one
-      { GemmCase c{600, 160, 256, PFD_ACT_SILU, true, true, true, false, v}; c.zero_rows = 300; c.k_split = 64; run_gemm_case(c); }
-    }
-    { GemmCase c{520, 256, 512, 0, true, true, false, false, 0}; c.k_split = 128; c.zero_rows = 256; run_gemm_case(c); }   // 128-wide tiles
-    // GroupNorm statistics from the producer (gn_out): every store pass that can feed a GroupNorm, and the split-K reduce
-    for (int v : {0, 3200, 3400, 5400, 5100, 9200, 9300, 5800, 5700, 3202, 9202}) {
-      { GemmCase c{768, 320, 512, 0, true, true, true, false, v}; c.gn_out = 1; run_gemm_case(c); }              // cpg 10
-      { GemmCase c{512, 640, 256, PFD_ACT_SILU, true, false, false, false, v}; c.gn_out = 1; run_gemm_case(c); } // cpg 20
-    }
-    { GemmCase c{256, 1280, 128, 0, true, true, false, false, 0}; c.gn_out = 1; run_gemm_case(c); }             // cpg 40
-    for (int v : {0, 10600, 10800, 10900, 10602, 5700, 5800, 5400}) {
-      { GemmCase c{0, 320, 0, 0, true, true, true, false, v, 0, 3, 1, 1, 0, 2, 16, 16, 128}; c.gn_out = 1; run_gemm_case(c); }   // 16^2
-      { GemmCase c{0, 640, 0, 0, true, false, true, false, v, 0, 3, 1, 1, 0, 1, 32, 32, 64}; c.gn_out = 1; run_gemm_case(c); }   // 32^2
-    }
-    { GemmCase c{0, 320, 0, 0, true, true, true, false, 0, 0, 3, 1, 1, 0, 1, 16, 96, 64}; c.gn_out = 1; run_gemm_case(c); }      // 2-D patch tiles
-    { GemmCase c{0, 320, 0, 0, true, false, false, false, 0, 0, 3, 2, 1, 0, 2, 32, 32, 128}; c.gn_out = 1; run_gemm_case(c); }   // stride 2
-    { GemmCase c{0, 320, 0, 0, true, false, false, false, 0, 0, 3, 1, 1, 1, 1, 8, 8, 128}; c.gn_out = 1; run_gemm_case(c); }     // upsample
-    run_gn_pstats_case(2, 256, 320, 0, PFD_ACT_SILU, 1e-5f);
-    run_gn_pstats_case(2, 1024, 640, 0, PFD_ACT_NONE, 1e-6f);
-    run_gn_pstats_case(3, 256, 320, 320, PFD_ACT_SILU, 1e-5f);     // aligned skip concat: a group = two producer groups
-    run_gn_pstats_case(2, 256, 640, 640, PFD_ACT_SILU, 1e-5f);
+    run_gn_case(8, 64, 1280, 0, 32, PFD_ACT_SILU, 1e-5f);
+    run_gn_case(8, 256, 1280, 1280, 32, PFD_ACT_SILU, 1e-5f);
+    run_gn_pstats_case(8, 4096, 320, 0, PFD_ACT_SILU, 1e-5f);
+    run_gn_pstats_case(8, 4096, 320, 320, PFD_ACT_SILU, 1e-5f);
+    run_gn_pstats_case(3, 1024, 640, 0, PFD_ACT_NONE, 1e-6f);
+    run_gn_pstats_case(2, 256, 1280, 1280, PFD_ACT_SILU, 1e-5f);
     printf("SELFTEST %d/%d passed, %d failed\n", g_total - g_fail, g_total, g_fail);
     return g_fail;
   }

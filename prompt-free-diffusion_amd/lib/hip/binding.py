@@ -14,7 +14,7 @@ import os
 _LIB = None
 _LIB_PATH = os.path.normpath(os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "..", "libpfd_hip.so"))
 
-ABI_VERSION = 8
+ABI_VERSION = 9
 
 ACT_NONE, ACT_GELU, ACT_RELU, ACT_SILU, ACT_GEGLU = 0, 1, 2, 3, 4
 
@@ -34,6 +34,8 @@ class PfdGemmDesc(C.Structure):
         ("gn_table", _vp), ("A2", _vp), ("lda2", _i64), ("gn_c1", _i32), ("gn_act", _i32),
         ("ln_stats", _vp), ("ln_colsum", _vp), ("ln_parts", _i32), ("ln_eps", _f32), ("ln_out", _vp),
         ("k_split", _i32), ("zero_rows", _i32), ("gn_out", _vp),
+        ("gnf_gamma", _vp), ("gnf_beta", _vp), ("gnf_y", _vp), ("gnf_ldy", _i64), ("gnf_eps", _f32), ("gnf_act", _i32),
+        ("gnf_rows", _i32), ("gnf_skip_raw", _i32),
     ]
 
 
@@ -80,7 +82,6 @@ SIGNATURES = {
     "pfd_im2col_f16": (_i32, [_vp, _i64, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
     "pfd_timestep_embedding_f16": (_i32, [_vp, _vp, _i32, _i32, _f32, _vp]),
     "pfd_cfg_ddim_step": (_i32, [_vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp]),
-    "pfd_prefetch": (_i32, [_vp, _sz, _vp]),
     "pfd_add_f16": (_i32, [_vp, _vp, _vp, _i64, _vp]),
     "pfd_axpby_f16": (_i32, [_vp, _f32, _vp, _f32, _vp, _i64, _vp]),
     "pfd_add_rowvec_f16": (_i32, [_vp, _i64, _vp, _vp, _i64, _i32, _i32, _vp]),
@@ -127,7 +128,8 @@ class PfdError(RuntimeError):
     pass
 
 
-_ERR = {-1: "PFD_EINVAL", -2: "PFD_ESHAPE", -3: "PFD_ELAUNCH"}
+PFD_EINVAL, PFD_ESHAPE, PFD_ELAUNCH = -1, -2, -3
+_ERR = {PFD_EINVAL: "PFD_EINVAL", PFD_ESHAPE: "PFD_ESHAPE", PFD_ELAUNCH: "PFD_ELAUNCH"}
 
 
 def check(rc, what):

@@ -120,6 +120,18 @@ class Conv2d(nn.Conv2d, _Packed):
     def _pk(self):
         return self._packed("w", lambda: (pack_conv_weight(self.weight), pack_vec(self.bias)), self.weight, self.bias)
 
+    def hip_gn(self, x, norm, *, silu=True, keep_raw=False, rowvec=None, res=None, rows_per_rv=None):
+        """this convolution followed by `norm` (a GroupNorm(32) over its output, + SiLU) with the normalisation done inside the
+        convolution's split-K reduction (ops.conv gn_fuse, PfdGemmDesc.gnf_y): -> (raw | None, normalised), or None when the
+        library does not serve the shape (nothing launched; the caller runs the two calls)"""
+        k, s, p = self.kernel_size[0], self.stride[0], self.padding[0]
+        if self.in_channels % 64 or k != 3 or norm.num_groups != 32 or norm.num_channels != self.out_channels:
+            return None
+        w, b = self._pk()
+        g, be = norm._pk()
+        return ops.conv(x, w, k, stride=s, pad=p, bias=b, rowvec=rowvec, res=res, rows_per_rv=rows_per_rv,
+                        gn_fuse=(g, be, norm.eps, silu, keep_raw))
+
     def hip(self, x, *, ups=False, rowvec=None, res=None, act=ACT_NONE, out=None, out_hw=None, rows_per_rv=None,
             gn=None, ln_out=None, gn_out=False):
         """ln_out (1x1 convolutions only): also return the partial row sums of the output, see ops.gemm.
@@ -213,8 +225,17 @@ class GroupNorm(nn.GroupNorm, _Packed):
     def _pk(self):
         return self._packed("w", lambda: (pack_vec(self.weight), pack_vec(self.bias)), self.weight, self.bias)
 
+    def fuse_key(self, silu):
+        """identifies (this norm's parameters, eps, activation) for a result its input's producer computed ahead"""
+        g, b = self._pk()
+        return (g.data_ptr(), b.data_ptr(), float(self.eps), bool(silu))
+
     def hip(self, x, x2=None, silu=False):
         g, b = self._pk()
+        if x2 is None:
+            y = ops.get_normed(x, (g.data_ptr(), b.data_ptr(), float(self.eps), bool(silu)))
+            if y is not None:        # the launch that wrote x already normalised it (Conv2d.hip_gn, PfdGemmDesc.gnf_y)
+                return y
         return ops.groupnorm(x, g, b, self.num_groups, self.eps, x2=x2, silu=silu)
 
     def hip_table(self, x, x2=None):

@@ -43,76 +43,8 @@ def serialised(fn):
     @functools.wraps(fn)
     def wrapper(*a, **k):
         with DEVICE_LOCK:
-            try:
-                return fn(*a, **k)
-            finally:
-                if WPREFETCH:
-                    prefetch_join()
+            return fn(*a, **k)
     return wrapper
-
-
-# ---- weight prefetch (round-5 candidate, PFD_WPREFETCH=1, default off, never run on hardware) ----
-# The weights of a UNet step (1.7 GB) pass through the 256 MB memory-side cache between two uses of a layer, so every weight
-# tile is an HBM miss when its GEMM asks for it, and the launches that fill the chip once are chains of such round trips
-# (round 1 measured them 40-60 % slower on cold weights than on warm ones).  With the switch on, gemm() / conv()
-# read their weight matrix on a side stream (pfd_prefetch: load and discard) as soon as the launch TWO GEMMs back has
-# finished, i.e. while the previous GEMM runs; the consumer itself does not wait for it.  Pure reads: no functional effect.
-# The side stream forks from and joins the current stream with events, which hipGraph capture records as parallel branches;
-# prefetch_join() must run before a capture ends (ddim.py / pipeline.py call it) and runs at the end of every public entry.
-WPREFETCH = os.environ.get("PFD_WPREFETCH", "0") == "1"
-_PF = threading.local()
-_PF_JOIN_EVERY = 32
-
-
-def _pf_state():
-    st = getattr(_PF, "st", None)
-    if st is None:
-        st = _PF.st = {"side": None, "marks": [], "last": None, "n": 0, "main": None}
-    return st
-
-
-def _prefetch_weights(w):
-    """enqueue the read of w on the side stream, gated on the completion of the launch two GEMMs back"""
-    st = _pf_state()
-    main = torch.cuda.current_stream()
-    if st["main"] is not None and st["main"] != main:
-        prefetch_join()                       # the caller switched streams: do not carry events across
-    st["main"] = main
-    if st["side"] is None or st["side"].device != w.device:
-        st["side"] = torch.cuda.Stream(device=w.device)
-    side = st["side"]
-    if len(st["marks"]) >= 2:
-        gate = st["marks"][-2]
-    else:                                     # first launches of a sequence: fork here
-        gate = torch.cuda.Event()
-        gate.record(main)
-    side.wait_event(gate)
-    _b.check(_lib().pfd_prefetch(w.data_ptr(), w.numel() * w.element_size(), side.cuda_stream), "pfd_prefetch")
-    done = torch.cuda.Event()
-    done.record(side)
-    st["last"] = done
-    st["n"] += 1
-    if st["n"] % _PF_JOIN_EVERY == 0:         # keep the fork shallow: this read was gated two launches back, it is long done
-        main.wait_event(done)
-        st["last"] = None
-
-
-def _prefetch_mark():
-    """after the consumer's launch: the event the prefetch two launches ahead will be gated on"""
-    st = _pf_state()
-    e = torch.cuda.Event()
-    e.record(torch.cuda.current_stream())
-    st["marks"] = (st["marks"] + [e])[-2:]
-
-
-def prefetch_join():
-    """the current stream waits for the outstanding prefetches; forget the events (they must not cross a capture boundary)"""
-    st = getattr(_PF, "st", None)
-    if st is None:
-        return
-    if st["last"] is not None:
-        torch.cuda.current_stream().wait_event(st["last"])
-    st["marks"], st["last"], st["main"] = [], None, None
 
 
 _WS = {}
@@ -264,7 +196,23 @@ def _written(out, stats=None):
         set_gn_stats(out, stats)
     elif out is not None and getattr(out, "_pfd_gn", None) is not None:
         out._pfd_gn = None
+    if out is not None and getattr(out, "_pfd_normed", None) is not None:
+        out._pfd_normed = None
     return out
+
+
+def set_normed(t, key, y):
+    """attach the GroupNorm of `t` that its producer already computed (conv(gn_fuse=...)): key = (id of the norm module's
+    gamma storage, eps, silu).  Rides on the tensor OBJECT like the statistics; any rewrite of the object drops it."""
+    t._pfd_normed = (key, t.data_ptr(), tuple(t.shape), y)
+    return t
+
+
+def get_normed(t, key):
+    ent = getattr(t, "_pfd_normed", None)
+    if ent is None or ent[0] != key or ent[1] != t.data_ptr() or ent[2] != tuple(t.shape):
+        return None
+    return ent[3]
 
 
 def cat_pair(t):
@@ -369,12 +317,8 @@ def gemm(a, w, *, bias=None, rowvec=None, rows_per_rv=1, res=None, act=ACT_NONE,
     if _TRACE:
         _trace(d)
     lib = _lib()
-    if WPREFETCH:
-        _prefetch_weights(w)
     rc = lib.pfd_gemm_f16_ex(_byref(d), tile, _stream()) if tile else lib.pfd_gemm_f16(_byref(d), _stream())
     _b.check(rc, f"pfd_gemm_f16 M{M} N{N} K{K}")
-    if WPREFETCH:
-        _prefetch_mark()
     _written(out, gst)
     return out if stats is None else (out, stats)
 
@@ -386,12 +330,20 @@ def conv_gn_fusable(B, H, W_, C1, C2, N, ksize=3, stride=1, pad=1):
             (B * H * W_) % 256 == 0 and N % 160 == 0 and C1 % 64 == 0 and C2 % 64 == 0)
 
 
+# Shapes whose fused GroupNorm request (conv(gn_fuse=...)) the library declined once (it decides whether a problem splits K):
+# not asked again.  Key: everything the decision depends on.
+_GNF_DECLINED = set()
+
+
 def conv(x, w, ksize, *, stride=1, pad=None, ups=False, bias=None, rowvec=None, res=None, act=ACT_NONE,
-         out=None, tile=0, out_hw=None, rows_per_rv=None, gn=None, gn_out=False):
+         out=None, tile=0, out_hw=None, rows_per_rv=None, gn=None, gn_out=False, gn_fuse=None):
     """Implicit-GEMM convolution of an NHWC image x[B,H,W,Cin] (Cin % 64 == 0) with packed
     weights w[N, ksize*ksize*Cin]; returns [B,Ho,Wo,N].  rowvec: [B, N] per-sample vector.
     gn = (table, x2, silu): GroupNorm(+SiLU) of the virtual concat [x | x2] applied while the input is staged
-    (table from groupnorm_table; see PfdGemmDesc.gn_table) -- x is then the UN-normalised tensor."""
+    (table from groupnorm_table; see PfdGemmDesc.gn_table) -- x is then the UN-normalised tensor.
+    gn_fuse = (gamma, beta, eps, silu, keep_raw): GroupNorm(32)(+SiLU) of the OUTPUT inside the launch's split-K reduction
+    (PfdGemmDesc.gnf_y, ABI 9).  Returns (raw | None, normalised) when the library serves it, else None with NOTHING launched
+    (a problem it does not split, a width the fused reduction is not built for): the caller runs conv + groupnorm."""
     _chk16(x, "conv x")
     _chk16(w, "conv W")
     B, H, W_, Cin = x.shape
@@ -448,18 +400,38 @@ def conv(x, w, ksize, *, stride=1, pad=None, ups=False, bias=None, rowvec=None, 
         if x2 is not None:
             d.A2, d.lda2 = x2.data_ptr(), x2.stride(2)
     gst = None
+    if gn_fuse is not None:
+        if gn is not None or gn_out:
+            raise ValueError("conv: gn_fuse cannot be combined with gn= / gn_out=")
+        g_gamma, g_beta, g_eps, g_silu, g_keep = gn_fuse
+        key = (B, H, W_, Cin, N, ksize, stride, pad, bool(ups), Ho, Wo, act, rowvec is not None,
+               None if rowvec is None else d.rows_per_rv)
+        if key in _GNF_DECLINED:
+            return None
+        _chk16(g_gamma, "conv gn_fuse gamma")
+        _chk16(g_beta, "conv gn_fuse beta")
+        if g_gamma.numel() != N or g_beta.numel() != N:
+            raise ValueError(f"conv: gn_fuse gamma / beta must have {N} entries")
+        y = torch.empty((B, Ho, Wo, N), dtype=torch.float16, device=x.device)
+        d.gnf_gamma, d.gnf_beta, d.gnf_y, d.gnf_ldy = g_gamma.data_ptr(), g_beta.data_ptr(), y.data_ptr(), N
+        d.gnf_eps, d.gnf_act, d.gnf_rows, d.gnf_skip_raw = float(g_eps), ACT_SILU if g_silu else ACT_NONE, Ho * Wo, 0 if g_keep else 1
+        lib = _lib()
+        rc = lib.pfd_gemm_f16_ex(_byref(d), tile, _stream()) if tile else lib.pfd_gemm_f16(_byref(d), _stream())
+        if rc == _b.PFD_ESHAPE:      # nothing was launched (include/pfd_hip.h)
+            _GNF_DECLINED.add(key)
+            return None
+        _b.check(rc, f"pfd_gemm_f16(conv, fused GroupNorm) M{M} N{N} K{K}")
+        if _TRACE:
+            _trace(d)
+        return (_written(out) if g_keep else None), y
     if gn_out and gn is None and gn_stats_wanted(B, Ho * Wo, N) and Cin % 64 == 0:   # (True = "where a GroupNorm will use them")
         gst = _new_gn_stats(M, N, x.device)
         d.gn_out = gst.data_ptr()
     if _TRACE:
         _trace(d)
     lib = _lib()
-    if WPREFETCH:
-        _prefetch_weights(w)
     rc = lib.pfd_gemm_f16_ex(_byref(d), tile, _stream()) if tile else lib.pfd_gemm_f16(_byref(d), _stream())
     _b.check(rc, f"pfd_gemm_f16(conv) M{M} N{N} K{K}" + (" with GroupNorm prologue" if gn is not None else ""))
-    if WPREFETCH:
-        _prefetch_mark()
     return _written(out, gst)
 
 

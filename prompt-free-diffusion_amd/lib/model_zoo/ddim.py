@@ -333,13 +333,11 @@ class DDIMSampler(object):
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):     # warm-up outside capture: packs weights, sizes the allocator
             run_loop(sx, sc, sh)
-            ops.prefetch_join()           # (PFD_WPREFETCH: no prefetch event crosses into the capture)
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         g = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g):
             outs = run_loop(sx, sc, sh)
-            ops.prefetch_join()           # the prefetch branch joins the captured stream before the capture ends
         return g, sx, sc, sh, outs, keep
 
     @ops.serialised

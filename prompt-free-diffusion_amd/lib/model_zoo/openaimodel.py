@@ -47,12 +47,24 @@ class TimestepBlock(nn.Module):
 class TimestepEmbedSequential(nn.Sequential, TimestepBlock):
     """Children get the time embedding / the context according to their kind."""
 
-    def hip(self, x, semb, context=None, x2=None, emb=None, cfg_pair=False):
+    def first_norm(self):
+        """(GroupNorm, silu) that reads this layer's input alone -- a ResBlock's in_layers[0] (+ SiLU), a SpatialTransformer's
+        norm -- or None (convolutions, the head)"""
+        first = self[0] if len(self) else None
+        if isinstance(first, ResBlock):
+            return first.in_layers[0], True
+        if isinstance(first, SpatialTransformer):
+            return first.norm, False
+        return None
+
+    def hip(self, x, semb, context=None, x2=None, emb=None, cfg_pair=False, next_norm=None):
         """semb: SiLU(time embedding) [B, 4C] or None when `emb` = (table [rows, sumC], {id(block): col}, shared)
-        already holds every ResBlock's emb_layers output (UNetModel2D_Next.emb_projections)"""
-        for layer in self:
+        already holds every ResBlock's emb_layers output (UNetModel2D_Next.emb_projections).
+        next_norm: see ResBlock.hip (only a trailing ResBlock uses it)"""
+        last = len(self) - 1
+        for li, layer in enumerate(self):
             if isinstance(layer, ResBlock):
-                x, x2 = layer.hip(x, semb, x2=x2, emb=emb), None
+                x, x2 = layer.hip(x, semb, x2=x2, emb=emb, next_norm=next_norm if li == last else None), None
             elif isinstance(layer, SpatialTransformer):
                 x = layer.hip(x, context, cfg_pair=cfg_pair)
             elif isinstance(layer, nn.Sequential):  # UNet head: GN -> SiLU -> conv
@@ -116,6 +128,8 @@ class ResBlock(TimestepBlock):
     # the patch kernel's loader waves costs the convolution 20-26 us, the apply pass it removes 13-18 us; end to end
     # 6.58 vs 6.68 images/s), so it is off unless PFD_GN_PROLOGUE=1 (tests switch it per call).
     fuse_groupnorm = os.environ.get("PFD_GN_PROLOGUE", "0") == "1"
+    # GroupNorm 2 (+ SiLU) inside the split-K reduction of the first convolution (PfdGemmDesc.gnf_y; tests switch it per call)
+    fuse_reduce_groupnorm = os.environ.get("PFD_GNF", "1") != "0"     # (PFD_GNF=0: A/B runs)
 
     def __init__(self, channels, emb_channels, dropout, out_channels=None, use_conv=False,
                  use_scale_shift_norm=False, dims=2, use_checkpoint=False, up=False, down=False):
@@ -146,10 +160,12 @@ class ResBlock(TimestepBlock):
         else:
             self.skip_connection = L.Conv2d(channels, self.out_channels, 1)
 
-    def hip(self, x, semb, x2=None, emb=None):
+    def hip(self, x, semb, x2=None, emb=None, next_norm=None):
         """x (and optional x2, the skip tensor of a virtual channel concat [x | x2]): NHWC fp16;
         semb: SiLU(time embedding) [B, emb_channels] fp16; emb: precomputed projections (see
-        TimestepEmbedSequential.hip)."""
+        TimestepEmbedSequential.hip).  next_norm = (GroupNorm module, silu) of the layer that reads this block's output
+        alone (not as half of a skip concat): where the last convolution splits K its reduction also writes that norm's
+        result, which rides on the returned tensor (ops.set_normed) -- the consumer's GroupNorm launch disappears."""
         C1 = x.shape[-1]
         C2 = 0 if x2 is None else x2.shape[-1]
         assert C1 + C2 == self.channels
@@ -160,6 +176,7 @@ class ResBlock(TimestepBlock):
         fuse_in = fuse and ops.conv_gn_fusable(B, H, W_, C1, C2, self.out_channels)
         fuse_out = fuse and ops.conv_gn_fusable(B, H, W_, self.out_channels, 0, self.out_channels)
         rows_per_rv = None
+        h_norm = None
         if emb is not None:
             table, cols, shared = emb
             c0 = cols[id(self)]
@@ -173,8 +190,15 @@ class ResBlock(TimestepBlock):
                                       gn=(self.in_layers[0].hip_table(x, x2), x2, True))
         else:
             hn = self.in_layers[0].hip(x, x2, silu=True)                   # [B,H,W,C1+C2]
-            # conv + bias + emb; its output is read by GroupNorm 2 only: the statistics come with it (ops.gemm gn_out)
-            h = self.in_layers[2].hip(hn, rowvec=e, rows_per_rv=rows_per_rv, gn_out=not fuse_out)
+            # conv + bias + emb; its output is read by GroupNorm 2 only.  Where the convolution splits K (the 8^2 / 16^2
+            # levels) GroupNorm 2 + SiLU happen inside its reduction launch and the raw tensor is never written (round 5,
+            # PfdGemmDesc.gnf_y); elsewhere the statistics come with the store (ops.gemm gn_out)
+            fused = None if fuse_out or not self.fuse_reduce_groupnorm else \
+                self.in_layers[2].hip_gn(hn, self.out_layers[0], silu=True, rowvec=e, rows_per_rv=rows_per_rv)
+            if fused is not None:
+                h, h_norm = None, fused[1]
+            else:
+                h = self.in_layers[2].hip(hn, rowvec=e, rows_per_rv=rows_per_rv, gn_out=not fuse_out)
         skip = self.skip_connection
         if isinstance(skip, nn.Identity):
             assert x2 is None
@@ -197,7 +221,14 @@ class ResBlock(TimestepBlock):
             return self.out_layers[3].hip(h, res=sk, gn=(self.out_layers[0].hip_table(h), None, True))
         # (the block's output feeds the next GroupNorm -- a ResBlock's, a SpatialTransformer's, the head's -- possibly
         #  later, as a skip: statistics with the store)
-        return self.out_layers[3].hip(self.out_layers[0].hip(h, silu=True), res=sk, gn_out=True)
+        if h_norm is None:
+            h_norm = self.out_layers[0].hip(h, silu=True)
+        if next_norm is not None and self.fuse_reduce_groupnorm:
+            norm, nsilu = next_norm
+            fused = self.out_layers[3].hip_gn(h_norm, norm, silu=nsilu, keep_raw=True, res=sk)
+            if fused is not None:
+                return ops.set_normed(fused[0], norm.fuse_key(nsilu), fused[1])
+        return self.out_layers[3].hip(h_norm, res=sk, gn_out=True)
 
     def forward(self, x, emb):
         semb = ops.activation(emb.to(torch.float16).contiguous(), ops.ACT_SILU)
@@ -397,17 +428,24 @@ class UNetModel2D_Next(nn.Module, L._Packed):
         ccs = list(control) if control is not None else None
         hs = []
         h = x
+        nn_of = self._next_norms(cnet, control is not None) if not isinstance(context, ContextMix) else {}
+        step = [0]
+
+        def data_layer(hh, x2=None):
+            return next(d_iter).hip(hh, semb, x2=x2, emb=emb, next_norm=nn_of.get(step[0]))
         for ltype in self.i_order:
             if ltype == 'd':
-                h = next(d_iter).hip(h, semb, emb=emb)
+                h = data_layer(h)
             elif ltype == 'c':
                 h = ctx_layer(h)
             else:
                 hs.append(ops.cat_pair(h) if pair[0] else h)   # a skip saved before the doubling: stored doubled
+            step[0] += 1
         if pair[0]:
             raise ValueError("cfg_pair: no context layer in the input half of this UNet")
         for ltype in self.m_order:
-            h = next(d_iter).hip(h, semb, emb=emb) if ltype == 'd' else ctx_layer(h)
+            h = data_layer(h) if ltype == 'd' else ctx_layer(h)
+            step[0] += 1
         if ccs is not None:
             h = ops.add(h, ccs.pop())
         skip = None
@@ -417,10 +455,51 @@ class UNetModel2D_Next(nn.Module, L._Packed):
                 if ccs is not None:
                     skip = ops.add(skip, ccs.pop())
             elif ltype == 'd':
-                h, skip = next(d_iter).hip(h, semb, x2=skip, emb=emb), None
+                h, skip = data_layer(h, x2=skip), None
             else:
                 h = ctx_layer(h)
+            step[0] += 1
         return h
+
+    def _next_norms(self, cnet, with_control):
+        """{position in i_order + m_order + o_order of a data layer: (GroupNorm, silu)} -- the norm that reads that layer's
+        output ALONE: the next layer is a context layer (SpatialTransformer.norm) or a data layer that starts with a ResBlock
+        and takes no skip concat (in_layers[0] + SiLU).  With ControlNet residuals the middle block's output is modified
+        before its consumer reads it: no hint there.  Cached per (context net, control) on the module."""
+        cache = self.__dict__.setdefault("_nn_cache", {})
+        key = (id(cnet), bool(with_control))
+        if key in cache:
+            return cache[key]
+        order = list(self.i_order) + list(self.m_order) + list(self.o_order)
+        d_list, c_list = list(self.data_blocks), list(cnet.context_blocks)
+        di = ci = 0
+        seq = []                                   # (kind, module | None) per position
+        for lt in order:
+            if lt == 'd':
+                seq.append(('d', d_list[di]))
+                di += 1
+            elif lt == 'c':
+                seq.append(('c', c_list[ci]))
+                ci += 1
+            else:
+                seq.append((lt, None))
+        n_in, n_mid = len(self.i_order), len(self.m_order)
+        out = {}
+        for i, (kind, mod) in enumerate(seq):
+            if kind != 'd' or not isinstance(mod[len(mod) - 1], ResBlock):
+                continue
+            j = i + 1
+            while j < len(seq) and seq[j][0] not in ('d', 'c', 'load_hidden_feature'):
+                j += 1                             # ('save_hidden_feature' keeps the tensor: the raw result is stored anyway)
+            if j >= len(seq) or seq[j][0] == 'load_hidden_feature':
+                continue                           # consumed as half of a skip concat (or not at all)
+            if with_control and i == n_in + n_mid - 1:
+                continue                           # `h = h + control.pop()` sits between (pfd.py:515)
+            fn = seq[j][1].first_norm()
+            if fn is not None:
+                out[i] = fn
+        cache[key] = out
+        return out
 
     def forward(self, x, timesteps, context):
         y = self.hip(ops.to_nhwc(x), timesteps, as_context_kv(context))

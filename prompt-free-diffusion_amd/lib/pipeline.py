@@ -101,13 +101,11 @@ class _GraphedStage:
             side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side):     # warm-up outside capture: packs weights, sizes the allocator
                 self.fn(sx)
-                ops.prefetch_join()           # (PFD_WPREFETCH: no prefetch event crosses into the capture)
             torch.cuda.current_stream().wait_stream(side)
             torch.cuda.synchronize()
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g):
                 out = self.fn(sx)
-                ops.prefetch_join()           # the prefetch branch joins the captured stream before the capture ends
             if len(self.graphs) >= 4:
                 torch.cuda.synchronize()      # never drop a graph whose replay may still be in flight
                 self.graphs.clear()

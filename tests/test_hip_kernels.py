@@ -156,6 +156,44 @@ def test_conv_groupnorm_prologue(B, hw, c1, c2, cout, silu):
         c8.hip(x8, gn=(g8.hip_table(x8), None, True))
 
 
+@pytest.mark.parametrize("B,hw,cin,silu,res", [(8, 16, 1280, True, False), (8, 8, 1280, True, False), (8, 8, 2560, True, False),
+                                               (4, 16, 640, False, True)])
+def test_conv_with_groupnorm_in_its_splitk_reduction(B, hw, cin, silu, res):
+    """conv3x3 -> GroupNorm32 (-> SiLU) (`h = in_layers(x) + emb_out; h = out_layers(h)`, openaimodel.py:254-272) with the
+    normalisation inside the convolution's split-K reduction launch (PfdGemmDesc.gnf_y, ABI 9): the same bits as the
+    two-call form (raw tensor too, when kept), equal to torch fp32 within fp16 noise; shapes the library does not split
+    are declined (None) without a launch."""
+    from lib.hip import layers as L
+    from lib.hip import ops
+    torch.manual_seed(11)
+    cout = 1280
+    conv = L.Conv2d(cin, cout, 3, padding=1).half().cuda()
+    gn = L.GroupNorm(32, cout, eps=1e-5).half().cuda()
+    with torch.no_grad():
+        gn.weight.normal_(1.0, 0.2)
+        gn.bias.normal_(0.0, 0.2)
+    x = _dev(B, hw, hw, cin, scale=1.0)
+    e = _dev(B, cout, seed=7)
+    r = _dev(B, hw, hw, cout, seed=6) if res else None
+    fused = conv.hip_gn(x, gn, silu=silu, keep_raw=res, rowvec=e, res=r)
+    assert fused is not None, "the 8^2 / 16^2 convolutions split K: the fused reduction must serve them"
+    raw, y = fused
+    h = conv.hip(x, rowvec=e, res=r)
+    two = gn.hip(h, silu=silu)
+    assert torch.equal(y, two)
+    assert (raw is None) == (not res) and (raw is None or torch.equal(raw, h))
+    ref = F.conv2d(x.float().permute(0, 3, 1, 2), conv.weight.float(), conv.bias.float(), padding=1) + e.float()[:, :, None, None]
+    if res:
+        ref = ref + r.float().permute(0, 3, 1, 2)
+    ref = F.group_norm(ref, 32, gn.weight.float(), gn.bias.float(), 1e-5)
+    ref = (F.silu(ref) if silu else ref).permute(0, 2, 3, 1)
+    close(y.float(), ref)
+    # a convolution the library does not split (64^2) / a width the fused form is not built for (cpg 10): declined, no launch
+    c64 = L.Conv2d(320, 320, 3, padding=1).half().cuda()
+    g64 = L.GroupNorm(32, 320).half().cuda()
+    assert c64.hip_gn(_dev(2, 64, 64, 320), g64) is None
+
+
 def test_groupnorm_concat_and_layernorm():
     from lib.hip import ops
     x1, x2 = _dev(2, 6, 5, 320), _dev(2, 6, 5, 640, seed=3)

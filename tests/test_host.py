@@ -330,91 +330,6 @@ def test_serving_validates_at_submit_and_isolates_failures(monkeypatch):
         late.future.result(5)
 
 
-def test_weight_prefetch_bookkeeping_with_fake_streams(monkeypatch):
-    """PFD_WPREFETCH (round-5 candidate, default off): the side-stream bookkeeping of lib/hip/ops.py on fake streams / events --
-    prefetch i is gated on the completion mark of launch i - 2 (the first two fork at the call), the consumer never waits for
-    its own prefetch except at the periodic join, prefetch_join() joins the last read and forgets every event."""
-    from lib.hip import ops
-    log = []
-
-    class FakeEvent:
-        n = 0
-
-        def __init__(self):
-            FakeEvent.n += 1
-            self.id, self.on = FakeEvent.n, None
-
-        def record(self, stream):
-            self.on = stream.name
-            log.append(("record", self.id, stream.name))
-
-    class FakeStream:
-        def __init__(self, name="side", device=None):
-            self.name, self.device, self.cuda_stream = name, device, 0x51DE
-
-        def wait_event(self, ev):
-            log.append(("wait", self.name, ev.id, ev.on))
-
-        def __ne__(self, other):
-            return self is not other
-
-    main = FakeStream("main")
-
-    class FakeLib:
-        def pfd_prefetch(self, ptr, nbytes, stream):
-            log.append(("prefetch", ptr, nbytes, stream))
-            return 0
-
-    class W:
-        device = None
-
-        def __init__(self, i):
-            self.i = i
-
-        def data_ptr(self):
-            return 1000 + self.i
-
-        def numel(self):
-            return 64
-
-        def element_size(self):
-            return 2
-
-    monkeypatch.setattr(ops.torch.cuda, "current_stream", lambda: main)
-    monkeypatch.setattr(ops.torch.cuda, "Stream", lambda device=None: FakeStream("side", device))
-    monkeypatch.setattr(ops.torch.cuda, "Event", FakeEvent)
-    monkeypatch.setattr(ops, "_lib", lambda: FakeLib())
-    ops._PF.st = None
-    marks = []
-    for i in range(5):
-        ops._prefetch_weights(W(i))
-        ops._prefetch_mark()
-        marks.append(log[-1][1])                     # id of the mark event recorded on main after launch i
-    pref = [k for k, e in enumerate(log) if e[0] == "prefetch"]
-    assert [log[k][1] for k in pref] == [1000 + i for i in range(5)] and all(log[k][2] == 128 for k in pref)
-    gates = [log[k - 1] for k in pref]               # the side stream's wait right in front of each read
-    assert all(g[0] == "wait" and g[1] == "side" and g[3] == "main" for g in gates)
-    assert gates[0][2] not in marks and gates[1][2] not in marks        # the first two fork at the call
-    assert [g[2] for g in gates[2:]] == marks[:3]                        # prefetch i waits for the mark of launch i - 2
-    assert not any(e[0] == "wait" and e[1] == "main" for e in log)       # the consumer stream has not waited for anything
-    ops.prefetch_join()
-    assert log[-1][0] == "wait" and log[-1][1] == "main" and log[-1][3] == "side"
-    st = ops._PF.st
-    assert st["marks"] == [] and st["last"] is None
-    n = len(log)
-    ops.prefetch_join()                              # nothing outstanding: no-op
-    assert len(log) == n
-    # the periodic join keeps the fork shallow
-    monkeypatch.setattr(ops, "_PF_JOIN_EVERY", 2)
-    ops._PF.st = None
-    del log[:]
-    for i in range(4):
-        ops._prefetch_weights(W(i))
-        ops._prefetch_mark()
-    assert sum(1 for e in log if e[0] == "wait" and e[1] == "main") == 2
-    ops._PF.st = None
-
-
 def test_tracked_launch_list_parses_under_the_gpu_tests_reader():
     """profiles/unet_c2_gemm_shapes.txt is read by GPU-only tests (tests/test_hip_kernels_fullsize.py) and by
     `selftest --replay`: run the SAME reader and the same record filters here, so a regenerated file (new fields, lost

@@ -1,8 +1,7 @@
-// CPU emulation of csrc/attention.hip (see hip/hip_runtime.h): the fused attention kernels against a double-precision
-// softmax(scale Q K^T) V, and the kernel stages of PFD_ATTN against each other -- mode 7 (round-5 candidate: s_setprio
-// around the MFMA clusters, never run on hardware) must give the bits of mode 6.
-//   usage: emu_attn <mode> [--quick]     (the mode is read once per process by the library: one process per mode;
-//   prints one line per case with a checksum of the output bits, which the caller compares between modes)
+// CPU emulation of csrc/attention.hip (see hip/hip_runtime.h): the fused attention kernels (8-wave d = 40 form with the PV
+// product on 16x16x32 and the maximum folded into the QK^T MFMA; 4-wave form for every head dim) against a double-precision
+// softmax(scale Q K^T) V.
+//   usage: emu_attn [--quick] [--w4]     (--w4: the 4-wave d = 40 form; prints one line per case with a checksum of the output bits)
 #include <stdio.h>
 
 #include <random>
@@ -78,11 +77,10 @@ static void run_case(int B, int H, int Nq, int Nk, int D) {
 
 int main(int argc, char** argv) {
   bool quick = false, force8 = true;
-  for (int i = 2; i < argc; ++i) {
+  for (int i = 1; i < argc; ++i) {
     quick = quick || !strcmp(argv[i], "--quick");
     if (!strcmp(argv[i], "--w4")) force8 = false;   // the 4-wave d = 40 form (what small launches take)
   }
-  if (argc > 1) setenv("PFD_ATTN", argv[1], 1);
   if (force8) setenv("PFD_ATTN_FORCE8", "1", 1);      // the 8-wave d = 40 form at these (small) sizes
   else unsetenv("PFD_ATTN_FORCE8");
   run_case(1, 2, 300, 200, 40);           // ragged queries and keys, 4 KV tiles (3 full + 1 peeled)

@@ -44,12 +44,14 @@ struct Case {
   int ksize = 0, stride = 1, pad = 0, ups = 0, B = 0, H = 0, W = 0, Cin = 0;
   int base_variant = -1;   // >= 0: additionally demand the same bits as this variant
   bool w_tiled = false;    // the weight is handed over K-tile-contiguous (PfdGemmDesc.w_tiled)
-  bool gn_par = false;     // the launch emits GroupNorm statistics; run it again under PFD_GN_PAR=1: same output, same statistics
+  bool gn_stats = false;   // the launch emits GroupNorm statistics (PfdGemmDesc.gn_out): checked against the sums of what it stored
+  int gnf = 0;             // 1 / 2: GroupNorm(+SiLU) fused into the split-K reduction (PfdGemmDesc.gnf_y), raw tensor skipped / kept
 };
 
 static int run_variant(const Case& c, int variant, const std::vector<h16>& A, const std::vector<h16>& A2, const std::vector<h16>& Wt,
                        const std::vector<h16>& bias, const std::vector<h16>& rv, const std::vector<h16>& R, int M, int K, int Ho, int Wo,
-                       std::vector<h16>& C, std::vector<float>& ws, std::vector<float>* gn = nullptr) {
+                       std::vector<h16>& C, std::vector<float>& ws, std::vector<float>* gn = nullptr, std::vector<h16>* gnf_y = nullptr,
+                       const std::vector<h16>* gnf_gb = nullptr, int gnf_skip_raw = 0) {
   const bool conv = c.ksize > 0;
   PfdGemmDesc d;
   memset(&d, 0, sizeof(d));
@@ -74,6 +76,10 @@ static int run_variant(const Case& c, int variant, const std::vector<h16>& A, co
   d.zero_rows = c.zero_rows;
   d.ws = ws.data(); d.ws_bytes = ws.size() * sizeof(float);
   if (gn) d.gn_out = gn->data();
+  if (gnf_y) {
+    d.gnf_gamma = gnf_gb->data(); d.gnf_beta = gnf_gb->data() + c.N; d.gnf_y = gnf_y->data(); d.gnf_ldy = c.N; d.gnf_eps = 1e-5f;
+    d.gnf_act = PFD_ACT_SILU; d.gnf_rows = conv ? Ho * Wo : M; d.gnf_skip_raw = gnf_skip_raw;
+  }
   return pfd_gemm160_try(&d, variant, c.splits, nullptr);
 }
 
@@ -107,7 +113,7 @@ static int run_case(const Case& c) {
   std::vector<float> ws((size_t)8 * M * N + 64);
   g_err.clear();
   std::vector<float> gn1((size_t)(M / 64 + 1) * (N / 160) * 32, -1.f), gn2 = gn1;
-  const int rc = run_variant(c, c.variant, A1, A2, Wt, bias, rv, R, M, K, Ho, Wo, C, ws, c.gn_par ? &gn1 : nullptr);
+  const int rc = run_variant(c, c.variant, A1, A2, Wt, bias, rv, R, M, K, Ho, Wo, C, ws, c.gn_stats ? &gn1 : nullptr);
   if (rc != 0) { printf("FAIL %-70s rc=%d %s\n", c.what, rc, g_err.c_str()); return 1; }
   // double-precision reference
   double max_err = 0, max_ref = 0;
@@ -150,7 +156,7 @@ static int run_case(const Case& c) {
     if (rc2 != 0 || nd) { fails = 1; extra = " | vs variant " + std::to_string(c.base_variant) + ": rc " + std::to_string(rc2) + ", " + std::to_string(nd) + " elements differ"; }
     else extra = " | == variant " + std::to_string(c.base_variant) + " bitwise";
   }
-  if (ok && c.gn_par) {
+  if (ok && c.gn_stats) {
     // the statistics are the sums of the f16 values the launch stored, per 64-row slab and group of N / 32 channels
     const int cpg = N / 32, tn = N / 160, ngl = 160 / cpg;
     double worst = 0;
@@ -163,39 +169,52 @@ static int run_case(const Case& c) {
           const size_t o = (((size_t)sl * tn + t) * 16 + gl) * 2;
           worst = std::max(worst, std::max(fabs(a - gn1[o]) / (1 + fabs(a)), fabs(q - gn1[o + 1]) / (1 + fabs(q))));
         }
-    std::vector<h16> C2((size_t)M * N, (h16)-55.f);
-    setenv("PFD_GN_PAR", "1", 1);
-    const int rc2 = run_variant(c, c.variant, A1, A2, Wt, bias, rv, R, M, K, Ho, Wo, C2, ws, &gn2);
-    unsetenv("PFD_GN_PAR");
-    const bool same = rc2 == 0 && !memcmp(C.data(), C2.data(), C.size() * sizeof(h16)) && !memcmp(gn1.data(), gn2.data(), gn1.size() * sizeof(float));
-    if (worst > 1e-3 || !same) fails = 1;
-    extra += std::string(" | statistics err ") + std::to_string(worst) + (same ? " | PFD_GN_PAR=1: same output and statistics bitwise" : " | PFD_GN_PAR=1 DIFFERS");
+    if (worst > 1e-3) fails = 1;
+    extra += std::string(" | statistics err ") + std::to_string(worst);
+  }
+  if (ok && c.gnf) {
+    // the same launch with the fused GroupNorm request: raw result (when kept) bit for bit the plain reduction's, the normalised
+    // tensor against a double-precision GroupNorm(32) + SiLU of that raw result
+    auto gb = rand_h((size_t)2 * N, 1.f);
+    std::vector<h16> C2((size_t)M * N, (h16)-55.f), Y((size_t)M * N, (h16)-33.f);
+    const int rc2 = run_variant(c, c.variant, A1, A2, Wt, bias, rv, R, M, K, Ho, Wo, C2, ws, nullptr, &Y, &gb, c.gnf == 1 ? 1 : 0);
+    size_t nd = 0, untouched = 0;
+    for (size_t i = 0; i < C.size(); ++i) { nd += memcmp(&C[i], &C2[i], sizeof(h16)) != 0; untouched += (float)C2[i] == -55.f; }
+    const int HW = conv ? Ho * Wo : M, Bn = M / HW, cpg = N / 32;
+    double werr = 0;
+    for (int b = 0; b < Bn; ++b)
+      for (int g = 0; g < 32; ++g) {
+        double a = 0, q = 0;
+        for (int p = 0; p < HW; ++p)
+          for (int ch = g * cpg; ch < (g + 1) * cpg; ++ch) { const double v = (double)C[((size_t)b * HW + p) * N + ch]; a += v; q += v * v; }
+        const double n = (double)HW * cpg, mean = a / n, rstd = 1.0 / sqrt(q / n - mean * mean + 1e-5);
+        for (int p = 0; p < HW; ++p)
+          for (int ch = g * cpg; ch < (g + 1) * cpg; ++ch) {
+            double v = ((double)C[((size_t)b * HW + p) * N + ch] - mean) * rstd * (double)gb[ch] + (double)gb[N + ch];
+            v = v / (1.0 + exp(-v));
+            werr = std::max(werr, fabs(v - (double)Y[((size_t)b * HW + p) * N + ch]) / std::max(1.0, fabs(v)));
+          }
+      }
+    const bool raw_ok = c.gnf == 2 ? nd == 0 : untouched == C2.size();
+    if (rc2 != 0 || !raw_ok || werr > 4e-3) fails = 1;
+    extra += " | fused GroupNorm: rc " + std::to_string(rc2) + (c.gnf == 2 ? ", raw differs in " + std::to_string(nd) : ", raw elements written " + std::to_string(C2.size() - untouched)) +
+             ", normalised err " + std::to_string(werr);
+    if (!fails) {   // and a request the library must decline without launching: the same problem unsplit
+      Case u = c; u.splits = 1;
+      std::vector<h16> C3((size_t)M * N, (h16)-55.f), Y3((size_t)M * N, (h16)-33.f);
+      const int rc3 = run_variant(u, c.variant, A1, A2, Wt, bias, rv, R, M, K, Ho, Wo, C3, ws, nullptr, &Y3, &gb, 0);
+      size_t touched = 0;
+      for (size_t i = 0; i < C3.size(); ++i) touched += ((float)C3[i] != -55.f) + ((float)Y3[i] != -33.f);
+      if (rc3 != 1 || touched) { fails = 1; extra += " | UNSPLIT REQUEST NOT DECLINED (rc " + std::to_string(rc3) + ", " + std::to_string(touched) + " written)"; }
+      else extra += " | unsplit request declined, nothing written";
+    }
   }
   printf("%s %-70s max err %.2e (max |ref| %.2f)%s\n", fails ? "FAIL" : "ok  ", c.what, max_err, max_ref, extra.c_str());
   fflush(stdout);
   return fails;
 }
 
-// --auto: which kernel the AUTOMATIC choice (variant 0) launches for a few small problems under the current environment
-// (PFD_AREG=<mask> must turn the ring / 2-stage picks into their register-operand forms, and only those)
-static int auto_map() {
-  emu::dry_run = true;   // the choice is made on the host: nothing has to run
-  struct P { const char* what; int M, N, K; };
-  const P ps[] = {{"ring23", 130, 160, 576}, {"ring83", 2100, 160, 576}, {"two-stage22", 700, 320, 320}, {"two-stage82", 9000, 160, 320}};
-  for (const auto& q : ps) {
-    Case c{q.what, q.M, q.N, q.K, 0, 0};
-    auto A = rand_h((size_t)q.M * q.K + 64, 1.f), W = rand_h((size_t)q.N * q.K, 0.1f), b = rand_h(q.N, 0.5f), rv = b, R = b, A2 = b;
-    std::vector<h16> C((size_t)q.M * q.N);
-    std::vector<float> ws((size_t)8 * q.M * q.N + 64);
-    emu::launched.clear();
-    const int rc = run_variant(c, 0, A, A2, W, b, rv, R, q.M, q.K, 0, 0, C, ws);
-    printf("auto %-12s rc %d -> %s\n", q.what, rc, emu::launched.empty() ? "(nothing)" : emu::launched[0].c_str());
-  }
-  return 0;
-}
-
 int main(int argc, char** argv) {
-  if (argc > 1 && !strcmp(argv[1], "--auto")) return auto_map();
   std::vector<Case> cases;
   auto lin = [&](const char* w, int M, int N, int K, int v, int sp, bool res, int base) {
     Case c{w, M, N, K, v, sp}; c.res = res; c.base_variant = base; cases.push_back(c); return &cases.back();
@@ -204,40 +223,28 @@ int main(int argc, char** argv) {
     Case c{w, 0, N, 0, v, sp}; c.res = res; c.ksize = ks; c.stride = st; c.pad = pad; c.ups = ups; c.B = B; c.H = H; c.W = W; c.Cin = Cin;
     c.base_variant = base; cases.push_back(c); return &cases.back();
   };
-  // the LDS-ring kernels the register-operand ones must agree with (sanity of the emulation itself)
+  // the hardware-validated LDS-ring kernels (sanity of the emulation itself)
   lin("variant 23 (64x160, 4-stage LDS ring) 200x160x512", 200, 160, 512, 23, 1, true, -1);
   lin("variant 83 (128x160, 8 waves, 3-stage LDS ring) 200x160x320", 200, 160, 320, 83, 1, false, -1);
-  // 5-stage LDS rings (forced variants 26 / 46, never run on hardware either)
+  // 5-stage LDS rings (forced variants 26 / 46)
   lin("variant 26 (64x160, 5-stage LDS ring) eleven steps", 200, 320, 704, 26, 1, true, 23);
   lin("variant 46 (64x160 on 8 waves, 5-stage LDS ring) nine steps", 130, 160, 576, 46, 1, true, 43);
-  // register-operand ring kernels (forced variants 27 / 45 / 85 / 29 / 86 / 28)
-  lin("variant 27 one K step", 100, 160, 64, 27, 1, true, 23);
-  lin("variant 27 seven steps = one trip round the ring", 130, 160, 448, 27, 1, true, 23);
-  lin("variant 27 eleven steps, ragged M, two column tiles", 200, 320, 704, 27, 1, false, 23);
-  lin("variant 27 split-K 2 (8 steps per split)", 100, 160, 1024, 27, 2, true, 23);
-  { auto c = lin("variant 27 two-source contraction (k_split 192)", 130, 160, 512, 27, 1, true, 23); c->k_split = 192; }
-  { auto c = lin("variant 27 zero rows (64 whole + a straddling tile)", 200, 160, 256, 27, 1, true, 23); c->zero_rows = 100; }
-  { auto c = lin("variant 27 SiLU + row vector", 130, 160, 256, 27, 1, false, 23); c->act = PFD_ACT_SILU; c->rowvec = true; }
-  { auto c = lin("variant 27 K-tile-contiguous weights, two column tiles", 130, 320, 448, 27, 1, true, 23); c->w_tiled = true; }
-  { auto c = lin("variant 85 K-tile-contiguous weights, split-K 2", 260, 320, 1024, 85, 2, false, 83); c->w_tiled = true; }
-  lin("variant 45 (8 waves) nine steps", 130, 160, 576, 45, 1, true, 43);
-  lin("variant 85 (128 rows, 8 waves) nine steps", 260, 160, 576, 85, 1, true, 83);
-  lin("variant 29 (5 weight stages) nine steps", 130, 160, 576, 29, 1, true, 23);
-  lin("variant 86 (128 rows, 3 stages) five steps", 260, 160, 320, 86, 1, true, 82);
-  lin("variant 28 (64 rows, 3 stages) five steps", 130, 320, 320, 28, 1, true, 22);
-  conv("variant 27 conv 3x3 s1 p1, 2 x 8 x 8 x 64 -> 160", 160, 27, 1, 3, 1, 1, 0, 2, 8, 8, 64, true, 23);
-  conv("variant 85 conv 3x3 s1 p1, 2 x 8 x 8 x 128 -> 160 (18 steps)", 160, 85, 1, 3, 1, 1, 0, 2, 8, 8, 128, true, 83);
-  conv("variant 45 conv 3x3 stride 2, 1 x 16 x 16 x 64 -> 160", 160, 45, 1, 3, 2, 1, 0, 1, 16, 16, 64, false, 43);
-  conv("variant 27 conv 3x3 + nearest-2x upsample, 1 x 4 x 4 x 64 -> 160", 160, 27, 1, 3, 1, 1, 1, 1, 4, 4, 64, false, 23);
-  conv("variant 85 conv 3x3 split-K 2, 1 x 8 x 8 x 128 -> 160", 160, 85, 2, 3, 1, 1, 0, 1, 8, 8, 128, true, 83);
-  // split-K reduction that also emits the GroupNorm statistics, plain and with three row sweeps in flight (PFD_GN_PAR=1)
-  { auto c = lin("split-K 4 + GroupNorm statistics (N 320: cpg 10), residual", 128, 320, 1024, 23, 4, true, -1); c->gn_par = true; }
-  { auto c = conv("split-K 2 conv 8x8x128 -> 1280 + statistics (cpg 40), SiLU-free", 1280, 83, 2, 3, 1, 1, 0, 2, 8, 8, 128, true, -1); c->gn_par = true; }
+  // split-K reduction that also emits the GroupNorm statistics (three row sweeps in flight)
+  { auto c = lin("split-K 4 + GroupNorm statistics (N 320: cpg 10), residual", 128, 320, 1024, 23, 4, true, -1); c->gn_stats = true; }
+  { auto c = conv("split-K 2 conv 8x8x128 -> 1280 + statistics (cpg 40), SiLU-free", 1280, 83, 2, 3, 1, 1, 0, 2, 8, 8, 128, true, -1); c->gn_stats = true; }
+  // split-K reduction that also NORMALISES (PfdGemmDesc.gnf_y, round 5): 8 samples so that B * 32 >= 128 blocks as the host demands
+  { auto c = conv("fused GroupNorm: split-K 2 conv 4x4x128 -> 1280 (cpg 40), row vector, raw skipped", 1280, 83, 2, 3, 1, 1, 0, 8, 4, 4, 128, false, -1); c->rowvec = true; c->gnf = 1; }
+  { auto c = conv("fused GroupNorm: split-K 3 conv 4x4x192 -> 1280, residual, raw kept", 1280, 23, 3, 3, 1, 1, 0, 4, 4, 4, 192, true, -1); c->gnf = 2; }
+  { auto c = conv("fused GroupNorm: split-K 2 patch conv 16x16x128 -> 1280, raw skipped", 1280, 98, 2, 3, 1, 1, 0, 4, 16, 16, 128, false, -1); c->rowvec = true; c->gnf = 1; }
   // the barrier forms of the patch kernel (sanity of the emulation on the hardware-validated kernels)
   conv("variant 98 patch conv 16x16 (loader waves, barrier per tap), 2 channel blocks", 160, 98, 1, 3, 1, 1, 0, 1, 16, 16, 128, true, -1);
   conv("variant 96 patch conv 16x16 (3-stage weight ring), 2 channel blocks", 160, 96, 1, 3, 1, 1, 0, 1, 16, 16, 128, true, 98);
   { auto c = conv("variant 96 patch conv 16x16, K-tile-contiguous weights, two column tiles", 320, 96, 1, 3, 1, 1, 0, 1, 16, 16, 128, true, -1); c->w_tiled = true; }
   { auto c = conv("variant 83 implicit-GEMM conv, K-tile-contiguous weights, two column tiles", 320, 83, 1, 3, 1, 1, 0, 1, 8, 8, 128, false, -1); c->w_tiled = true; }
+  // 8 x 8 images: tiles of four whole samples on the loader-wave patch kernels (round 5)
+  conv("variant 96 patch conv 8x8, four samples per tile, 2 channel blocks", 160, 96, 1, 3, 1, 1, 0, 4, 8, 8, 128, true, -1);
+  { auto c = conv("variant 98 patch conv 8x8, two tiles, split over 3 channel blocks, row vector", 160, 98, 3, 3, 1, 1, 0, 8, 8, 8, 192, false, -1); c->rowvec = true; }
+  { auto c = conv("variant 96 patch conv 8x8 + GroupNorm statistics, two column tiles", 320, 96, 1, 3, 1, 1, 0, 4, 8, 8, 64, true, -1); c->gn_stats = true; }
   conv("variant 99 patch conv 16x16 (8-wave form), 2 channel blocks", 160, 99, 1, 3, 1, 1, 0, 1, 16, 16, 128, true, 98);
   // the patch kernel that hands over through LDS progress words (95) against the barrier form (98)
   conv("variant 95 patch conv 16x16, 2 channel blocks", 160, 95, 1, 3, 1, 1, 0, 1, 16, 16, 128, true, 98);

@@ -75,98 +75,6 @@ def audit(asm_path):
     return {k: v for k, v in res.items() if "kernel" in k}
 
 
-def areg_loop_waits(asm_path):
-    """gemm160ar_kernel (A fragments in registers, uncounted asm loads): {kernel: (KEEP, bad)} where `bad` lists every VM
-    wait between the first and the last MFMA of the kernel that is neither the counted wait of the K loop (vmcnt(KEEP),
-    KEEP = per-step VMEM instructions x (ring depth - 2)) nor the drain of the loop's tail (a bare vmcnt(0)); a
-    compiler-inserted wait there (it shows as `vmcnt(N) lgkmcnt(M)` or another N) would serialise the ring."""
-    res, name, body = {}, None, []
-    for line in open(asm_path):
-        m = re.match(r"^(_Z[A-Za-z0-9_]+):", line)
-        if m:
-            name, body = m.group(1), []
-            continue
-        if name and "gemm160ar_kernel" in name:
-            t = line.split(";")[0].strip()
-            if t.startswith(".Lfunc_end"):
-                tm = re.search(r"gemm160ar_kernelILi(\d)ELi(\d)ELi(\d)E", name)
-                waves_m, wmb, nbuf = (int(x) for x in tm.groups())
-                nw = 2 * waves_m
-                keep = (2 * wmb + (20 + nw - 1) // nw) * (nbuf - 2)
-                idx = [i for i, x in enumerate(body) if x.startswith("v_mfma")]
-                loop = body[idx[0]:idx[-1] + 1]
-                waits = [x for x in loop if x.startswith("s_waitcnt") and "vmcnt" in x]
-                bad = [x for x in waits if x not in (f"s_waitcnt vmcnt({keep})", "s_waitcnt vmcnt(0)")]
-                res[name] = (keep, bad, len([x for x in waits if x == f"s_waitcnt vmcnt({keep})"]), nbuf)
-                name = None
-            elif t:
-                body.append(t)
-    return res
-
-
-def _regs(tok):
-    """v[a:b] / vN operand -> set of VGPR numbers"""
-    m = re.match(r"^v\[(\d+):(\d+)\]$", tok)
-    if m:
-        return set(range(int(m.group(1)), int(m.group(2)) + 1))
-    m = re.match(r"^v(\d+)$", tok)
-    return {int(m.group(1))} if m else set()
-
-
-def areg_register_hygiene(asm_path):
-    """gemm160ar_kernel: a register loaded by one of the uncounted asm loads (the activation ring) may be READ by nothing but
-    the MFMAs that consume it -- a compiler copy / spill of such a register between the load and the counted wait would move
-    garbage (guide 5.7 item 1).  hipcc does use the ring registers as address temporaries while they are dead (between the
-    last MFMA of a slot and the load that refills it, often as the load's own address operand); those reads see a value
-    written by an ordinary instruction and are fine.  Walks each kernel in program order with, per register, whether its last
-    writer was an asm load.  -> {kernel: (offending instructions, ring registers)}"""
-    res, name, body, in_asm = {}, None, [], False
-    for line in open(asm_path):
-        m = re.match(r"^(_Z[A-Za-z0-9_]+):", line)
-        if m:
-            name, body = m.group(1), []
-            continue
-        if name and "gemm160ar_kernel" in name:
-            raw = line.strip()
-            if raw.startswith(";;#ASMSTART"):
-                in_asm = True
-                continue
-            if raw.startswith(";;#ASMEND"):
-                in_asm = False
-                continue
-            t = line.split(";")[0].strip()
-            if t.startswith(".Lfunc_end"):
-                ring = set()
-                for asm, x in body:
-                    if asm and x.startswith("global_load_dwordx4"):
-                        ring |= _regs(x.split()[1].rstrip(","))
-                loaded = set()      # ring registers whose last writer is an asm load
-                bad = []
-                for asm, x in body:
-                    parts = x.split()
-                    if len(parts) < 2 or x.endswith(":"):
-                        continue
-                    ops = [o.rstrip(",") for o in parts[1:]]
-                    if asm and x.startswith("global_load_dwordx4"):
-                        loaded |= _regs(ops[0])       # (its address operand may overlap: read at issue, before the write)
-                        continue
-                    store = parts[0].startswith(("global_store", "scratch_store", "ds_write", "buffer_store"))
-                    srcs = ops if store else ops[1:]
-                    dsts = [] if store else ops[:1]
-                    if parts[0].startswith("v_mfma"):
-                        srcs, dsts = [ops[3]], [ops[0]]          # A / B operands may read the ring; C / D must not be it
-                    for o in srcs:
-                        if _regs(o) & loaded:
-                            bad.append(x)
-                    for o in dsts:
-                        loaded -= _regs(o)
-                res[name] = (bad, len(ring))
-                name = None
-            elif t:
-                body.append((in_asm, t))
-    return res
-
-
 def findings(files=None):
     files = files or [os.path.join(CSRC, f) for f in ("gemm_glds.hip", "gemm_conv.hip", "norm.hip")]
     bad, rows = [], []
