@@ -1362,17 +1362,15 @@ __global__ __launch_bounds__(768) void conv3x3_patch_ws_kernel(const G160Params 
   // output tile: TH x TW pixels (TW = the image width when a tile is whole image rows, else p.pt_w)
   const int W = p.Wd, H = p.H;
   const int hw = H * W;
-  // Round 5: 8 x 8 images (the lowest UNet level).  A tile is FOUR whole samples -- 4 x 64 consecutive output rows -- and the
-  // patch holds their four 10 x 10 zero-padded images back to back (4 x 100 = 400 rows: exactly PATCH_ROWS): patch row
-  // s * 100 + (y + 1) * 10 + (x + 1).  The 64 rows of a consumer wave's row group wm are sample wm of the tile.  Before,
-  // these convolutions ran the 64 x 160 implicit-GEMM ring kernels, which re-fetch the activations per tap and stage a
-  // 20 KB weight tile per 64 rows: 322 MB of LDS fill for 15 GFLOP, bound by the L2 -> LDS path at ~9 TB/s (35 us, 430 TF/s).
-  const bool s8 = GN == 0 && hw == 64;          // (host: W == H == 8, M % 256 == 0; the GroupNorm-prologue forms never see it)
-  const int TW = s8 ? 8 : (p.pt_w ? p.pt_w : W);
-  const int TH = s8 ? 8 : 256 / TW, PW = TW + 2;
-  const int tpi = s8 ? 1 : hw / 256, ntx = W / TW;
-  const int b = s8 ? tile_m * 4 : tile_m / tpi;
-  const int ti = s8 ? 0 : tile_m - b * tpi;
+  // (Round 5 also ran 8 x 8 images through this kernel -- tiles of four whole samples, 4 x 100 patch rows -- instead of the
+  //  64 x 160 ring kernels: 43 vs 35 us per 512 x 1280 x 11520 convolution with 7 splits, +1.1 % per batch; with 10 / 16
+  //  splits still +0.5 %: 112-160 blocks of a kernel with a ~10 us fixed cost do not beat 256 blocks of latency-chained
+  //  ring tiles.  Removed; profiles/r05_patch8_ab.log.)
+  const int TW = p.pt_w ? p.pt_w : W;
+  const int TH = 256 / TW, PW = TW + 2;
+  const int tpi = hw / 256, ntx = W / TW;
+  const int b = tile_m / tpi;
+  const int ti = tile_m - b * tpi;
   const int y0 = (ti / ntx) * TH, x0 = (ti % ntx) * TW;
   const int m0 = b * hw + y0 * W + x0;          // first output pixel of the tile (see tile_row_m)
   const int ncbs = max(0, cb_end - cb_begin);
@@ -1400,19 +1398,17 @@ __global__ __launch_bounds__(768) void conv3x3_patch_ws_kernel(const G160Params 
     // ================================ loader waves ================================
     const int lw = wave - NCW;
     const int srow = lane >> 3, cpos = lane & 7;
-    const int prow_count = s8 ? 400 : (TH + 2) * PW;
+    const int prow_count = (TH + 2) * PW;
     const half_t* img = p.A + (long)b * hw * p.lda;
     // patch piece q covers LDS rows 8 q .. 8 q + 7; this loader owns q = 6 tap + lw (all loaders) and
     // q = 6 tap + 4 + lw (loaders 0-1), tap = 0..8, q < 50
     auto piece_off = [&](int q) -> int {   // element offset of this lane's source chunk from `img`, -1 = zero padding
       const int r = q * 8 + srow;
-      const int sm = s8 ? r / 100 : 0;              // sample of the tile (8 x 8 images), its 10 x 10 patch rows behind each other
-      const int rr = r - sm * 100;
-      const int py = (s8 ? rr : r) / PW, px = (s8 ? rr : r) - py * PW;
+      const int py = r / PW, px = r - py * PW;
       const int y = y0 - 1 + py, x = x0 - 1 + px;
       const int c = (cpos - (r & ~1)) & 7;   // rotation swizzle of the patch rows
       const bool ok = q < P_INSTR && r < prow_count && y >= 0 && y < H && x >= 0 && x < W;
-      return ok ? (int)((sm * hw + y * W + x) * p.lda + c * 8) : -1;
+      return ok ? (int)((y * W + x) * p.lda + c * 8) : -1;
     };
     int off_a[9], off_b[9];
 #pragma unroll
@@ -1633,8 +1629,7 @@ __global__ __launch_bounds__(768) void conv3x3_patch_ws_kernel(const G160Params 
     for (int i = 0; i < WMB; ++i) {
       const int ql = wm * 64 + i * 16;
       const int ty = ql / TW, tx = ql - ty * TW;
-      // (8 x 8 images: the 16 rows of a fragment are two image rows of sample wm)
-      rbase[i] = s8 ? wm * 100 + (2 * i + (l15 >> 3)) * 10 + (l15 & 7) : ty * PW + tx + l15;
+      rbase[i] = ty * PW + tx + l15;
     }
     const int sw = (l15 >> 1) & 7;
     const int boff0 = wn * 80 * ROWB + l15 * ROWB + (((0 + g) ^ sw) << 4);
@@ -1739,233 +1734,9 @@ __global__ __launch_bounds__(768) void conv3x3_patch_ws_kernel(const G160Params 
   epilogue_store<256, 5, 768, false, true>(pe, m0, n0, smem, tid, tile_m * (256 / GN_SLAB));
 }
 
-// ------------------------------------------------------------------------------------------------
-// Round-5 candidate, forced only (variant 95; never the automatic choice, not yet run on hardware): the wave-specialised
-// patch kernel WITHOUT the block-wide barrier per tap.  conv3x3_patch_ws_kernel passes 12 waves through one s_barrier
-// per tap: all eight consumers start their fragment reads together and drain the MFMA pipe together (wait share 0.50,
-// in-loop rate 0.67 of the instruction's ceiling).  Here the two sides hand over through per-wave progress words in LDS:
-//   ready[lw] = T + 1 by loader wave lw when ITS pieces of tap T (and, at a block's tap 0, of the patch) have landed
-//             (its own s_waitcnt vmcnt(0));  a consumer starts tap T when all four words are >= T + 1
-//   done[w]   = T + 1 by consumer wave w when its fragment reads of tap T have returned (lgkmcnt(0));  a loader refills the
-//             weight stage of tap T - 1 with tap T + 1 -- and writes the next block's patch pieces into the buffer block
-//             ci - 1 used -- when all eight words are >= T
-// so waves drift up to one tap apart and the two MFMA waves of a SIMD stop waiting at the same instant.  Two weight
-// stages (the 3-stage ring fills all 160 KiB; the progress words need 48 bytes), same LDS images, swizzles, DMA pieces,
-// summation order and epilogue as the <0, false, 2> instantiation: results must be bit-identical to it.  Every poll is
-// bounded (FL_SPIN_CAP): a protocol error gives wrong numbers in selftest, not a hung GPU.
-// ------------------------------------------------------------------------------------------------
-// (One WORD PER WAVE, not one shared counter per side: with a counter, `ready >= 4 (T + 1)` is also reached by three loaders
-//  that have handed over tap T + 1 and a fourth that is still on tap T - 1 -- 3 (T + 2) + T -- and the consumers would start
-//  tap T on pieces that have not landed; likewise `done`.  Each wave publishes its own progress, a waiter needs ALL of them.)
-constexpr int FL_SPIN_CAP = 1 << 16;   // ~3 ms of polling: three orders of magnitude above a tap, far below a watchdog
-typedef __attribute__((address_space(3))) unsigned lds_u32_t;
-// wait until every one of the N (4 | 8) progress words at `flags` is >= target: lane l polls word l % N, the wave votes
-template <int N>
-__device__ __forceinline__ void fl_wait_all(const char* flags, unsigned target, int lane) {
-  const volatile lds_u32_t* f = (const volatile lds_u32_t*)flags + (lane & (N - 1));   // ds_read_b32, not a flat load
-#pragma nounroll
-  for (int spin = 0; spin < FL_SPIN_CAP; ++spin) {
-    const unsigned v = *f;
-    if (__builtin_amdgcn_ballot_w64(v < target) == 0) break;
-    __builtin_amdgcn_s_sleep(1);
-  }
-  asm volatile("" ::: "memory");
-}
-// publish this wave's progress (its own word: a plain store, program order behind the waits that precede the call)
-__device__ __forceinline__ void fl_publish(char* flags, int w, unsigned count, int lane) {
-  asm volatile("" ::: "memory");
-  if (lane == 0) *((volatile lds_u32_t*)flags + w) = count;
-  asm volatile("" ::: "memory");
-}
-
-__global__ __launch_bounds__(768) void conv3x3_patch_fl_kernel(const G160Params p) {
-  constexpr int NCW = 8, NLW = 4, WMB = 4;
-  constexpr int PATCH_BYTES = PATCH_ROWS * ROWB;  // 51200
-  constexpr int WT_BYTES = BN * ROWB;             // 20480
-  constexpr int OFF_W = 2 * PATCH_BYTES;
-  constexpr int OFF_FLAGS = OFF_W + 2 * WT_BYTES; // ready[4] (loader waves), done[8] (consumer waves): taps handed over / read
-  constexpr int SMEM = OFF_FLAGS + 1024;
-  static_assert(SMEM <= 160 * 1024, "LDS");
-  constexpr int P_INSTR = PATCH_ROWS / 8;          // 50 DMA pieces per patch
-  __shared__ __attribute__((aligned(1024))) char smem[SMEM];
-  PFD_ARG_BATCH_CONV(p);
-
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int nblk = p.tiles_m * p.tiles_n;
-  const int t = xcd_remap(blockIdx.x, nblk);
-  const int tile_m = p.nmajor ? t % p.tiles_m : t / p.tiles_n;
-  const int tile_n = p.nmajor ? t / p.tiles_m : t - tile_m * p.tiles_n;
-  const int n0 = tile_n * BN;
-  const int split = blockIdx.z;
-  const int ncb = p.Cin / BK;
-  const int cb_begin = split * p.kt_per_split;
-  const int cb_end = min(ncb, cb_begin + p.kt_per_split);
-  const int W = p.Wd, H = p.H;
-  const int TW = p.pt_w ? p.pt_w : W;
-  const int TH = 256 / TW, PW = TW + 2;
-  const int hw = H * W;
-  const int tpi = hw / 256, ntx = W / TW;
-  const int b = tile_m / tpi;
-  const int ti = tile_m - b * tpi;
-  const int y0 = (ti / ntx) * TH, x0 = (ti % ntx) * TW;
-  const int m0 = b * hw + y0 * W + x0;
-  const int ncbs = max(0, cb_end - cb_begin);
-  const int nsteps = ncbs * 9;
-  char* const f_ready = smem + OFF_FLAGS;
-  char* const f_done = smem + OFF_FLAGS + 16;
-
-  auto block_barrier = [&]() {
-    __builtin_amdgcn_sched_barrier(0);
-    asm volatile("" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-    __builtin_amdgcn_sched_barrier(0);
-  };
-  if (tid < 12) {
-    volatile lds_u32_t* f = (volatile lds_u32_t*)(smem + OFF_FLAGS);
-    f[tid] = 0u;
-  }
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  block_barrier();                            // the counters are zero before anyone polls or adds
-
-  if (wave >= NCW) {
-    // ================================ loader waves ================================
-    const int lw = wave - NCW;
-    const int srow = lane >> 3, cpos = lane & 7;
-    const int prow_count = (TH + 2) * PW;
-    const half_t* img = p.A + (long)b * hw * p.lda;
-    auto piece_off = [&](int q) -> int {
-      const int r = q * 8 + srow;
-      const int py = r / PW, px = r - py * PW;
-      const int y = y0 - 1 + py, x = x0 - 1 + px;
-      const int c = (cpos - (r & ~1)) & 7;   // rotation swizzle of the patch rows
-      const bool ok = q < P_INSTR && r < prow_count && y >= 0 && y < H && x >= 0 && x < W;
-      return ok ? (int)((y * W + x) * p.lda + c * 8) : -1;
-    };
-    int off_a[9], off_b[9];
-#pragma unroll
-    for (int tp = 0; tp < 9; ++tp) {
-      off_a[tp] = piece_off(6 * tp + lw);
-      off_b[tp] = piece_off(6 * tp + 4 + lw);
-    }
-    auto issue_patch = [&](int buf, int cb, int q, int off) {
-      glds16(off >= 0 ? (const void*)(img + off + cb * BK) : (const void*)g_zero_page,
-             smem + buf * PATCH_BYTES + q * 1024);
-    };
-    const half_t* wp[5];
-#pragma unroll
-    for (int j = 0; j < 5; ++j) {
-      const int r = (lw + NLW * j) * 8 + srow;
-      const int c = cpos ^ ((r >> 1) & 7);
-      wp[j] = PFD_W_ROW_PTR(BN, p, tile_n, n0, r, c * 8);
-    }
-    auto issue_w = [&](int stage, int tap, int cb) {
-      const long k0 = (long)(tap * (p.Cin / BK) + cb) * p.w_kstep;
-#pragma unroll
-      for (int j = 0; j < 5; ++j) glds16(wp[j] + k0, smem + OFF_W + stage * WT_BYTES + (lw + NLW * j) * 1024);
-    };
-    if (nsteps > 0) {
-#pragma unroll
-      for (int tp = 0; tp < 9; ++tp) {     // the whole first patch
-        if (6 * tp + lw < P_INSTR) issue_patch(0, cb_begin, 6 * tp + lw, off_a[tp]);
-        if (lw < 2 && 6 * tp + 4 + lw < P_INSTR) issue_patch(0, cb_begin, 6 * tp + 4 + lw, off_b[tp]);
-      }
-      issue_w(0, 0, cb_begin);
-    }
-    int stage = 0;
-    unsigned T = 0;                           // taps handed over so far
-    for (int ci = 0; ci < ncbs; ++ci) {
-      const int cb = cb_begin + ci;
-      const int pbuf = ci & 1;
-      const bool more = ci + 1 < ncbs;
-      const int cb1 = more ? cb + 1 : cb;
-#pragma unroll
-      for (int tap = 0; tap < 9; ++tap) {
-        __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): this wave's pieces of tap T (and of the patch) are in LDS
-        fl_publish(f_ready, lw, T + 1, lane);
-        fl_wait_all<8>(f_done, T, lane);      // every consumer has read tap T - 1: its weight stage (and block ci - 1's patch) are free
-        if (tap < 8) issue_w(stage ^ 1, tap + 1, cb);
-        else if (more) issue_w(stage ^ 1, 0, cb1);
-        if (more) {
-          if (6 * tap + lw < P_INSTR) issue_patch(pbuf ^ 1, cb1, 6 * tap + lw, off_a[tap]);
-          if (lw < 2 && 6 * tap + 4 + lw < P_INSTR) issue_patch(pbuf ^ 1, cb1, 6 * tap + 4 + lw, off_b[tap]);
-        }
-        stage ^= 1;
-        ++T;
-      }
-    }
-    block_barrier();                          // (B) consumers finished the last tap: LDS is free
-    block_barrier();                          // (C) the staging image is written
-  } else {
-    // ================================ consumer waves ================================
-    const int wm = wave >> 1, wn = wave & 1;
-    const int l15 = lane & 15, g = lane >> 4;
-    int rbase[WMB];
-#pragma unroll
-    for (int i = 0; i < WMB; ++i) {
-      const int ql = wm * 64 + i * 16;
-      const int ty = ql / TW, tx = ql - ty * TW;
-      rbase[i] = ty * PW + tx + l15;
-    }
-    const int sw = (l15 >> 1) & 7;
-    const int boff0 = wn * 80 * ROWB + l15 * ROWB + (((0 + g) ^ sw) << 4);
-    const int boff1 = wn * 80 * ROWB + l15 * ROWB + (((4 + g) ^ sw) << 4);
-    float4_t acc[WMB][5];
-#pragma unroll
-    for (int i = 0; i < WMB; ++i)
-#pragma unroll
-      for (int j = 0; j < 5; ++j) acc[i][j] = (float4_t){0.f, 0.f, 0.f, 0.f};
-    auto a_off = [&](int i, int toff, int ks) -> int {   // byte offset of A fragment i in the patch (rotation swizzle)
-      const int r = rbase[i] + toff;
-      return r * ROWB + ((((ks * 4 + g) + (r & ~1)) & 7) << 4);
-    };
-    int stage = 0;
-    unsigned T = 0;
-    for (int ci = 0; ci < ncbs; ++ci) {
-      const char* patch = smem + (ci & 1) * PATCH_BYTES;
-      int toff = 0;
-#pragma nounroll
-      for (int ky = 0; ky < 3; ++ky) {
-#pragma nounroll
-        for (int kx = 0; kx < 3; ++kx) {
-          ++T;
-          fl_wait_all<4>(f_ready, T, lane);   // all four loaders' pieces of this tap have landed
-          const char* wt = smem + OFF_W + stage * WT_BYTES;
-#pragma unroll
-          for (int ks = 0; ks < 2; ++ks) {
-            half8_t af[WMB], bf[5];
-#pragma unroll
-            for (int i = 0; i < WMB; ++i) af[i] = *reinterpret_cast<const half8_t*>(patch + a_off(i, toff, ks));
-            const int bo = ks ? boff1 : boff0;
-#pragma unroll
-            for (int j = 0; j < 5; ++j) bf[j] = *reinterpret_cast<const half8_t*>(wt + bo + j * 16 * ROWB);
-#pragma unroll
-            for (int i = 0; i < WMB; ++i)
-#pragma unroll
-              for (int j = 0; j < 5; ++j)
-                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[j], af[i], acc[i][j], 0, 0, 0);
-          }
-          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this tap's fragments are in registers
-          fl_publish(f_done, wave, T, lane);
-          stage ^= 1;
-          toff += 1;
-        }
-        toff += PW - 3;
-      }
-    }
-    block_barrier();                          // (B)
-    {
-      const G160Params pe = reload_params();
-      epilogue_stage<WMB, 5, true>(acc, pe, lane, m0, n0, wm, wn, split, smem);
-    }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    block_barrier();                          // (C)
-  }
-  const G160Params pe = reload_params();
-  epilogue_store<256, 5, 768, false, true>(pe, m0, n0, smem, tid, tile_m * (256 / GN_SLAB));
-}
+// (Round 5: a form of this kernel that hands tiles over through per-wave progress words in LDS instead of one block-wide
+//  barrier per tap -- forced variant 95, bit-identical, validated on hardware -- measured +0.2 % per batch and was removed,
+//  profiles/r05_e2e_ab_candidates.log; the protocol and its failed two-counter draft are in the git history.)
 
 // sum the split-K slabs and apply the epilogue (bias, row vector, activation, residual)
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const G160Params p) {
@@ -2041,8 +1812,12 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const G160Params p) 
 // 2-10 MB at the 8^2 / 16^2 levels; same slab order per element, same order of the rows in the statistics = the same bits;
 // adopted with the GroupNorm apply's grouped partial loads at -0.3 % per batch, profiles/r05_e2e_ab_candidates.log).
 // Up to 8 splits x 3 sweeps x 32 bytes = 96 + 24 VGPRs of loads.
-__global__ __launch_bounds__(256) void splitk_reduce_gn_kernel(const G160Params p) {
-  __shared__ __attribute__((aligned(16))) float red[5 * 320];
+// (round 5: 16 waves per slab -- the whole 64 rows requested in one round trip -- measured +0.3 % per batch against these 4,
+//  profiles/r05_small_kernel_threads_ab.log: unlike the single-launch GroupNorm kernels this grid is already 256-512 blocks)
+constexpr int RGN_T = 256;
+__global__ __launch_bounds__(RGN_T) void splitk_reduce_gn_kernel(const G160Params p) {
+  constexpr int RW = RGN_T / 64, ROWS_SW = 3 * RW;      // rows of one sweep of the block
+  __shared__ __attribute__((aligned(16))) float red[(RW + 1) * 320];
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int tiles_n = p.N / 160;
   const int slab = blockIdx.x / tiles_n, tile_n = blockIdx.x - slab * tiles_n;
@@ -2054,8 +1829,8 @@ __global__ __launch_bounds__(256) void splitk_reduce_gn_kernel(const G160Params 
   for (int e = 0; e < 8; ++e) cs[e] = cq[e] = 0.f;
   Pack16 bb;
   bb.u = *reinterpret_cast<const uint4*>(p.bias ? p.bias + n : g_zero_page);
-  constexpr int SWEEPS = (GN_SLAB + 11) / 12, U = 3;
-  static_assert(SWEEPS % U == 0, "six sweeps, three at a time");
+  constexpr int SWEEPS = (GN_SLAB + ROWS_SW - 1) / ROWS_SW, U = SWEEPS < 3 ? SWEEPS : 3;
+  static_assert(SWEEPS % U == 0, "sweeps in groups of U");
   for (int it0 = 0; it0 < SWEEPS; it0 += U) {
     int m[U];
     bool ok[U];
@@ -2063,7 +1838,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_gn_kernel(const G160Params 
     float v[U][8];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-      const int row_u = w * 3 + rsub + (it0 + u) * 12;
+      const int row_u = w * 3 + rsub + (it0 + u) * ROWS_SW;
       m[u] = min(slab * GN_SLAB + min(row_u, GN_SLAB - 1), p.M - 1);
       ok[u] = active && row_u < GN_SLAB && slab * GN_SLAB + row_u < p.M;
       rv[u].u = *reinterpret_cast<const uint4*>(p.rowvec ? p.rowvec + (long)(m[u] / p.rows_per_rv) * p.ldrv + n : g_zero_page);
@@ -2112,7 +1887,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_gn_kernel(const G160Params 
       if (ok[u]) *reinterpret_cast<uint4*>(p.C + (long)m[u] * p.ldc + n) = o.u;
     }
   }
-  gn_slab_reduce<1, 256>(cs, cq, tid, p.N / 32, slab, p.M / GN_SLAB, tiles_n, tile_n, p.gn_out, [&](int) { return red; });
+  gn_slab_reduce<1, RGN_T>(cs, cq, tid, p.N / 32, slab, p.M / GN_SLAB, tiles_n, tile_n, p.gn_out, [&](int) { return red; });
 }
 
 
@@ -2124,7 +1899,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_gn_kernel(const G160Params 
 // and forms it from the fp32 slabs: epilogue as in splitk_reduce_kernel (same slab order, same operation order: the same
 // f16 values), statistics and normalisation as in gn_small_kernel (same thread -> chunk mapping, same order of the adds,
 // same expressions: the same bits).  The raw result is stored too unless skip_raw.  Loads are unconditional and issued a
-// group of four chunks x four slabs at a time (16 x 16 bytes in flight per thread), indices walk incrementally (no
+// group of two chunks x four slabs at a time (8 x 16 bytes in flight per thread, 1024 threads), indices walk incrementally (no
 // division per chunk), gamma / beta of the group sit in LDS before the statistics barrier.
 struct GnFuse {
   const half_t* gamma;
@@ -2134,17 +1909,29 @@ struct GnFuse {
   float eps;
   int act, rows, skip_raw;
 };
-constexpr int GNF_MAX = 32;     // chunks (4 halfs) per thread: rows * (N / 128) <= 256 * GNF_MAX
+// 1024 threads per (sample, group) slab: the job is one round trip of 40-660 KB per block, i.e. bound by how many loads a
+// block has in flight; with 256 threads it took as long as the plain reduction (2048 blocks) + gn_small_kernel together
+// (16.8 us, profiles/r05_fused_gnorm_ab.log)
+#ifndef PFD_GN_THREADS
+#define PFD_GN_THREADS 1024   // (-DPFD_GN_THREADS=256: A/B builds; must match norm.hip for the bit identity)
+#endif
+constexpr int GNF_T = PFD_GN_THREADS;
+constexpr int GNF_MAX = 8192 / GNF_T;      // chunks (4 halfs) per thread: rows * (N / 128) <= GNF_T * GNF_MAX
+constexpr int GNF_U = 2;        // chunks whose slab slices are requested together: 2 x 4 slabs x 16 bytes = 32 VGPRs of loads (128-VGPR budget at 16 waves per CU)
 
-__global__ __launch_bounds__(256) void splitk_reduce_gnorm_kernel(const G160Params p, const GnFuse f) {
-  __shared__ float red[8];
+__global__ __launch_bounds__(GNF_T) void splitk_reduce_gnorm_kernel(const G160Params p, const GnFuse f) {
+  __shared__ float red[2 * GNF_T / 64];
   __shared__ float gam_s[256], bet_s[256];
   const int cpg = p.N / 32, cpr = cpg / 4;
-  const int g = blockIdx.x, b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  // XCD-aware order: the 32 group slabs of a sample are 160-byte column strips of the same rows, i.e. neighbours share
+  // cache lines -- all of them on one XCD (one L2), as many samples per XCD as the grid has (round 5: the plain (g, b) grid
+  // spread the groups of a sample over all eight L2s and every strip edge was fetched twice from the memory side)
+  const int lin = xcd_remap(blockIdx.x, gridDim.x);
+  const int g = lin & 31, b = lin >> 5, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int HW = f.rows, total = HW * cpr;
   const int n_g = g * cpg;
   const long m_b = (long)b * HW;
-  const int dr = 256 / cpr, dc = 256 - dr * cpr;
+  const int dr = GNF_T / cpr, dc = GNF_T - dr * cpr;
   // one row vector per sample (host: rows_per_rv % rows == 0 or rows_per_rv >= M)
   const half_t* rvb = p.rowvec ? p.rowvec + (m_b / p.rows_per_rv) * p.ldrv + n_g : g_zero_page;
   const int rv_step = p.rowvec ? 4 : 0, b_step = p.bias ? 4 : 0;
@@ -2155,17 +1942,17 @@ __global__ __launch_bounds__(256) void splitk_reduce_gnorm_kernel(const G160Para
   uint2 v[GNF_MAX];
   int r = tid / cpr, ch = tid - r * cpr;
 #pragma unroll
-  for (int k0 = 0; k0 < GNF_MAX; k0 += 4) {
-    if (256 * k0 >= total) {          // block-uniform: nothing of this group (or any later one) exists
+  for (int k0 = 0; k0 < GNF_MAX; k0 += GNF_U) {
+    if (GNF_T * k0 >= total) {          // block-uniform: nothing of this group (or any later one) exists
 #pragma unroll
-      for (int u = 0; u < 4; ++u) v[k0 + u] = make_uint2(0, 0);
+      for (int u = 0; u < GNF_U; ++u) v[k0 + u] = make_uint2(0, 0);
       continue;
     }
-    int ru[4], cu[4];
-    bool on[4];
+    int ru[GNF_U], cu[GNF_U];
+    bool on[GNF_U];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      on[u] = tid + 256 * (k0 + u) < total;
+    for (int u = 0; u < GNF_U; ++u) {
+      on[u] = tid + GNF_T * (k0 + u) < total;
       ru[u] = on[u] ? r : 0;          // slots past the slab read the slab's first chunk and are dropped below
       cu[u] = on[u] ? ch : 0;
       r += dr;
@@ -2175,22 +1962,22 @@ __global__ __launch_bounds__(256) void splitk_reduce_gnorm_kernel(const G160Para
         ++r;
       }
     }
-    Pack8 bq[4], rq[4], xq[4];
+    Pack8 bq[GNF_U], rq[GNF_U], xq[GNF_U];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
+    for (int u = 0; u < GNF_U; ++u) {
       bq[u].u = *reinterpret_cast<const uint2*>(bb0 + cu[u] * b_step);
       rq[u].u = *reinterpret_cast<const uint2*>(rvb + cu[u] * rv_step);
       xq[u].u = *reinterpret_cast<const uint2*>(rb + (long)ru[u] * r_ld + cu[u] * r_step);
     }
-    float acc[4][4];
+    float acc[GNF_U][4];
 #pragma unroll
-    for (int u = 0; u < 4; ++u)
+    for (int u = 0; u < GNF_U; ++u)
 #pragma unroll
       for (int e = 0; e < 4; ++e) acc[u][e] = 0.f;
     for (int s0 = 0; s0 < p.splits; s0 += 4) {   // the slab order of splitk_reduce_kernel
-      float4_t a[4][4];
+      float4_t a[GNF_U][4];
 #pragma unroll
-      for (int u = 0; u < 4; ++u)
+      for (int u = 0; u < GNF_U; ++u)
 #pragma unroll
         for (int q = 0; q < 4; ++q)
           a[u][q] = *reinterpret_cast<const float4_t*>(p.ws + ((long)min(s0 + q, p.splits - 1) * p.M + m_b + ru[u]) * p.N +
@@ -2199,13 +1986,13 @@ __global__ __launch_bounds__(256) void splitk_reduce_gnorm_kernel(const G160Para
       for (int q = 0; q < 4; ++q) {
         const float w = s0 + q < p.splits ? 1.f : 0.f;   // the clamped duplicates add nothing
 #pragma unroll
-        for (int u = 0; u < 4; ++u)
+        for (int u = 0; u < GNF_U; ++u)
 #pragma unroll
           for (int e = 0; e < 4; ++e) acc[u][e] += a[u][q][e] * w;
       }
     }
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
+    for (int u = 0; u < GNF_U; ++u) {
       Pack8 o;
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
@@ -2238,21 +2025,28 @@ __global__ __launch_bounds__(256) void splitk_reduce_gnorm_kernel(const G160Para
   }
   sm = wave_sum(sm);
   sq = wave_sum(sq);
+  constexpr int NWV = GNF_T / 64;
   if (lane == 0) {
     red[wave] = sm;
-    red[4 + wave] = sq;
+    red[NWV + wave] = sq;
   }
   __syncthreads();
   const float count = (float)HW * (float)cpg;
-  const float mean = (red[0] + red[1] + red[2] + red[3]) / count;
-  const float rstd = rsqrtf(fmaxf((red[4] + red[5] + red[6] + red[7]) / count - mean * mean, 0.f) + f.eps);
+  float ts = red[0], tq = red[NWV];
+#pragma unroll
+  for (int w = 1; w < NWV; ++w) {   // gn_small_kernel's order
+    ts += red[w];
+    tq += red[NWV + w];
+  }
+  const float mean = ts / count;
+  const float rstd = rsqrtf(fmaxf(tq / count - mean * mean, 0.f) + f.eps);
   half_t* yb = f.y + m_b * f.ldy + n_g;
   r = tid / cpr;
   ch = tid - r * cpr;
   asm volatile("" : "+v"(r), "+v"(ch));   // a second walk, not the index registers of the first one kept alive
 #pragma unroll
   for (int k = 0; k < GNF_MAX; ++k) {
-    if (tid + 256 * k < total) {
+    if (tid + GNF_T * k < total) {
       Pack8 q, o;
       q.u = v[k];
 #pragma unroll
@@ -2282,11 +2076,11 @@ thread_local GnFuse t_gnf = {nullptr, nullptr, nullptr, 0, 0.f, 0, 0, 0};
 inline void launch_splitk_reduce(const G160Params& p, hipStream_t s) {
   if (t_gnf.y) {   // (host: no gn_out / ln_out with it)
     const GnFuse f = t_gnf;
-    hipLaunchKernelGGL(splitk_reduce_gnorm_kernel, dim3(32, p.M / f.rows), dim3(256), 0, s, p, f);
+    hipLaunchKernelGGL(splitk_reduce_gnorm_kernel, dim3(32 * (p.M / f.rows)), dim3(GNF_T), 0, s, p, f);
     return;
   }
   if (p.gn_out) {
-    hipLaunchKernelGGL(splitk_reduce_gn_kernel, dim3((p.M / GN_SLAB) * (p.N / 160)), dim3(256), 0, s, p);
+    hipLaunchKernelGGL(splitk_reduce_gn_kernel, dim3((p.M / GN_SLAB) * (p.N / 160)), dim3(RGN_T), 0, s, p);
   } else {
     const long nvec = (long)p.M * (p.N / 8);
     int g = (int)((nvec + 255) / 256);
@@ -2330,19 +2124,6 @@ inline bool patch_ring_on() {
 // same for the loader-wave implicit-GEMM kernel (gemm160ws_kernel): PFD_WS_RING=0 keeps two stages
 inline bool ws_ring_on() {
   static const bool on = !(getenv("PFD_WS_RING") && atoi(getenv("PFD_WS_RING")) == 0);
-  return on;
-}
-
-// TEMPORARY (round-5 A/B of the remaining forced-only candidates; removed with the losers): PFD_R5X bit mask --
-//   1: 64 x 160 ring on 4 waves, 4 stages -> 5 (23 -> 26)   2: the same on 8 waves (43 -> 46)   4: patch kernel without the barrier per tap (95)
-inline int r5x_mode() {
-  static const int m = getenv("PFD_R5X") ? atoi(getenv("PFD_R5X")) : 0;
-  return m;
-}
-
-// TEMPORARY (A/B): PFD_PATCH8=0 keeps the 8 x 8 convolutions on the implicit-GEMM ring kernels
-inline bool patch8_on() {
-  static const bool on = !(getenv("PFD_PATCH8") && atoi(getenv("PFD_PATCH8")) == 0);
   return on;
 }
 
@@ -2417,7 +2198,6 @@ int launch160ws(G160Params& p, int bucket, hipStream_t s, int pp) {
 }
 
 // ws: 0 = 8-wave kernel, 1 = + 4 loader waves, 2 = + ping-pong consumer groups, 3 = loader waves + 3-stage weight ring,
-//     4 = loader waves handing over through LDS counters instead of a barrier per tap (forced variant 95, round-5 candidate)
 int launch_patch(G160Params& p, hipStream_t s, int ws) {
   p.tiles_m = p.M / 256;
   p.tiles_n = p.N / BN;
@@ -2433,7 +2213,6 @@ int launch_patch(G160Params& p, hipStream_t s, int ws) {
                    2.0 * p.B * p.H * p.Wd * p.Cin + 2.0 * p.N * p.K + 2.0 * p.M * p.N * (p.R ? 2 : 1), s);
   if (p.gn_table && p.gn_act == PFD_ACT_SILU) hipLaunchKernelGGL((conv3x3_patch_ws_kernel<2, false>), grid, dim3(768), 0, s, p);
   else if (p.gn_table) hipLaunchKernelGGL((conv3x3_patch_ws_kernel<1, false>), grid, dim3(768), 0, s, p);
-  else if (ws == 4) hipLaunchKernelGGL(conv3x3_patch_fl_kernel, grid, dim3(768), 0, s, p);
   else if (ws == 3) hipLaunchKernelGGL((conv3x3_patch_ws_kernel<0, false, 3>), grid, dim3(768), 0, s, p);
   else if (ws == 2) hipLaunchKernelGGL((conv3x3_patch_ws_kernel<0, true>), grid, dim3(768), 0, s, p);
   else if (ws) hipLaunchKernelGGL((conv3x3_patch_ws_kernel<0, false>), grid, dim3(768), 0, s, p);
@@ -2505,7 +2284,7 @@ int pfd_gemm160_try(const PfdGemmDesc* d, int variant, int splits, hipStream_t s
   if (gnf) {
     const int cpg = d->N / 32;
     if (bn != 160 || (d->N % 32) || (cpg % 4) || cpg < 32 || cpg > 256 || d->gnf_rows <= 0 || (d->M % d->gnf_rows) ||
-        (long)d->gnf_rows * (cpg / 4) > 256L * GNF_MAX || (long)(d->M / d->gnf_rows) * 32 < 128 || !d->gnf_gamma || !d->gnf_beta ||
+        (long)d->gnf_rows * (cpg / 4) > (long)GNF_T * GNF_MAX || (long)(d->M / d->gnf_rows) * 32 < 128 || !d->gnf_gamma || !d->gnf_beta ||
         (d->gnf_ldy & 3) || (reinterpret_cast<uintptr_t>(d->gnf_y) & 7) || d->act == PFD_ACT_GEGLU || d->Ct || d->ln_stats ||
         d->ln_out || d->gn_out || d->bias_per_row || !d->ws ||
         (d->gnf_act != PFD_ACT_NONE && d->gnf_act != PFD_ACT_SILU))
@@ -2562,13 +2341,10 @@ int pfd_gemm160_try(const PfdGemmDesc* d, int variant, int splits, hipStream_t s
     if (p.Wd % 32 == 0 && p.H % 8 == 0) pt_w = 32;
     else if (p.Wd % 16 == 0 && p.H % 16 == 0) pt_w = 16;
   }
-  // 8 x 8 images (round 5): tiles of four whole samples on the loader-wave patch kernels (not the 8-wave / flag / prologue forms)
-  const bool s8 = p.ksize == 3 && p.Wd == 8 && p.H == 8 && p.M % 256 == 0 && !p.gn_table && patch8_on() &&
-                  (variant == 0 || variant == 98 || variant == 96);
-  const bool patch_w = p.Wd == 16 || p.Wd == 32 || p.Wd == 64 || (pt_w != 0 && r3tiles_on()) || s8;
-  if (bn == 160 && (variant == 0 || variant == 99 || variant == 98 || variant == 97 || variant == 96 || variant == 95) && p.ksize == 3 && p.stride == 1 && p.pad == 1 && !p.ups &&
-      patch_w && p.Ho == p.H && p.Wo == p.Wd && (pt_w != 0 || s8 || p.H % (256 / p.Wd) == 0) &&
-      p.M % 256 == 0 && (s8 || ((long)p.H * p.Wd) % 256 == 0) && p.act != PFD_ACT_GEGLU) {
+  const bool patch_w = p.Wd == 16 || p.Wd == 32 || p.Wd == 64 || (pt_w != 0 && r3tiles_on());
+  if (bn == 160 && (variant == 0 || variant == 99 || variant == 98 || variant == 97 || variant == 96) && p.ksize == 3 && p.stride == 1 && p.pad == 1 && !p.ups &&
+      patch_w && p.Ho == p.H && p.Wo == p.Wd && (pt_w != 0 || p.H % (256 / p.Wd) == 0) &&
+      p.M % 256 == 0 && ((long)p.H * p.Wd) % 256 == 0 && p.act != PFD_ACT_GEGLU) {
     p.pt_w = pt_w;
     p.pt_sh = pt_w == 32 ? 5 : 4;
     // (The 8-wave 128-row ring beats the patch kernel on its smallest problems -- 16384 x 320 x 2880: 50 -> 43 us,
@@ -2595,12 +2371,10 @@ int pfd_gemm160_try(const PfdGemmDesc* d, int variant, int splits, hipStream_t s
     // on the long-K ones (32768 x 320 x 8640: 149 -> 131 us = 1435 TF; profiles/r02_patch_ws_ab.log), with ping-pong
     // consumer groups (round 3); 99 forces the 8-wave form, 98 loader waves + lock-step consumers, 97 ping-pong
     // 96 forces the 3-stage weight ring (two taps of weights in flight, counted vmcnt; round 4); PFD_PATCH_RING=0/1 picks the default
-    if (s8 && pp_on()) return 1;
-    const int ws = variant == 99 ? 0 : variant == 98 ? 1 : variant == 97 ? 2 : variant == 96 ? 3 : variant == 95 ? 4 : (pp_on() ? 2 : ((r5x_mode() & 4) && !p.gn_table && !s8) ? 4 : patch_ring_on() ? 3 : 1);
-    if (ws == 4 && p.gn_table) return 1;   // the GroupNorm prologue lives in conv3x3_patch_ws_kernel<1 / 2> only
+    const int ws = variant == 99 ? 0 : variant == 98 ? 1 : variant == 97 ? 2 : variant == 96 ? 3 : (pp_on() ? 2 : patch_ring_on() ? 3 : 1);
     return launch_patch(p, s, ws) < 0 ? PFD_ELAUNCH : 0;
   }
-  if (variant == 99 || variant == 98 || variant == 97 || variant == 96 || variant == 95 || p.gn_table) return 1;
+  if (variant == 99 || variant == 98 || variant == 97 || variant == 96 || p.gn_table) return 1;
   const bool auto_variant = variant == 0;
   const int nk_all = p.K / BK;
   if (auto_variant) {
@@ -2656,7 +2430,7 @@ int pfd_gemm160_try(const PfdGemmDesc* d, int variant, int splits, hipStream_t s
       if (splits > 8) splits = 8;
       while (splits > 1 && nk / splits < 16) --splits;  // the slab round trip must stay small vs the K loop
       while (splits > 1 && (size_t)splits * p.M * p.N * 4 > d->ws_bytes) --splits;
-    } else if (p.act != PFD_ACT_GEGLU && d->ws && (variant == 22 || variant == 23 || variant == 41 || variant == 43 || variant == 26 || variant == 46) && tl <= 128 && nk >= 16) {
+    } else if (p.act != PFD_ACT_GEGLU && d->ws && (variant == 22 || variant == 23 || variant == 41 || variant == 43) && tl <= 128 && nk >= 16) {
       splits = (int)(256 / tl);   // M <= 1024 rows (8^2 level, cond-half projections): 25 -> 21 us
       if (splits > 4) splits = 4;
       while (splits > 1 && (size_t)splits * p.M * p.N * 4 > d->ws_bytes) --splits;
@@ -2680,8 +2454,6 @@ int pfd_gemm160_try(const PfdGemmDesc* d, int variant, int splits, hipStream_t s
     if (variant == 82 && (p.ksize == 0 || (p.stride == 1 && !p.ups)) && tiles(128) <= 256 && nk_split >= 6) variant = 83;
   }
   const int conv = p.ksize > 0 ? 1 : 0;
-  if (auto_variant && bn == 160 && r5x_mode() != 0)
-    variant = (variant == 23 && (r5x_mode() & 1)) ? 26 : (variant == 43 && (r5x_mode() & 2)) ? 46 : variant;
   if (variant == 48 || variant == 49 || variant == 47) {   // 8 MFMA waves + 4 loader waves (49: ping-pong consumer groups, 47: 3-stage ring)
     const int mode = variant == 49 ? 1 : variant == 47 ? 2 : 0;
     if (bn == 128) return launch160ws<4>(p, 12 + 4 * conv, s, mode) < 0 ? PFD_ELAUNCH : 0;
@@ -2706,11 +2478,8 @@ int pfd_gemm160_try(const PfdGemmDesc* d, int variant, int splits, hipStream_t s
     // deep operand rings (counted vmcnt): K tiles in flight ahead of the MFMAs = 3 (64-row tile) / 2 (128-row tile)
     case 23: return launch160<2, 2, 4>(p, 14 + 4 * conv, s) < 0 ? PFD_ELAUNCH : 0;
     case 25: return launch160<2, 4, 3>(p, 13 + 4 * conv, s) < 0 ? PFD_ELAUNCH : 0;
-    // round-5 candidates, forced only (no heuristic picks them): the 64-row tiles on a 5-stage ring = 4 K tiles (112 KB of
-    // a CU's 160 KB) in flight.  The K loop of the chip-filling-once problems is a latency chain -- nk / DEPTH round trips
-    // of ~1.9 us each -- so 4 in flight instead of 3 is worth up to a quarter of it if the deeper ring costs nothing else
-    case 26: return launch160<2, 2, 5>(p, 14 + 4 * conv, s) < 0 ? PFD_ELAUNCH : 0;
-    case 46: return launch160<4, 1, 5>(p, 14 + 4 * conv, s) < 0 ? PFD_ELAUNCH : 0;
+    // (round 5: the same tiles on a 5-stage ring -- 4 K tiles in flight -- measured 0.0 % end to end and were removed,
+    //  profiles/r05_e2e_ab_candidates.log)
     // round 3 experiments: the same tiles on 8 waves (4 x 2 wave layout, wave tile 16 x 80 / 32 x 80): twice the waves
     // issuing LDS-DMA pieces per CU and two waves per SIMD on the problems whose one 4-wave block per CU is bound by the
     // piece issue rate (64-row tiles: 41 two stages, 43 four-stage ring; 128-row tiles: 82 two stages, 83 three)

@@ -365,12 +365,19 @@ __global__ __launch_bounds__(256) void gn_table_kernel(const half_t* __restrict_
 // registers (<= 32 chunks of 4 halves per thread), so statistics + normalise + activation are ONE launch
 // and the input is read once (4 B/element).  Serves the 8^2 / 16^2 / 32^2 UNet levels, where the
 // two-launch form is bound by launch latency (1280 @ 8^2: 10 us for 1.3 MB).  Needs (C/G) % 4 == 0.
-constexpr int GNS_MAX = 32;
+// 1024 threads per block since round 5 (four times fewer before): the launch is one round trip of the slab, so its time is set
+// by the loads a block has in flight.  The fused split-K reduction + GroupNorm of gemm_glds.hip (splitk_reduce_gnorm_kernel)
+// uses the SAME thread -> chunk mapping and the same order of the adds: the two give the same bits.
+#ifndef PFD_GN_THREADS
+#define PFD_GN_THREADS 1024   // (-DPFD_GN_THREADS=256: A/B builds)
+#endif
+constexpr int GNS_T = PFD_GN_THREADS;
+constexpr int GNS_MAX = 8192 / GNS_T;
 
-__global__ __launch_bounds__(256) void gn_small_kernel(GnSrc s, const half_t* __restrict__ gamma,
+__global__ __launch_bounds__(GNS_T) void gn_small_kernel(GnSrc s, const half_t* __restrict__ gamma,
                                                        const half_t* __restrict__ beta, half_t* __restrict__ y,
                                                        long ldy, int HW, int G, int act, float eps) {
-  __shared__ float red[8];
+  __shared__ float red[2 * GNS_T / 64];
   const int C = s.C1 + s.C2;
   const int cpg = C / G, cpr = cpg / 4;
   const int g = blockIdx.x, b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -379,7 +386,7 @@ __global__ __launch_bounds__(256) void gn_small_kernel(GnSrc s, const half_t* __
   float sm = 0.f, sq = 0.f;
 #pragma unroll
   for (int k = 0; k < GNS_MAX; ++k) {
-    const int idx = tid + 256 * k;
+    const int idx = tid + GNS_T * k;
     v[k] = make_uint2(0, 0);
     if (idx < total) {
       const int r = idx / cpr, c = g * cpg + (idx - r * cpr) * 4;
@@ -401,17 +408,24 @@ __global__ __launch_bounds__(256) void gn_small_kernel(GnSrc s, const half_t* __
   }
   sm = wave_sum(sm);
   sq = wave_sum(sq);
+  constexpr int NWV = GNS_T / 64;
   if (lane == 0) {
     red[wave] = sm;
-    red[4 + wave] = sq;
+    red[NWV + wave] = sq;
   }
   __syncthreads();
   const float count = (float)HW * (float)cpg;
-  const float mean = (red[0] + red[1] + red[2] + red[3]) / count;
-  const float rstd = rsqrtf(fmaxf((red[4] + red[5] + red[6] + red[7]) / count - mean * mean, 0.f) + eps);
+  float ts = red[0], tq = red[NWV];
+#pragma unroll
+  for (int w = 1; w < NWV; ++w) {
+    ts += red[w];
+    tq += red[NWV + w];
+  }
+  const float mean = ts / count;
+  const float rstd = rsqrtf(fmaxf(tq / count - mean * mean, 0.f) + eps);
 #pragma unroll
   for (int k = 0; k < GNS_MAX; ++k) {
-    const int idx = tid + 256 * k;
+    const int idx = tid + GNS_T * k;
     if (idx < total) {
       const int r = idx / cpr, c = g * cpg + (idx - r * cpr) * 4;
       Pack8 p, ga, be, o;
@@ -692,7 +706,7 @@ static void gn_chunks(int B, int C, int HW, int* nchunks_out, int* rpc_out) {
 // 1 when pfd_groupnorm_f16 would take the single-launch small-slab form (which needs no separate statistics)
 static bool gn_is_small(int B, int C, int HW, int G) {
   const int cpg = C / G;
-  return cpg % 4 == 0 && cpg >= 32 && (long)HW * (cpg / 4) <= 256 * GNS_MAX && (long)B * G >= 128;
+  return cpg % 4 == 0 && cpg >= 32 && (long)HW * (cpg / 4) <= GNS_T * GNS_MAX && (long)B * G >= 128;
 }
 
 extern "C" size_t pfd_groupnorm_ws_bytes(int32_t B, int32_t C, int32_t HW) {
@@ -721,7 +735,7 @@ extern "C" int pfd_groupnorm_f16(const void* x1, int32_t C1, int64_t ldx1, const
     // (round 5: a form with incremental indices and gamma / beta in LDS -- 5419 -> 3172 instructions -- measured -0.04 %
     //  per batch, profiles/r05_e2e_ab_candidates.log: not kept; the fused split-K reduction + GroupNorm of gemm_glds.hip
     //  takes most of these launches instead)
-    hipLaunchKernelGGL(gn_small_kernel, dim3(G, B), dim3(256), 0, s, src, (const half_t*)gamma, (const half_t*)beta,
+    hipLaunchKernelGGL(gn_small_kernel, dim3(G, B), dim3(GNS_T), 0, s, src, (const half_t*)gamma, (const half_t*)beta,
                        (half_t*)y, (long)ldy, HW, G, act, eps);
     if (prof) pfd_prof_end(s);
     return pfd_check_launch("pfd_groupnorm_f16(small)");

@@ -1569,7 +1569,7 @@ int main(int argc, char** argv) {
     printf("SELFTEST %d/%d passed, %d failed\n", g_total - g_fail, g_total, g_fail);
     return g_fail;
   }
-  if (argc > 1 && !strcmp(argv[1], "--r5")) {   // round 5: what was adopted, and the candidates still waiting for their A/B
+  if (argc > 1 && !strcmp(argv[1], "--r5")) {   // round 5: the kernels adopted this round
     // adopted: the split-K reduction that also normalises (PfdGemmDesc.gnf_y) at the shapes the UNet / ControlNet give it
     run_gnf_case(8, 16, 16, 1280, 1280, PFD_ACT_SILU, 1e-5f, false, true, false);       // ResBlock conv1 @16^2 (patch kernel, split 4)
     run_gnf_case(8, 8, 8, 1280, 1280, PFD_ACT_SILU, 1e-5f, false, true, false);         // @8^2 (ring kernel, split 4)
@@ -1578,41 +1578,10 @@ int main(int argc, char** argv) {
     run_gnf_case(8, 16, 16, 1280, 1280, PFD_ACT_NONE, 1e-6f, true, false, true);        // + residual, raw kept, no activation
     run_gnf_case(4, 8, 8, 1280, 1280, PFD_ACT_SILU, 1e-5f, true, true, true);           // UNet batch 4
     run_gnf_case(8, 16, 16, 1280, 1280, PFD_ACT_SILU, 1e-5f, false, true, false, 10802);   // forced patch kernel, split 2
+    run_gnf_case(8, 8, 8, 1280, 1280, PFD_ACT_SILU, 1e-5f, false, true, false, 3308);        // forced 4-stage ring, split 8
     run_gnf_decline_case(8, 64, 64, 320, 320);                                          // 64^2: not split, cpg 10
     run_gnf_decline_case(8, 32, 32, 640, 640);                                          // cpg 20: the fused form is not built for it
-    // 8 x 8 images on the loader-wave patch kernels (tiles of four whole samples)
-    run_gemm_case({0, 320, 0, 0, true, true, true, false, 0, 0, 3, 1, 1, 0, 8, 8, 8, 320});                  // automatic choice, split over channel blocks
-    run_gemm_case({0, 1280, 0, 0, true, true, true, false, 0, 0, 3, 1, 1, 0, 8, 8, 8, 1280});                // the 8^2 ResBlock convolution
-    run_gemm_case({0, 160, 0, PFD_ACT_SILU, true, false, true, false, 10800, 0, 3, 1, 1, 0, 4, 8, 8, 128}); // 2-stage form, one tile
-    run_gemm_case({0, 320, 0, 0, true, true, false, false, 10603, 0, 3, 1, 1, 0, 12, 8, 8, 448});            // 3 tiles, uneven split (3, 2, 2)
-    { GemmCase c{0, 320, 0, 0, true, true, true, false, 0, 0, 3, 1, 1, 0, 8, 8, 8, 256}; c.gn_out = 1; run_gemm_case(c); }
-    run_gnf_case(8, 8, 8, 1280, 1280, PFD_ACT_SILU, 1e-5f, false, true, false, 10604);   // fused GroupNorm behind the 8 x 8 patch tiles
-    // candidates (forced only until their end-to-end A/B, PFD_R5X): 64-row tiles on a 5-stage operand ring (26 / 46)
-    for (int v : {3600, 5600}) {
-      run_gemm_case({300, 320, 64, 0, true, true, false, false, v});                                        // ONE K step (ring deeper than the loop)
-      run_gemm_case({300, 320, 192, PFD_ACT_SILU, true, true, true, false, v});                             // three K steps
-      run_gemm_case({1100, 320, 1024, 0, true, true, true, false, v});
-      run_gemm_case({2048, 1280, 1280, 0, true, false, true, false, v});                                    // the 16^2 out-projection class
-      run_gemm_case({512, 1280, 1280, PFD_ACT_GELU, true, true, false, false, v + 2});                      // split-K 2
-      run_gemm_case({0, 320, 0, 0, true, true, true, false, v, 0, 3, 1, 1, 0, 2, 16, 16, 128});               // 3x3 s1 as implicit GEMM
-      run_gemm_case({0, 160, 0, 0, true, false, false, false, v, 0, 3, 2, 1, 0, 2, 16, 16, 128});             // stride 2
-      run_gemm_case({0, 1280, 0, 0, true, true, true, false, v + 4, 0, 3, 1, 1, 0, 8, 8, 8, 1280});           // the 8^2 conv class, split-K 4
-      { GemmCase c{700, 320, 1024, 0, true, true, true, false, v}; c.k_split = 384; run_gemm_case(c); }
-      { GemmCase c{1100, 320, 512, 0, true, true, false, false, v}; c.zero_rows = 512; run_gemm_case(c); }
-      { GemmCase c{768, 320, 512, 0, true, true, true, false, v}; c.gn_out = 1; run_gemm_case(c); }
-    }
-    // forced variant 95: the patch kernel that hands over through LDS counters instead of a barrier per tap
-    {
-      const int v = 10500;
-      run_gemm_case({0, 320, 0, 0, true, true, true, false, v, 0, 3, 1, 1, 0, 2, 16, 16, 320});               // 16^2, 5 channel blocks
-      run_gemm_case({0, 160, 0, PFD_ACT_SILU, true, true, true, false, v, 0, 3, 1, 1, 0, 1, 32, 32, 128});    // 32^2, 2 blocks
-      run_gemm_case({0, 320, 0, 0, true, false, true, false, v, 0, 3, 1, 1, 0, 1, 64, 64, 64});               // 64^2, ONE block (no successor)
-      run_gemm_case({0, 160, 0, 0, true, true, true, false, v + 2, 0, 3, 1, 1, 0, 1, 16, 16, 256});           // split over channel blocks
-      { GemmCase c{0, 320, 0, 0, true, true, true, false, v, 0, 3, 1, 1, 0, 2, 16, 16, 128}; c.gn_out = 1; run_gemm_case(c); }
-      run_conv_same_case(8, 64, 64, 320, 320, 10800, 10500, true);
-      run_conv_same_case(8, 32, 32, 640, 640, 10800, 10500, true);
-    }
-    // the statistics-emitting split-K reduction (three row sweeps in flight) and the GroupNorm apply from producer statistics
+    // the statistics-emitting split-K reduction (1024 threads per slab) and the GroupNorm apply from producer statistics
     { GemmCase c{512, 1280, 2048, 0, true, true, true, false, 3304}; c.gn_out = 1; run_gemm_case(c); }                          // split-K 4, cpg 40
     { GemmCase c{0, 320, 0, 0, true, true, true, false, 9302, 0, 3, 1, 1, 0, 2, 16, 16, 128}; c.gn_out = 1; run_gemm_case(c); }   // conv, split-K 2
     run_gn_case(8, 64, 1280, 0, 32, PFD_ACT_SILU, 1e-5f);

@@ -129,7 +129,7 @@ class ResBlock(TimestepBlock):
     # 6.58 vs 6.68 images/s), so it is off unless PFD_GN_PROLOGUE=1 (tests switch it per call).
     fuse_groupnorm = os.environ.get("PFD_GN_PROLOGUE", "0") == "1"
     # GroupNorm 2 (+ SiLU) inside the split-K reduction of the first convolution (PfdGemmDesc.gnf_y; tests switch it per call)
-    fuse_reduce_groupnorm = os.environ.get("PFD_GNF", "1") != "0"     # (PFD_GNF=0: A/B runs)
+    fuse_reduce_groupnorm = True
 
     def __init__(self, channels, emb_channels, dropout, out_channels=None, use_conv=False,
                  use_scale_shift_norm=False, dims=2, use_checkpoint=False, up=False, down=False):

@@ -2,10 +2,8 @@
 for the HOST against a shim of the HIP runtime -- one OS thread per GPU thread of a block, MFMA / shuffles / ballot as
 rendezvous of a wave's 64 threads, LDS as block-shared statics, real barriers -- and the library's own dispatcher
 (pfd_gemm160_try, forced variants, split-K) runs small problems through it.  Checked against a double-precision reference,
-and forced-only candidates (5-stage rings 26 / 46, the patch kernel that hands over through LDS progress words, 95) bit for
-bit against the kernels they would replace (23 / 43 / 98); the split-K reduction with the fused GroupNorm (round 5) against
-the plain reduction + a double-precision GroupNorm.  What the model cannot see: s_waitcnt counts (tests/test_ring_protocol.py and
-tests/test_isa_audit.py cover those), register allocation, timing."""
+and the split-K reduction with the fused GroupNorm (round 5) against the plain reduction + a double-precision GroupNorm.
+What the model cannot see: s_waitcnt counts (tests/test_isa_audit.py covers the compiler's), register allocation, timing."""
 import os
 import subprocess
 import sys
@@ -48,13 +46,8 @@ def test_emulation_reproduces_the_hardware_validated_kernels(emu):
     assert sum("== variant 98 bitwise" in l for l in lines) == 2      # 3-stage ring and 8-wave forms of the patch kernel
 
 
-def test_five_stage_rings_match_the_four_stage_rings_bit_for_bit(emu):
-    lines = _run(emu, "variant 26", "variant 46")
-    assert len(lines) == 2 and all("bitwise" in l for l in lines), "\n".join(lines)
-
-
 def test_statistics_emitting_splitk_reduce(emu):
-    """split-K reduction that also emits the GroupNorm statistics of what it stores (three row sweeps of loads in flight):
+    """split-K reduction that also emits the GroupNorm statistics of what it stores (1024 threads per slab):
     statistics == sums of the stored f16 values"""
     lines = _run(emu, "statistics")
     assert len(lines) == 2 and all("statistics err" in l for l in lines), "\n".join(lines)
@@ -67,11 +60,6 @@ def test_splitk_reduce_with_fused_groupnorm(emu):
     same request on the unsplit problem declined with nothing written"""
     lines = _run(emu, "fused GroupNorm")
     assert len(lines) == 3 and all("unsplit request declined, nothing written" in l for l in lines), "\n".join(lines)
-
-
-def test_flag_handover_patch_kernel_matches_the_barrier_form(emu):
-    lines = _run(emu, "variant 95")
-    assert len(lines) == 2 and all("== variant 98 bitwise" in l for l in lines)
 
 
 def test_attention_kernels_on_the_emulation(emu):

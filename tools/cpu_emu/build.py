@@ -20,10 +20,8 @@ SUBST = [
     (r'asm volatile\("" : "\+v"\(([^;]*?)\)\);', '((void)0);'),
     (r'asm volatile\("" : "\+v"\(r\), "\+v"\(ch\)\);', '((void)0);'),
     (r'asm volatile\("" : "\+s"\(k\)::"memory"\);', '((void)0);'),
-    (r'(?s)asm volatile\("" ::"s"\(p\.tiles_m\).*?\);', '((void)0);'),   # the argument-load batch of gemm160ar_kernel
-    # the uncounted activation load of gemm160ar_kernel
-    (r'asm volatile\("global_load_dwordx4 %0, %1, off" : "=v"\(d\) : "v"\(\(const __attribute__\(\(address_space\(1\)\)\) void\*\)src\) : "memory"\);',
-     'memcpy(&d, src, 16);'),
+    (r'(?s)asm volatile\("" ::"s"\(p\.tiles_m\).*?\);', '((void)0);'),   # the argument-load batch at kernel entry (PFD_ARG_BATCH_*)
+    (r'asm volatile\("" ::"v"\(t\)\);', '((void)0);'),
     # the opaque 16-byte LDS store of the GroupNorm prologue
     (r'asm volatile\("ds_write_b128 %0, %1" ::"v"\(addr\), "v"\(d\) : "memory"\);', 'memcpy(lds_dst, &d, 16); (void)addr;'),
 ]

@@ -2,7 +2,7 @@
 // in this directory for the execution model).  tools/cpu_emu/build.py writes gemm_glds_emu.inc -- the kernel file with its
 // gfx950 inline-asm statements replaced by their C meaning -- and compiles this file for the host.  The same host dispatcher
 // (pfd_gemm160_try: tile choice, split-K, forced variants) and the same device code (index arithmetic, LDS images and
-// swizzles, ring slots, barriers, the flag hand-over of variant 95, epilogues) then run on CPU threads, and the result is
+// swizzles, ring slots, barriers, epilogues, the split-K reductions) then run on CPU threads, and the result is
 // compared with a double-precision reference.  What it cannot see: s_waitcnt counts (a copy lands when it is issued),
 // register allocation, timing.
 //   usage: emu_gemm [case ...]      no argument = the built-in list; exit code = number of failed cases
@@ -226,9 +226,6 @@ int main(int argc, char** argv) {
   // the hardware-validated LDS-ring kernels (sanity of the emulation itself)
   lin("variant 23 (64x160, 4-stage LDS ring) 200x160x512", 200, 160, 512, 23, 1, true, -1);
   lin("variant 83 (128x160, 8 waves, 3-stage LDS ring) 200x160x320", 200, 160, 320, 83, 1, false, -1);
-  // 5-stage LDS rings (forced variants 26 / 46)
-  lin("variant 26 (64x160, 5-stage LDS ring) eleven steps", 200, 320, 704, 26, 1, true, 23);
-  lin("variant 46 (64x160 on 8 waves, 5-stage LDS ring) nine steps", 130, 160, 576, 46, 1, true, 43);
   // split-K reduction that also emits the GroupNorm statistics (three row sweeps in flight)
   { auto c = lin("split-K 4 + GroupNorm statistics (N 320: cpg 10), residual", 128, 320, 1024, 23, 4, true, -1); c->gn_stats = true; }
   { auto c = conv("split-K 2 conv 8x8x128 -> 1280 + statistics (cpg 40), SiLU-free", 1280, 83, 2, 3, 1, 1, 0, 2, 8, 8, 128, true, -1); c->gn_stats = true; }
@@ -241,14 +238,7 @@ int main(int argc, char** argv) {
   conv("variant 96 patch conv 16x16 (3-stage weight ring), 2 channel blocks", 160, 96, 1, 3, 1, 1, 0, 1, 16, 16, 128, true, 98);
   { auto c = conv("variant 96 patch conv 16x16, K-tile-contiguous weights, two column tiles", 320, 96, 1, 3, 1, 1, 0, 1, 16, 16, 128, true, -1); c->w_tiled = true; }
   { auto c = conv("variant 83 implicit-GEMM conv, K-tile-contiguous weights, two column tiles", 320, 83, 1, 3, 1, 1, 0, 1, 8, 8, 128, false, -1); c->w_tiled = true; }
-  // 8 x 8 images: tiles of four whole samples on the loader-wave patch kernels (round 5)
-  conv("variant 96 patch conv 8x8, four samples per tile, 2 channel blocks", 160, 96, 1, 3, 1, 1, 0, 4, 8, 8, 128, true, -1);
-  { auto c = conv("variant 98 patch conv 8x8, two tiles, split over 3 channel blocks, row vector", 160, 98, 3, 3, 1, 1, 0, 8, 8, 8, 192, false, -1); c->rowvec = true; }
-  { auto c = conv("variant 96 patch conv 8x8 + GroupNorm statistics, two column tiles", 320, 96, 1, 3, 1, 1, 0, 4, 8, 8, 64, true, -1); c->gn_stats = true; }
   conv("variant 99 patch conv 16x16 (8-wave form), 2 channel blocks", 160, 99, 1, 3, 1, 1, 0, 1, 16, 16, 128, true, 98);
-  // the patch kernel that hands over through LDS progress words (95) against the barrier form (98)
-  conv("variant 95 patch conv 16x16, 2 channel blocks", 160, 95, 1, 3, 1, 1, 0, 1, 16, 16, 128, true, 98);
-  conv("variant 95 patch conv 16x16, one block (no successor), two samples", 160, 95, 1, 3, 1, 1, 0, 2, 16, 16, 64, false, 98);
   int fails = 0, n = 0;
   for (const auto& c : cases) {
     if (argc > 1) {
