@@ -195,6 +195,14 @@ typedef struct PfdGemmDesc {
   int32_t gnf_act;
   int32_t gnf_rows;      /* rows per sample (Ho * Wo of a convolution) */
   int32_t gnf_skip_raw;
+  /* Residual stored ONCE for a doubled batch (ABI 9).  The classifier-free-guidance batch is [x | x] with one timestep
+   * (ddim.py:145-149 `torch.cat([x] * 2)`), so everything in front of the first cross-attention is identical for the two
+   * halves and is computed once (lib/model_zoo/attention.py, cfg_pair); the launches that re-join the halves -- the
+   * cross-attention out-projection `attn2(...) + x` and `proj_out(...) + x_in` of the first SpatialTransformer
+   * (attention.py:303-305, 370) -- then add a residual that exists as ONE copy: with 0 < res_rows < M output row m adds
+   * R[m - res_rows] for m >= res_rows (M / 2 <= res_rows: at most one wrap).  0 (or M) = one residual row per output row.
+   * Wide-tile kernels only (PFD_ESHAPE otherwise); not together with gnf_y. */
+  int32_t res_rows;
 } PfdGemmDesc;
 int pfd_gemm_f16(const PfdGemmDesc* d, pfd_stream_t stream);
 /* Same, with the kernel variant forced (tests and tuning only); 0 = the library's heuristic.

@@ -694,6 +694,8 @@ int launch(const AttnParams& p, hipStream_t s) {
   // 8-wave blocks pay when a block has many queries to amortise the staging over and the grid still fills the chip twice
   const bool big = p.Nq >= 1024 && (long)p.B * p.H * ((p.Nq + 255) / 256) >= 512;
   const bool w8 = D == 40 && (big || attn_force8());
+  // (round 5: 64-query blocks of two waves for the grids that fill less than the chip -- d = 160 at 16^2 / 8^2 -- measured
+  //  the same or slightly slower, profiles/r05_e2e_ab_candidates.log)
   const int qb = w8 ? 256 : 128;
   dim3 grid(((p.Nq + qb - 1) / qb) * p.H * p.B);
   if constexpr (D == 40) {

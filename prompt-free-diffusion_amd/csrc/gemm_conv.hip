@@ -346,6 +346,10 @@ extern "C" int pfd_gemm_f16_ex(const PfdGemmDesc* d, int32_t tile, pfd_stream_t 
     pfd_set_error("pfd_gemm_f16: GroupNorm statistics of the output are emitted by the wide-tile kernels only (see PfdGemmDesc.gn_out)");
     return PFD_ESHAPE;
   }
+  if (d->res_rows > 0 && d->res_rows != d->M) {
+    pfd_set_error("pfd_gemm_f16: a residual stored once for a doubled batch is read by the wide-tile kernels only (see PfdGemmDesc.res_rows)");
+    return PFD_ESHAPE;
+  }
   if (d->gnf_y) {
     pfd_set_error("pfd_gemm_f16: the fused GroupNorm lives in the split-K reduction of the wide-tile kernels only (see PfdGemmDesc.gnf_y)");
     return PFD_ESHAPE;

@@ -86,7 +86,14 @@ struct G160Params {
   float2* gn_out;          // GroupNorm statistics of the OUTPUT, per 64-row slab and group (PfdGemmDesc.gn_out); nullptr = none
   int k_split;             // linear kernels: K tiles at k >= k_split come from A2 (== K when there is no second source)
   int zero_rows;           // linear kernels: operand rows below this are all zero and are never read (PfdGemmDesc.zero_rows)
+  int r_wrap;              // residual rows (PfdGemmDesc.res_rows): output row m adds R[m >= r_wrap ? m - r_wrap : m]; INT_MAX = no wrap
 };
+
+// residual row of output row m (clamped to the problem): the residual of a CFG pair [x | x] is stored once (res_rows)
+__device__ __forceinline__ long res_row(const G160Params& p, int m) {
+  const int mc = min(m, p.M - 1);
+  return mc >= p.r_wrap ? mc - p.r_wrap : mc;
+}
 
 __device__ __forceinline__ void glds16(const void* src, void* lds_dst) {
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
@@ -469,6 +476,7 @@ __device__ __forceinline__ void epilogue_store_gn(const G160Params& p, int m0, i
   constexpr int NSLAB = BM / GN_SLAB, W = NTHREADS / 64, WPS = W / NSLAB, SWEEP = 3 * WPS;
   constexpr int ITERS = (GN_SLAB + SWEEP - 1) / SWEEP;
   // residual chunks in flight together (the 12-wave kernels sit at their 168-register limit: two)
+  // (round 5: 4 / 8 chunks in flight in the 12-wave kernels compile without scratch and measure the same, profiles/r05_epilogue_depth_ab.log)
   constexpr int UB = NTHREADS >= 768 ? 2 : (ITERS < 4 ? ITERS : 4);
   static_assert(BM % GN_SLAB == 0 && W % NSLAB == 0 && (WPS + 1) * 1280 <= GN_SLAB * RS, "a slab's image region holds its scratch");
   const int lane = tid & 63, w = tid >> 6;
@@ -487,7 +495,7 @@ __device__ __forceinline__ void epilogue_store_gn(const G160Params& p, int m0, i
 #pragma unroll
       for (int u = 0; u < UB; ++u) {
         const int row = min(row0 + (it0 + u) * SWEEP, (s + 1) * GN_SLAB - 1);
-        r[u].u = gld<uint4>(p.R + (long)min(tile_row_m<PT>(p, m0, row), p.M - 1) * p.ldr + n0 + cc * 8);
+        r[u].u = gld<uint4>(p.R + res_row(p, tile_row_m<PT>(p, m0, row)) * p.ldr + n0 + cc * 8);
       }
     }
 #pragma unroll
@@ -552,7 +560,7 @@ __device__ __forceinline__ void epilogue_store(const G160Params& p, int m0, int 
         if (has_r) {
 #pragma unroll
           for (int j = 0; j < CPL; ++j)
-            r[j].u = gld<uint4>(p.R + (long)min(m0 + rowc, p.M - 1) * p.ldr + n0 + (k + 4 * j) * 8);
+            r[j].u = gld<uint4>(p.R + res_row(p, m0 + rowc) * p.ldr + n0 + (k + 4 * j) * 8);
         }
         float sum = 0.f, sq = 0.f;
 #pragma unroll
@@ -595,7 +603,7 @@ __device__ __forceinline__ void epilogue_store(const G160Params& p, int m0, int 
         for (int u = 0; u < U; ++u) {
           const int c = min(tid + (it0 + u) * NTHREADS, TOTAL - 1);
           const int row = c / CPR, cc = c - row * CPR;
-          r[u].u = gld<uint4>(p.R + (long)min(tile_row_m<PT>(p, m0, row), p.M - 1) * p.ldr + nc0 + cc * 8);
+          r[u].u = gld<uint4>(p.R + res_row(p, tile_row_m<PT>(p, m0, row)) * p.ldr + nc0 + cc * 8);
         }
       }
 #pragma unroll
@@ -905,19 +913,11 @@ __global__ __launch_bounds__(WAVES_M * 128) void gemm160_kernel(const G160Params
 // step for all 12 waves: loaders arrive after vmcnt(0) (their pieces of tile kt landed), consumers after the
 // MFMAs of tile kt - 1; then loaders refill the buffer the consumers just left.
 // ------------------------------------------------------------------------------------------------
-// PP ("ping-pong") = the two halves of the consumer waves run one barrier interval apart.  Lock-step consumers all
-// wait for their first fragments at the same moment after every barrier (the MFMA pipes idle for the ds_read latency,
-// ~250 of ~1600 cycles per K step) and then contend for the pipe.  With PP a K step is four barrier intervals; group 0
-// (waves 0-3, one per SIMD) reads the fragments of one 32-deep half step while group 1 (waves 4-7, the other wave of
-// each SIMD) issues the 20 MFMAs of its previous half step, and vice versa -- a SIMD always has exactly one wave in
-// an MFMA segment and the partner's LDS reads are hidden under it (guide 5.5 T3/T5: role split + s_setprio).
-//   interval:   4s        4s+1      4s+2      4s+3      4s+4
-//   group 0:    L(s,0)    M(s,0)    L(s,1)    M(s,1)    L(s+1,0)
-//   group 1:    M(s-1,1)  L(s,0)    M(s,0)    L(s,1)    M(s,1)
-//   loaders:    issue tile s+1 (its buffer was last read in interval 4s-1), then wait for it before barrier 4s+4
+// (Ping-pong consumer groups -- the two halves of the consumer waves one barrier interval apart, four intervals per K
+//  step -- measured no better than lock-step consumers in round 3, profiles/r03_krot_pp_replay.log, and were removed in round 5.)
 // NST: operand stages.  2 = one K tile ahead (loaders wait vmcnt(0) per K step); 3 = two K tiles ahead with a counted
 // vmcnt (round 4; 156 KiB of LDS at the 160-wide tile), lock-step consumers only.
-template <bool CONV, int NT, bool PP, int NST = 2>
+template <bool CONV, int NT, int NST = 2>
 __global__ __launch_bounds__(768) void gemm160ws_kernel(const G160Params p) {
   constexpr int WMB = 4, NCW = 8, NLW = 4;
   constexpr int BN = 32 * NT, BM = 256;
@@ -926,7 +926,7 @@ __global__ __launch_bounds__(768) void gemm160ws_kernel(const G160Params p) {
   static_assert(A_INSTR % NLW == 0 && B_INSTR % NLW == 0, "pieces must split evenly over the loader waves");
   constexpr int STAGE = (BM + BN) * ROWB;
   constexpr int SMEM = NST * STAGE;
-  static_assert(NST == 2 || (NST == 3 && !PP), "the 3-stage ring serves the lock-step consumers");
+  static_assert(NST == 2 || NST == 3, "operand stages");
   static_assert(SMEM <= 160 * 1024, "LDS");
   static_assert(BM * stage_row_bytes(BN) <= SMEM, "the epilogue's staging image reuses the operand ring");
   __shared__ __attribute__((aligned(1024))) char smem[SMEM];
@@ -1067,11 +1067,6 @@ __global__ __launch_bounds__(768) void gemm160ws_kernel(const G160Params p) {
       __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): this wave's pieces of K tile s are in LDS
       block_barrier();                      // (A) tile s complete; every consumer is done reading tile s - 1
       if (s + 1 < nsteps) issue((s + 1) & 1);
-      if constexpr (PP) {
-        block_barrier();
-        block_barrier();
-        block_barrier();
-      }
     }
     }
     block_barrier();                        // (B) consumers finished reading the last tile: LDS is free
@@ -1090,44 +1085,7 @@ __global__ __launch_bounds__(768) void gemm160ws_kernel(const G160Params p) {
     const int off_k1 = ((4 + g) ^ sw) * 16 + l15 * ROWB;
     const int a_row0 = wm * WMB * 16 * ROWB;
     const int b_row0 = BM * ROWB + wn * (16 * NT) * ROWB;
-    if constexpr (PP) {
-      half8_t af[WMB], bf[NT];
-      auto rd = [&](int s, int ks) __attribute__((always_inline)) {   // L segment: the 9 (8) fragments of one half step
-        const char* base = smem + (s & 1) * STAGE;
-        const int off = ks ? off_k1 : off_k0;
-#pragma unroll
-        for (int i = 0; i < WMB; ++i)
-          af[i] = *reinterpret_cast<const half8_t*>(base + a_row0 + i * 16 * ROWB + off);
-#pragma unroll
-        for (int j = 0; j < NT; ++j)
-          bf[j] = *reinterpret_cast<const half8_t*>(base + b_row0 + j * 16 * ROWB + off);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the stage may be refilled two barriers from here
-      };
-      auto mm = [&]() __attribute__((always_inline)) {               // M segment
-        __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-        for (int i = 0; i < WMB; ++i)
-#pragma unroll
-          for (int j = 0; j < NT; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[j], af[i], acc[i][j], 0, 0, 0);
-        __builtin_amdgcn_s_setprio(0);
-      };
-      // Both groups run the SAME sequence (barrier, L0, barrier, M0, barrier, L1, barrier, M1) per K step; group 1 passes
-      // one extra barrier first and group 0 one extra barrier last, which puts group 1 exactly one interval behind.
-      const bool g1 = wave >= NCW / 2;        // wave-uniform
-      if (g1) block_barrier();                // 4s (A) of step 0
-      for (int s = 0; s < nsteps; ++s) {
-        block_barrier();                      // group 0: 4s (A)        group 1: 4s + 1
-        rd(s, 0);
-        block_barrier();
-        mm();
-        block_barrier();
-        rd(s, 1);
-        block_barrier();                      // group 0: 4s + 3        group 1: 4(s + 1) (A), or (B) after the last step
-        mm();
-      }
-      if (!g1) block_barrier();               // (B)
-    } else {
+    {
       int cst = 0;
       for (int s = 0; s < nsteps; ++s) {
         block_barrier();                      // (A)
@@ -1330,18 +1288,17 @@ __global__ __launch_bounds__(512) void conv3x3_patch_kernel(const G160Params p) 
 // 12 waves) and epilogue; the consumers' instruction stream is ds_read + MFMA only.
 // ------------------------------------------------------------------------------------------------
 // GN: 0 = plain input, 1 = GroupNorm affine map in the staging path, 2 = affine map + SiLU
-// PP: ping-pong consumer groups, four barrier intervals per tap (see gemm160ws_kernel)
 // NWS: weight stages.  2 = one tap ahead, loaders wait vmcnt(0) per tap (a tap's 20 KB weight tile has one tap of MFMA
 //      work, ~0.55 us, to arrive -- less than the loaded LDS-DMA round trip, so every tap ends in a wait);
 //      3 = two taps ahead with counted vmcnt (round 4): the whole 160 KiB of LDS (2 patches + 3 weight tiles).
-template <int GN, bool PP, int NWS = 2>
+template <int GN, int NWS = 2>
 __global__ __launch_bounds__(768) void conv3x3_patch_ws_kernel(const G160Params p) {
   constexpr int NCW = 8, NLW = 4, WMB = 4;
   constexpr int PATCH_BYTES = PATCH_ROWS * ROWB;  // 51200
   constexpr int WT_BYTES = BN * ROWB;             // 20480
   constexpr int OFF_W = 2 * PATCH_BYTES;
   constexpr int SMEM = OFF_W + NWS * WT_BYTES;    // 143360 | 163840
-  static_assert(NWS == 2 || (NWS == 3 && GN == 0 && !PP), "the 3-stage weight ring serves the plain lock-step form");
+  static_assert(NWS == 2 || (NWS == 3 && GN == 0), "the 3-stage weight ring serves the plain form");
   static_assert(SMEM <= 160 * 1024, "LDS");
   constexpr int P_INSTR = PATCH_ROWS / 8;          // 50 DMA pieces per patch
   __shared__ __attribute__((aligned(1024))) char smem[SMEM];
@@ -1385,13 +1342,6 @@ __global__ __launch_bounds__(768) void conv3x3_patch_ws_kernel(const G160Params 
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
-  };
-  auto pp_barriers = [&]() {   // the three extra barriers of a ping-pong step (loader side)
-    if constexpr (PP) {
-      block_barrier();
-      block_barrier();
-      block_barrier();
-    }
   };
 
   if (wave >= NCW) {
@@ -1538,7 +1488,6 @@ __global__ __launch_bounds__(768) void conv3x3_patch_ws_kernel(const G160Params 
             rb = nb;
           }
           stage ^= 1;
-          pp_barriers();
         }
       }
     } else if constexpr (NWS == 3) {
@@ -1614,7 +1563,6 @@ __global__ __launch_bounds__(768) void conv3x3_patch_ws_kernel(const G160Params 
             if (lw < 2 && 6 * tap + 4 + lw < P_INSTR) issue_patch(pbuf ^ 1, cb1, 6 * tap + 4 + lw, off_b[tap]);
           }
           stage ^= 1;
-          pp_barriers();
         }
       }
     }
@@ -1643,53 +1591,7 @@ __global__ __launch_bounds__(768) void conv3x3_patch_ws_kernel(const G160Params 
       const int r = rbase[i] + toff;
       return r * ROWB + ((((ks * 4 + g) + (r & ~1)) & 7) << 4);
     };
-    if constexpr (PP) {
-      half8_t af[WMB], bf[5];
-      auto rd = [&](const char* patch, const char* wt, int toff, int ks) __attribute__((always_inline)) {
-#pragma unroll
-        for (int i = 0; i < WMB; ++i) af[i] = *reinterpret_cast<const half8_t*>(patch + a_off(i, toff, ks));
-        const int bo = ks ? boff1 : boff0;
-#pragma unroll
-        for (int j = 0; j < 5; ++j) bf[j] = *reinterpret_cast<const half8_t*>(wt + bo + j * 16 * ROWB);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the weight stage is refilled two barriers from here
-      };
-      auto mm = [&]() __attribute__((always_inline)) {
-        __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-        for (int i = 0; i < WMB; ++i)
-#pragma unroll
-          for (int j = 0; j < 5; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[j], af[i], acc[i][j], 0, 0, 0);
-        __builtin_amdgcn_s_setprio(0);
-      };
-      // same sequence for both groups; group 1 passes one extra barrier first, group 0 one extra barrier last
-      const bool g1 = wave >= NCW / 2;          // wave-uniform
-      if (g1) block_barrier();
-      int stage = 0;
-      for (int ci = 0; ci < ncbs; ++ci) {
-        const char* patch = smem + (ci & 1) * PATCH_BYTES;
-        int toff = 0;
-#pragma nounroll
-        for (int ky = 0; ky < 3; ++ky) {
-#pragma nounroll
-          for (int kx = 0; kx < 3; ++kx) {
-            const char* wt = smem + OFF_W + stage * WT_BYTES;
-            block_barrier();                    // group 0: (A) of this tap; group 1: one interval later
-            rd(patch, wt, toff, 0);
-            block_barrier();
-            mm();
-            block_barrier();
-            rd(patch, wt, toff, 1);
-            block_barrier();
-            mm();
-            stage ^= 1;
-            toff += 1;
-          }
-          toff += PW - 3;
-        }
-      }
-      if (!g1) block_barrier();                 // (B)
-    } else {
+    {
       int stage = 0;
       for (int ci = 0; ci < ncbs; ++ci) {
         const char* patch = smem + (ci & 1) * PATCH_BYTES;
@@ -1750,7 +1652,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const G160Params p) 
     Pack16 bb, rv, rr;
     bb.u = *reinterpret_cast<const uint4*>(p.bias ? p.bias + n : g_zero_page);
     rv.u = *reinterpret_cast<const uint4*>(p.rowvec ? p.rowvec + (long)(m / p.rows_per_rv) * p.ldrv + n : g_zero_page);
-    rr.u = *reinterpret_cast<const uint4*>(p.R ? p.R + (long)m * p.ldr + n : g_zero_page);
+    rr.u = *reinterpret_cast<const uint4*>(p.R ? p.R + res_row(p, m) * p.ldr + n : g_zero_page);
     float v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     for (int s0 = 0; s0 < p.splits; s0 += 4) {
       float4_t a[4], b[4];
@@ -1842,7 +1744,7 @@ __global__ __launch_bounds__(RGN_T) void splitk_reduce_gn_kernel(const G160Param
       m[u] = min(slab * GN_SLAB + min(row_u, GN_SLAB - 1), p.M - 1);
       ok[u] = active && row_u < GN_SLAB && slab * GN_SLAB + row_u < p.M;
       rv[u].u = *reinterpret_cast<const uint4*>(p.rowvec ? p.rowvec + (long)(m[u] / p.rows_per_rv) * p.ldrv + n : g_zero_page);
-      rr[u].u = *reinterpret_cast<const uint4*>(p.R ? p.R + (long)m[u] * p.ldr + n : g_zero_page);
+      rr[u].u = *reinterpret_cast<const uint4*>(p.R ? p.R + res_row(p, m[u]) * p.ldr + n : g_zero_page);
 #pragma unroll
       for (int e = 0; e < 8; ++e) v[u][e] = 0.f;
     }
@@ -2091,47 +1993,14 @@ inline void launch_splitk_reduce(const G160Params& p, hipStream_t s) {
   if (p.ln_out) pfd_ln_rowstats_launch(p.C, p.ldc, p.M, p.N, reinterpret_cast<float*>(p.ln_out), s, false);   // inside this launch's event pair
 }
 
-// Rotated K walk (k_rotation), measured on the cold replay of the sampler's launch list (profiles/r03_krot_pp_replay.log):
-// linears gain (2048 x 3840 x 1280: 35.2 -> 30.6 us, 2048 x 10240 x 1280 GEGLU 64.9 -> 61.7, 2048 x 1280 x 1280
-// 18.3 -> 17.1, 8192 x 640 x 640 17.1 -> 16.3) and so do the loader-wave implicit-GEMM convolutions (upsample convs
-// 191.9 -> 168.6, 176.0 -> 164.4 us); the split-K convolutions of the 8^2 level lose (512 x 1280 x 23040: 52 -> 66 us:
-// eight rotated streams per XCD instead of one) and the patch kernel is 2-3 % slower, so those keep the plain walk.
-// End to end the selection is worth nothing measurable (bench.py, same box: 559.0 ms per batch without, 559.2 / 560.8 with),
-// and a rotated walk makes a row's fp32 summation order depend on WHERE in the batch the row sits -- the zero-context
-// shortcut (same rows, half the batch) then stops being bit-identical to the full computation.  So the default is OFF;
-// PFD_KROT: 0 = never (default), 1 = the selection above, 2 = every kernel.
-inline int krot_mode() {
-  static const int m = getenv("PFD_KROT") ? atoi(getenv("PFD_KROT")) : 0;
-  return m;
-}
-// Ping-pong consumer groups (template flag PP of the loader-wave kernels) measured no better than lock-step consumers:
-// patch conv 32768 x 320 x 2880 53.4 -> 53.5 us, x 8640 125.0 -> 128.8; upsample conv 8192 x 1280 x 11520 191.9 -> 202.1
-// (profiles/r03_krot_pp_replay.log) -- the exposed fragment latency it hides is paid back in three more barriers per
-// K step.  Kept selectable for measurements: PFD_PP=1, or forced variants 49 (256-row tile) / 97 (patch kernel).
-inline bool pp_on() {
-  static const bool on = getenv("PFD_PP") && atoi(getenv("PFD_PP")) != 0;
-  return on;
-}
-
-// 3-stage weight ring of the wave-specialised patch kernel (round 4): PFD_PATCH_RING=0 keeps the 2-stage form
-inline bool patch_ring_on() {
-  static const bool on = !(getenv("PFD_PATCH_RING") && atoi(getenv("PFD_PATCH_RING")) == 0);
-  return on;
-}
-// (Also tried in round 4 and removed: requesting the next tap's A fragments before its barrier -- the patch is stable in
-//  LDS for all nine taps, so only the weight fragments have to sit behind the barrier.  No effect: 7.32 / 7.41 vs 7.42 / 7.38 ms
-//  per replayed pass, 507 vs 510 ms per batch; profiles/r04_patch_prefetch_ab.log.)
-// same for the loader-wave implicit-GEMM kernel (gemm160ws_kernel): PFD_WS_RING=0 keeps two stages
-inline bool ws_ring_on() {
-  static const bool on = !(getenv("PFD_WS_RING") && atoi(getenv("PFD_WS_RING")) == 0);
-  return on;
-}
-
-// PFD_R3TILES=0 keeps the round-2 tile choice (A/B runs of the round-3 rules in pfd_gemm160_try)
-inline bool r3tiles_on() {
-  static const bool on = !(getenv("PFD_R3TILES") && atoi(getenv("PFD_R3TILES")) == 0);
-  return on;
-}
+// History of the switches that used to live here (removed in round 5; their measurements are in profiles/ and DESIGN 3.5):
+//  * rotated K walk (k_rotation; PFD_KROT): gains on single linears of the cold replay, nothing end to end (559.0 vs 559.2 /
+//    560.8 ms per batch), and it makes a row's fp32 summation order depend on where in the batch the row sits -- the kernels
+//    keep the parameter at 0;
+//  * ping-pong consumer groups of the loader-wave kernels (template flag PP; PFD_PP, forced variants 49 / 97): no better than
+//    lock-step consumers (profiles/r03_krot_pp_replay.log) -- never instantiated any more;
+//  * PFD_PATCH_RING / PFD_WS_RING = 0 (two weight stages instead of three, -4.6 ms per batch for three), PFD_R3TILES = 0 (the
+//    round-2 tile rules), PFD_RING = 0 (no deep operand rings): A/B switches of decisions that have stood for two rounds.
 
 // 1 when streaming W once per XCD would cost more L2-miss traffic than streaming the activations once per XCD
 inline int pick_nmajor(const G160Params& p) {
@@ -2146,7 +2015,7 @@ int launch160(G160Params& p, int bucket, hipStream_t s) {
   p.tiles_m = (p.M + BM - 1) / BM;
   p.tiles_n = p.N / (32 * NT);
   p.nmajor = pick_nmajor(p);
-  p.krot = krot_mode() == 2 || (krot_mode() == 1 && p.ksize == 0);
+  p.krot = 0;
   const int nk = p.K / BK;
   p.kt_per_split = (nk + p.splits - 1) / p.splits;
   p.splits = (nk + p.kt_per_split - 1) / p.kt_per_split;
@@ -2167,12 +2036,12 @@ int launch160(G160Params& p, int bucket, hipStream_t s) {
 }
 
 template <int NT>
-// mode: 0 = two stages, 1 = ping-pong consumer groups, 2 = 3-stage ring
+// mode: 0 = two stages, 2 = 3-stage ring
 int launch160ws(G160Params& p, int bucket, hipStream_t s, int pp) {
   p.tiles_m = (p.M + 255) / 256;
   p.tiles_n = p.N / (32 * NT);
   p.nmajor = pick_nmajor(p);
-  p.krot = krot_mode() >= 1;
+  p.krot = 0;
   const int nk = p.K / BK;
   p.kt_per_split = (nk + p.splits - 1) / p.splits;
   p.splits = (nk + p.kt_per_split - 1) / p.kt_per_split;
@@ -2184,25 +2053,23 @@ int launch160ws(G160Params& p, int bucket, hipStream_t s, int pp) {
     pfd_prof_begin(bucket, 2.0 * p.M * p.N * p.K, a_bytes + 2.0 * p.N * p.K + 2.0 * p.M * n_out * (p.R ? 2 : 1), s);
   }
   if (p.ksize > 0) {
-    if (pp == 1) hipLaunchKernelGGL((gemm160ws_kernel<true, NT, true>), grid, dim3(768), 0, s, p);
-    else if (pp == 2) hipLaunchKernelGGL((gemm160ws_kernel<true, NT, false, 3>), grid, dim3(768), 0, s, p);
-    else hipLaunchKernelGGL((gemm160ws_kernel<true, NT, false>), grid, dim3(768), 0, s, p);
+    if (pp == 2) hipLaunchKernelGGL((gemm160ws_kernel<true, NT, 3>), grid, dim3(768), 0, s, p);
+    else hipLaunchKernelGGL((gemm160ws_kernel<true, NT>), grid, dim3(768), 0, s, p);
   } else {
-    if (pp == 1) hipLaunchKernelGGL((gemm160ws_kernel<false, NT, true>), grid, dim3(768), 0, s, p);
-    else if (pp == 2) hipLaunchKernelGGL((gemm160ws_kernel<false, NT, false, 3>), grid, dim3(768), 0, s, p);
-    else hipLaunchKernelGGL((gemm160ws_kernel<false, NT, false>), grid, dim3(768), 0, s, p);
+    if (pp == 2) hipLaunchKernelGGL((gemm160ws_kernel<false, NT, 3>), grid, dim3(768), 0, s, p);
+    else hipLaunchKernelGGL((gemm160ws_kernel<false, NT>), grid, dim3(768), 0, s, p);
   }
   if (p.splits > 1) launch_splitk_reduce(p, s);
   if (prof) pfd_prof_end(s);
   return pfd_check_launch("pfd_gemm_f16(wave-specialised)");
 }
 
-// ws: 0 = 8-wave kernel, 1 = + 4 loader waves, 2 = + ping-pong consumer groups, 3 = loader waves + 3-stage weight ring,
+// ws: 0 = 8-wave kernel, 1 = + 4 loader waves (two weight stages), 3 = loader waves + 3-stage weight ring (the default)
 int launch_patch(G160Params& p, hipStream_t s, int ws) {
   p.tiles_m = p.M / 256;
   p.tiles_n = p.N / BN;
   p.nmajor = pick_nmajor(p);
-  p.krot = krot_mode() == 2;
+  p.krot = 0;
   const int ncb = p.Cin / BK;
   p.kt_per_split = (ncb + p.splits - 1) / p.splits;   // channel blocks per split
   p.splits = (ncb + p.kt_per_split - 1) / p.kt_per_split;
@@ -2211,11 +2078,10 @@ int launch_patch(G160Params& p, hipStream_t s, int ws) {
   if (prof)
     pfd_prof_begin(19, 2.0 * p.M * p.N * p.K,
                    2.0 * p.B * p.H * p.Wd * p.Cin + 2.0 * p.N * p.K + 2.0 * p.M * p.N * (p.R ? 2 : 1), s);
-  if (p.gn_table && p.gn_act == PFD_ACT_SILU) hipLaunchKernelGGL((conv3x3_patch_ws_kernel<2, false>), grid, dim3(768), 0, s, p);
-  else if (p.gn_table) hipLaunchKernelGGL((conv3x3_patch_ws_kernel<1, false>), grid, dim3(768), 0, s, p);
-  else if (ws == 3) hipLaunchKernelGGL((conv3x3_patch_ws_kernel<0, false, 3>), grid, dim3(768), 0, s, p);
-  else if (ws == 2) hipLaunchKernelGGL((conv3x3_patch_ws_kernel<0, true>), grid, dim3(768), 0, s, p);
-  else if (ws) hipLaunchKernelGGL((conv3x3_patch_ws_kernel<0, false>), grid, dim3(768), 0, s, p);
+  if (p.gn_table && p.gn_act == PFD_ACT_SILU) hipLaunchKernelGGL((conv3x3_patch_ws_kernel<2>), grid, dim3(768), 0, s, p);
+  else if (p.gn_table) hipLaunchKernelGGL((conv3x3_patch_ws_kernel<1>), grid, dim3(768), 0, s, p);
+  else if (ws == 3) hipLaunchKernelGGL((conv3x3_patch_ws_kernel<0, 3>), grid, dim3(768), 0, s, p);
+  else if (ws) hipLaunchKernelGGL((conv3x3_patch_ws_kernel<0>), grid, dim3(768), 0, s, p);
   else hipLaunchKernelGGL(conv3x3_patch_kernel, grid, dim3(512), 0, s, p);
   if (p.splits > 1) launch_splitk_reduce(p, s);
   if (prof) pfd_prof_end(s);
@@ -2223,12 +2089,6 @@ int launch_patch(G160Params& p, hipStream_t s, int ws) {
 }
 
 }  // namespace
-
-// PFD_RING=0 in the environment keeps every problem on the 2-stage kernels (A/B runs)
-static bool ring_on() {
-  static const bool on = !(getenv("PFD_RING") && atoi(getenv("PFD_RING")) == 0);
-  return on;
-}
 
 // Called by pfd_gemm_f16_ex (gemm_conv.hip).  Returns 1 if the problem is not for this path.
 // variant: 0 = heuristic, 44 / 24 / 22 force <WAVES_M,WMB>; splits: 0 = heuristic.
@@ -2301,11 +2161,17 @@ int pfd_gemm160_try(const PfdGemmDesc* d, int variant, int splits, hipStream_t s
   };
   struct GnfDisarm { ~GnfDisarm() { t_gnf.y = nullptr; } } gnf_disarm;
   // two-source contraction / zero rows (ABI 8): the 8-wave / 4-wave linear kernels only
+  // residual stored once for a doubled batch (ABI 9): one wrap at most, whole rows; not with the fused GroupNorm reduction
+  p.r_wrap = 0x7fffffff;
+  if (d->res_rows > 0 && d->res_rows != d->M) {
+    if (!d->R || d->res_rows >= d->M || 2L * d->res_rows < d->M || d->gnf_y) return 1;
+    p.r_wrap = d->res_rows;
+  }
   p.k_split = d->K; p.zero_rows = 0;
   if (d->k_split > 0 || d->zero_rows > 0) {
     if (d->ksize > 0 || d->gn_table || d->bias_per_row || d->Ct) return 1;
     if (d->zero_rows < 0 || d->zero_rows >= d->M || (d->zero_rows > 0 && d->ln_stats)) return 1;
-    if (variant == 47 || variant == 48 || variant == 49 || variant == 84) return 1;
+    if (variant == 47 || variant == 48 || variant == 84) return 1;
     if (d->k_split > 0) {
       if (d->k_split >= d->K || (d->k_split % BK) || !d->A2 || (d->lda2 & 7) || (reinterpret_cast<uintptr_t>(d->A2) & 15)) return 1;
       p.k_split = d->k_split;
@@ -2316,11 +2182,11 @@ int pfd_gemm160_try(const PfdGemmDesc* d, int variant, int splits, hipStream_t s
   if (p.ln_in) {   // LayerNorm fold: plain linear, statistics over K = ln_parts slices of 160 columns
     if (d->ksize > 0 || !p.ln_cs || p.ln_P < 1 || p.ln_P > 8 || p.ln_P * 160 != d->K) return 1;
     if ((reinterpret_cast<uintptr_t>(p.ln_in) & 7) || (reinterpret_cast<uintptr_t>(p.ln_cs) & 15)) return 1;
-    if (variant == 47 || variant == 48 || variant == 49) return 1;   // the loader-wave kernels serve convolutions
+    if (variant == 47 || variant == 48) return 1;   // the loader-wave kernels serve convolutions
   }
   if (p.ln_out) {  // statistics of the output rows for the consumer's fold
     if (bn != 160 || d->ksize > 0 || d->act == PFD_ACT_GEGLU || d->Ct || (reinterpret_cast<uintptr_t>(p.ln_out) & 7)) return 1;
-    if (variant == 47 || variant == 48 || variant == 49) return 1;
+    if (variant == 47 || variant == 48) return 1;
   }
   if (p.gn_table) {   // GroupNorm prologue: patch kernel or nothing (validated here, PFD_ESHAPE by the caller otherwise)
     if (bn != 160 || (variant != 0 && variant != 98)) return 1;
@@ -2341,8 +2207,8 @@ int pfd_gemm160_try(const PfdGemmDesc* d, int variant, int splits, hipStream_t s
     if (p.Wd % 32 == 0 && p.H % 8 == 0) pt_w = 32;
     else if (p.Wd % 16 == 0 && p.H % 16 == 0) pt_w = 16;
   }
-  const bool patch_w = p.Wd == 16 || p.Wd == 32 || p.Wd == 64 || (pt_w != 0 && r3tiles_on());
-  if (bn == 160 && (variant == 0 || variant == 99 || variant == 98 || variant == 97 || variant == 96) && p.ksize == 3 && p.stride == 1 && p.pad == 1 && !p.ups &&
+  const bool patch_w = p.Wd == 16 || p.Wd == 32 || p.Wd == 64 || pt_w != 0;
+  if (bn == 160 && (variant == 0 || variant == 99 || variant == 98 || variant == 96) && p.ksize == 3 && p.stride == 1 && p.pad == 1 && !p.ups &&
       patch_w && p.Ho == p.H && p.Wo == p.Wd && (pt_w != 0 || p.H % (256 / p.Wd) == 0) &&
       p.M % 256 == 0 && ((long)p.H * p.Wd) % 256 == 0 && p.act != PFD_ACT_GEGLU) {
     p.pt_w = pt_w;
@@ -2367,14 +2233,14 @@ int pfd_gemm160_try(const PfdGemmDesc* d, int variant, int splits, hipStream_t s
       const int kps = (ncb + splits - 1) / splits;
       if (!gnf_arm((ncb + kps - 1) / kps)) return 1;
     }
-    // default: the wave-specialised form (4 loader waves): +4 ... 13 % on every patch-eligible conv of the UNet, most
-    // on the long-K ones (32768 x 320 x 8640: 149 -> 131 us = 1435 TF; profiles/r02_patch_ws_ab.log), with ping-pong
-    // consumer groups (round 3); 99 forces the 8-wave form, 98 loader waves + lock-step consumers, 97 ping-pong
-    // 96 forces the 3-stage weight ring (two taps of weights in flight, counted vmcnt; round 4); PFD_PATCH_RING=0/1 picks the default
-    const int ws = variant == 99 ? 0 : variant == 98 ? 1 : variant == 97 ? 2 : variant == 96 ? 3 : (pp_on() ? 2 : patch_ring_on() ? 3 : 1);
+    // default: the wave-specialised form (4 loader waves; +4 ... 13 % on every patch-eligible conv of the UNet, most on the
+    // long-K ones, profiles/r02_patch_ws_ab.log) with the 3-stage weight ring (two taps of weights in flight, counted vmcnt;
+    // round 4, -4.6 ms per batch); 99 forces the 8-wave form, 98 the loader-wave form with two weight stages (the
+    // GroupNorm-prologue instances are built on it)
+    const int ws = variant == 99 ? 0 : variant == 98 ? 1 : 3;   // 96 forces what is the default anyway
     return launch_patch(p, s, ws) < 0 ? PFD_ELAUNCH : 0;
   }
-  if (variant == 99 || variant == 98 || variant == 97 || variant == 96 || p.gn_table) return 1;
+  if (variant == 99 || variant == 98 || variant == 96 || p.gn_table) return 1;
   const bool auto_variant = variant == 0;
   const int nk_all = p.K / BK;
   if (auto_variant) {
@@ -2395,12 +2261,12 @@ int pfd_gemm160_try(const PfdGemmDesc* d, int variant, int splits, hipStream_t s
     if (p.ksize == 0 && variant == 44 && p.M >= 8192 && nk_all <= 20) variant = 24;
     // 128-row tiles that fill the chip at most once run the 3-stage ring (one 110 KB block per CU is no loss
     // there): 8192x640x2560 46 -> 38 us, 8192x640x1280 25 -> 24 (profiles/r02_ring_replay.log)
-    if (ring_on() && bn == 160 && p.ksize == 0 && variant == 24 && t128 <= 256 && nk_all >= 16) variant = 25;
+    if (bn == 160 && p.ksize == 0 && variant == 24 && t128 <= 256 && nk_all >= 16) variant = 25;
     if (p.ksize == 0 && variant == 24 && nk_all <= 40 && t128 <= 256 && tiles(64) >= 384) variant = 22;
     // implicit-GEMM convolutions (stride 2, fused upsample, widths the patch kernel does not take) run long K loops
     // of 53 KB stages: with the DMA pieces on four dedicated loader waves they gain 5-17 % (32768 x 640 x 5760
     // upsample conv: 225 -> 192 us = 1260 TF); the short-K linears do not (profiles/r02_wave_specialised_ab.log)
-    if (variant == 44 && p.ksize > 0) variant = pp_on() ? 49 : ws_ring_on() ? 47 : 48;
+    if (variant == 44 && p.ksize > 0) variant = 47;
     // round 3 (cold replay under every forced variant, profiles/r03_tile_variants_replay.log): the 128-row tile on EIGHT
     // waves (4 x 2 wave layout, wave tile 32 x 80; variants 82 / 83) instead of four beats the 4-wave form wherever
     // that was chosen (qkv 8192 x 1920 x 640: 32.5 -> 27.3 us, 32768 x 960 x 320: 34.3 -> 31.8, ff-out 8192 x 640 x 2560
@@ -2408,7 +2274,7 @@ int pfd_gemm160_try(const PfdGemmDesc* d, int variant, int splits, hipStream_t s
     // tile (84: 8192 x 5120 x 640 69 -> 60 us, 2048 x 10240 x 1280 63 -> 51); long-K problems on <= 2048 rows and the
     // stride-2 convolutions take the 64-row tile on eight waves with the 4-stage ring and NO split-K (43: 2048 x 1280 x
     // 5120 55 -> 48 us, 2048 x 640 x 5760 / s2 52 -> 37, 8192 x 320 x 2880 / s2 38.5 -> 30.7).
-    if (r3tiles_on() && bn == 160) {
+    if (bn == 160) {
       if (p.act == PFD_ACT_GEGLU && p.ksize == 0 && p.N % 320 == 0 && p.M >= 2048 && nk_all >= 10) variant = 84;
       else if (p.ksize == 0 && (variant == 24 || variant == 25) && p.M <= 2048 && nk_all >= 64) variant = 43;
       else if (p.ksize > 0 && p.stride == 2 && p.M <= 8192 && (variant == 24 || variant == 25 || variant == 22)) variant = 43;
@@ -2416,13 +2282,13 @@ int pfd_gemm160_try(const PfdGemmDesc* d, int variant, int splits, hipStream_t s
       else if (variant == 25) variant = 83;
     }
   }
-  const int bm = (variant == 44 || variant == 48 || variant == 49 || variant == 47 || variant == 84) ? 256
+  const int bm = (variant == 44 || variant == 48 || variant == 47 || variant == 84) ? 256
                  : (variant == 24 || variant == 25 || variant == 82 || variant == 83) ? 128 : 64;
   if (splits == 0) {
     splits = 1;
     const long tl = tiles(bm);
     const int nk = nk_all;
-    if (p.act != PFD_ACT_GEGLU && d->ws && (variant == 44 || variant == 48 || variant == 49 || variant == 47) && tl < 200 && nk >= 48 &&
+    if (p.act != PFD_ACT_GEGLU && d->ws && (variant == 44 || variant == 48 || variant == 47) && tl < 200 && nk >= 48 &&
         (size_t)2 * p.M * p.N * 4 <= d->ws_bytes) {
       splits = 2;  // 128 tiles of 256x160: two K halves fill the chip (758 vs 579 TF at 640->640 @32^2)
     } else if (p.act != PFD_ACT_GEGLU && d->ws && (variant == 24 || variant == 25 || variant == 82 || variant == 83) && tl < 256) {
@@ -2442,7 +2308,7 @@ int pfd_gemm160_try(const PfdGemmDesc* d, int variant, int splits, hipStream_t s
     const int kps = (nk_all + splits - 1) / splits;
     if (!gnf_arm((nk_all + kps - 1) / kps)) return 1;
   }
-  if (auto_variant && bn == 160 && ring_on()) {
+  if (auto_variant && bn == 160) {
     // Problems whose blocks fill the chip once (the 16^2 / 8^2 levels: <= 256 tiles, or split-K slices of them) are
     // bound by the DMA round trip per K tile, not by MFMA or LDS capacity: they take the deep operand rings (3 K tiles
     // in flight on 64-row tiles, 2 on 128-row tiles; counted vmcnt + raw barrier).  Cold replay of the sampler's launch
@@ -2454,8 +2320,8 @@ int pfd_gemm160_try(const PfdGemmDesc* d, int variant, int splits, hipStream_t s
     if (variant == 82 && (p.ksize == 0 || (p.stride == 1 && !p.ups)) && tiles(128) <= 256 && nk_split >= 6) variant = 83;
   }
   const int conv = p.ksize > 0 ? 1 : 0;
-  if (variant == 48 || variant == 49 || variant == 47) {   // 8 MFMA waves + 4 loader waves (49: ping-pong consumer groups, 47: 3-stage ring)
-    const int mode = variant == 49 ? 1 : variant == 47 ? 2 : 0;
+  if (variant == 48 || variant == 47) {   // 8 MFMA waves + 4 loader waves (49: ping-pong consumer groups, 47: 3-stage ring)
+    const int mode = variant == 47 ? 2 : 0;
     if (bn == 128) return launch160ws<4>(p, 12 + 4 * conv, s, mode) < 0 ? PFD_ELAUNCH : 0;
     return launch160ws<5>(p, 12 + 4 * conv, s, mode) < 0 ? PFD_ELAUNCH : 0;
   }

@@ -129,6 +129,7 @@ struct GemmCase {
   int k_split = 0;  // > 0: columns >= k_split of the operand come from a second buffer (PfdGemmDesc.k_split)
   int zero_rows = 0;  // > 0: the first rows of the operand are all zero and not stored (PfdGemmDesc.zero_rows)
   int gn_out = 0;     // 1: the launch also emits the GroupNorm statistics of its output (PfdGemmDesc.gn_out)
+  int res_rows = 0;   // > 0: the residual holds that many rows and is read with one wrap (PfdGemmDesc.res_rows)
 };
 
 static void run_gemm_case(const GemmCase& c) {
@@ -189,6 +190,7 @@ static void run_gemm_case(const GemmCase& c) {
   d.w_tiled = c.w_tiled;
   if (c.k_split) { d.A2 = dA2.p; d.lda2 = lda2; d.k_split = c.k_split; }
   d.zero_rows = c.zero_rows;
+  d.res_rows = c.res_rows;
   Dev<float> dGn(c.gn_out ? (size_t)(M / 64) * (N / 160) * 32 : 2);
   if (c.gn_out) {
     HIP_OK(hipMemset(dGn.p, 0xFF, dGn.n * sizeof(float)));   // NaN pattern: every used slot must be written
@@ -196,8 +198,9 @@ static void run_gemm_case(const GemmCase& c) {
   }
   const int rc = pfd_gemm_f16_ex(&d, c.tile, nullptr);
   char name[256];
-  snprintf(name, sizeof(name), "gemm M%d N%d K%d act%d b%d r%d rv%d br%d tile%d%s ks%d zr%d%s ld+%d %s", M, N, K, c.act,
-           c.bias, c.res, c.rowvec, c.bias_row, c.tile, c.w_tiled ? "T" : "", c.k_split, c.zero_rows, c.gn_out ? " gn" : "", c.extra_ld,
+  snprintf(name, sizeof(name), "gemm M%d N%d K%d act%d b%d r%d rv%d br%d tile%d%s ks%d zr%d%s%s ld+%d %s", M, N, K, c.act,
+           c.bias, c.res, c.rowvec, c.bias_row, c.tile, c.w_tiled ? "T" : "", c.k_split, c.zero_rows, c.gn_out ? " gn" : "",
+           c.res_rows ? (" rr" + std::to_string(c.res_rows)).c_str() : "", c.extra_ld,
            conv ? (std::string("conv k") + std::to_string(c.ksize) + " s" + std::to_string(c.stride) + " p" +
                    std::to_string(c.pad) + " u" + std::to_string(c.ups))
                       .c_str()
@@ -254,7 +257,7 @@ static void run_gemm_case(const GemmCase& c) {
       } else {
         v = act_ref(pre[(size_t)m * N + n], c.act);
       }
-      if (c.res) v += (double)R[m * ldr + n];
+      if (c.res) v += (double)R[(c.res_rows > 0 && m >= c.res_rows ? m - c.res_rows : m) * ldr + n];
       ref[(size_t)m * ldc + n] = v;
       gotc[(size_t)m * ldc + n] = got[(size_t)m * ldc + n];
     }
@@ -310,7 +313,7 @@ static void run_tiled_weight_cases() {
   { GemmCase c{900, 320, 1536, 0, true, false, false, false, 3203}; c.w_tiled = 1; run_gemm_case(c); }
   { GemmCase c{600, 256, 512, 0, true, true, false, false, 5400}; c.w_tiled = 1; run_gemm_case(c); }          // 128-wide tiles
   { GemmCase c{0, 256, 0, PFD_ACT_SILU, true, true, true, false, 0, 0, 3, 1, 1, 0, 2, 9, 7, 128}; c.w_tiled = 1; run_gemm_case(c); }
-  for (int v : {10800, 10700, 10900, 10802}) {   // patch kernels (tap / channel-block walk over the tiled K axis)
+  for (int v : {10800, 10600, 10900, 10802}) {   // patch kernels (tap / channel-block walk over the tiled K axis)
     GemmCase c{0, 320, 0, 0, true, true, true, false, v, 0, 3, 1, 1, 0, 2, 32, 32, 128}; c.w_tiled = 1; run_gemm_case(c);
     GemmCase e{0, 160, 0, PFD_ACT_SILU, true, false, true, false, v, 0, 3, 1, 1, 0, 1, 64, 64, 256}; e.w_tiled = 1; run_gemm_case(e);
   }
@@ -1581,7 +1584,15 @@ int main(int argc, char** argv) {
     run_gnf_case(8, 8, 8, 1280, 1280, PFD_ACT_SILU, 1e-5f, false, true, false, 3308);        // forced 4-stage ring, split 8
     run_gnf_decline_case(8, 64, 64, 320, 320);                                          // 64^2: not split, cpg 10
     run_gnf_decline_case(8, 32, 32, 640, 640);                                          // cpg 20: the fused form is not built for it
-    // the statistics-emitting split-K reduction (1024 threads per slab) and the GroupNorm apply from producer statistics
+    // residual stored once for a doubled batch (PfdGemmDesc.res_rows): every store pass and both plain reductions
+    for (int v : {0, 9200, 9300, 3200, 3300, 5400, 5800}) {
+      { GemmCase c{1024, 320, 256, 0, true, true, true, false, v}; c.res_rows = 512; run_gemm_case(c); }                      // plain store pass
+      if (v != 5800) { GemmCase c{1024, 320, 256, 0, true, true, false, false, v}; c.res_rows = 512; c.zero_rows = 512; run_gemm_case(c); }  // + zero rows: the cross-attention re-join (not on the loader-wave kernel)
+      { GemmCase c{1024, 320, 320, 0, true, true, false, false, v}; c.res_rows = 512; c.gn_out = 1; run_gemm_case(c); }       // statistics-emitting store pass: proj_out
+    }
+    { GemmCase c{1024, 320, 2048, 0, true, true, false, false, 3304}; c.res_rows = 512; run_gemm_case(c); }                    // split-K 4: plain reduction
+    { GemmCase c{1024, 320, 2048, 0, true, true, false, false, 3304}; c.res_rows = 512; c.gn_out = 1; run_gemm_case(c); }      // ... statistics-emitting reduction
+    // the statistics-emitting split-K reduction and the GroupNorm apply from producer statistics
     { GemmCase c{512, 1280, 2048, 0, true, true, true, false, 3304}; c.gn_out = 1; run_gemm_case(c); }                          // split-K 4, cpg 40
     { GemmCase c{0, 320, 0, 0, true, true, true, false, 9302, 0, 3, 1, 1, 0, 2, 16, 16, 128}; c.gn_out = 1; run_gemm_case(c); }   // conv, split-K 2
     run_gn_case(8, 64, 1280, 0, 32, PFD_ACT_SILU, 1e-5f);
@@ -1739,8 +1750,8 @@ int main(int argc, char** argv) {
     run_gemm_case({0, 320, 0, 0, true, true, false, false, 10800, 0, 3, 1, 1, 0, 1, 32, 32, 128});
     run_gemm_case({0, 160, 0, 0, true, false, true, false, 10802, 0, 3, 1, 1, 0, 1, 64, 64, 128});
     // round 3: rotated K walk (several M tiles, K tiles >= M tiles and < M tiles, split-K, conv wrap-around) and the
-    // ping-pong consumer groups (5900 = 256-row tile, 10700 = patch kernel); 5800 / 10800 are the lock-step forms
-    for (int v : {5800, 5900}) {
+    // loader-wave kernels (5800 / 5700 = 256-row tile, 10800 / 10600 = patch kernel with two / three weight stages)
+    for (int v : {5800, 5700}) {   // 58 = two operand stages, 57 = the 3-stage ring (the default)
       run_gemm_case({1100, 320, 1024, 0, true, true, true, false, v});
       run_gemm_case({700, 640, 192, PFD_ACT_GELU, true, false, true, false, v});
       run_gemm_case({600, 320, 2048, 0, true, true, false, false, v + 2});                       // split-K 2
@@ -1749,7 +1760,7 @@ int main(int argc, char** argv) {
       run_gemm_case({0, 160, 0, 0, true, false, false, false, v, 0, 3, 1, 1, 1, 2, 9, 12, 64});   // upsample
       run_gemm_case({600, 256, 512, 0, true, true, false, false, v});                            // 128-wide tiles
     }
-    for (int v : {10800, 10700}) {
+    for (int v : {10800, 10600}) {
       run_gemm_case({0, 320, 0, 0, true, true, true, false, v, 0, 3, 1, 1, 0, 2, 32, 32, 128});
       run_gemm_case({0, 160, 0, PFD_ACT_SILU, true, false, true, false, v, 0, 3, 1, 1, 0, 1, 64, 64, 256});
       run_gemm_case({0, 320, 0, 0, true, true, false, false, v, 0, 3, 1, 1, 0, 3, 16, 16, 320});

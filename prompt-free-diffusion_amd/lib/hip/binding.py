@@ -35,7 +35,7 @@ class PfdGemmDesc(C.Structure):
         ("ln_stats", _vp), ("ln_colsum", _vp), ("ln_parts", _i32), ("ln_eps", _f32), ("ln_out", _vp),
         ("k_split", _i32), ("zero_rows", _i32), ("gn_out", _vp),
         ("gnf_gamma", _vp), ("gnf_beta", _vp), ("gnf_y", _vp), ("gnf_ldy", _i64), ("gnf_eps", _f32), ("gnf_act", _i32),
-        ("gnf_rows", _i32), ("gnf_skip_raw", _i32),
+        ("gnf_rows", _i32), ("gnf_skip_raw", _i32), ("res_rows", _i32),
     ]
 
 

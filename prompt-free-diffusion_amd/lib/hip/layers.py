@@ -133,8 +133,9 @@ class Conv2d(nn.Conv2d, _Packed):
                         gn_fuse=(g, be, norm.eps, silu, keep_raw))
 
     def hip(self, x, *, ups=False, rowvec=None, res=None, act=ACT_NONE, out=None, out_hw=None, rows_per_rv=None,
-            gn=None, ln_out=None, gn_out=False):
+            gn=None, ln_out=None, gn_out=False, res_rows=None):
         """ln_out (1x1 convolutions only): also return the partial row sums of the output, see ops.gemm.
+        res_rows (1x1 convolutions only): the residual is stored once for a doubled batch, see ops.gemm.
         gn_out=True: this output will be read by a GroupNorm -- where that norm takes the two-launch form the launch also
         emits its statistics (PfdGemmDesc.gn_out); they ride on the returned tensor (ops.get_gn_stats)"""
         w, b = self._pk()
@@ -152,15 +153,15 @@ class Conv2d(nn.Conv2d, _Packed):
                     ops.gn_stats_wanted(B, H * W_, self.out_channels) and ops.wide_tile_ok(self.out_channels, cin)
                 y = ops.gemm(x.reshape(-1, cin), w, bias=b, rowvec=rowvec,
                              rows_per_rv=H * W_ if rows_per_rv is None else rows_per_rv, res=r2, act=act,
-                             out=o2, ln_out=ln_out, gn_out=want)
+                             out=o2, ln_out=ln_out, gn_out=want, res_rows=res_rows)
                 if ln_out is not None and ln_out is not False:
                     return y[0].view(B, H, W_, self.out_channels), y[1]
                 v = y.view(B, H, W_, self.out_channels)
                 if want:
                     ops.set_gn_stats(v, ops.get_gn_stats(y))
                 return v
-            if ln_out is not None and ln_out is not False:
-                raise ValueError("ln_out is for 1x1 convolutions (token-wise linears)")
+            if (ln_out is not None and ln_out is not False) or res_rows is not None:
+                raise ValueError("ln_out / res_rows are for 1x1 convolutions (token-wise linears)")
             return ops.conv(x, w, k, stride=s, pad=p, ups=ups, bias=b, rowvec=rowvec, res=res, act=act, out=out,
                             out_hw=out_hw, rows_per_rv=rows_per_rv, gn_out=gn_out)
         if ups:

@@ -61,8 +61,8 @@ def _workspace(device):
 
 
 _TRACE = os.environ.get("PFD_TRACE_GEMM")
-# PFD_LN_FOLD=0: every LayerNorm is its own launch again (A/B runs)
-LN_FOLD = os.environ.get("PFD_LN_FOLD", "1") != "0"
+# False: every LayerNorm is its own launch again (tests flip it per call; the round-3 A/B: -52 ms per batch for the fold)
+LN_FOLD = True
 
 
 # One record per GEMM / conv launch: THE field list of profiles/unet_c2_gemm_shapes.txt.  The writer below, the readers in
@@ -158,7 +158,7 @@ def ln_rowstats(x, out=None):
 
 # GroupNorm statistics from the producers (PfdGemmDesc.gn_out / pfd_groupnorm_pstats_f16); PFD_GN_PSTATS=0: every
 # two-launch GroupNorm reads its input for statistics again (A/B runs)
-GN_PSTATS = os.environ.get("PFD_GN_PSTATS", "1") != "0"
+GN_PSTATS = True
 
 
 def gn_stats_wanted(B, HW, N, M=None):
@@ -225,7 +225,7 @@ def cat_pair(t):
 
 
 # ABI 8 forms (PfdGemmDesc.k_split / zero_rows); PFD_GEMM_FUSE=0 keeps the two-launch forms (A/B runs)
-GEMM_FUSE = os.environ.get("PFD_GEMM_FUSE", "1") != "0"
+GEMM_FUSE = True
 
 
 def wide_tile_ok(N, K):
@@ -235,13 +235,15 @@ def wide_tile_ok(N, K):
 
 def gemm(a, w, *, bias=None, rowvec=None, rows_per_rv=1, res=None, act=ACT_NONE, out=None,
          bias_per_row=False, n=None, k=None, tile=0, out_t=None, n_split=None, ln=None, ln_out=None,
-         a2=None, zero_rows=0, gn_out=False):
+         a2=None, zero_rows=0, gn_out=False, res_rows=None):
     """out[M, N] = epi(a[M, K] @ w[N, K]^T); see pfd_gemm_f16 in include/pfd_hip.h.
     a2: second source of the contraction -- the operand is the virtual column concat [a | a2] (K = Ka + Ka2; the
     1x1 skip convolution over a skip concat).  zero_rows: that many all-zero operand rows come in front of a's rows
     (M = zero_rows + rows of a); their result is epi(0).  Both: wide-tile kernels only (wide_tile_ok).
     gn_out: the launch also emits the GroupNorm statistics of its output (PfdGemmDesc.gn_out); they ride on the returned
     tensor (get_gn_stats).
+    res_rows: `res` holds that many rows and is the residual of BOTH halves of a doubled batch (M == 2 * res_rows; the CFG
+    pair [x | x] stored once, PfdGemmDesc.res_rows).  Wide-tile kernels only.
     out_t / n_split: columns >= n_split go, transposed, to out_t[N - n_split, M] (wide-tile path only).
     ln = (stats, colsum, eps): LayerNorm of `a` folded into the contraction (w is the gamma-scaled weight, bias is b';
     PfdGemmDesc.ln_stats).  ln_out: True (allocate) or a float32 [M, N/160, 2] tensor -> the partial row sums of the
@@ -293,6 +295,12 @@ def gemm(a, w, *, bias=None, rowvec=None, rows_per_rv=1, res=None, act=ACT_NONE,
     if a2 is not None:
         d.A2, d.lda2, d.k_split = a2.data_ptr(), lda2, Ka
     d.zero_rows = zero_rows
+    if res_rows is not None:
+        if res is None or M != 2 * res_rows or _rows(res)[0] != res_rows:
+            raise ValueError(f"gemm: res_rows {res_rows} needs a residual of exactly that many rows and M == 2 * res_rows (M {M})")
+        d.res_rows = res_rows
+    elif res is not None and _rows(res)[0] != M:
+        raise ValueError(f"gemm: residual of {_rows(res)[0]} rows for {M} output rows (res_rows= names a shared one)")
     if ln is not None:
         st, cs, eps = ln
         if st.dtype != torch.float32 or not st.is_contiguous() or st.dim() != 3 or st.shape[0] != M or \

@@ -207,11 +207,15 @@ class CrossAttention(nn.Module, L._Packed):
             return N % 8 == 0 and Cd % 160 == 0 and x.shape[1] % 64 == 0
         return Cd % 160 == 0 or Cd % 128 == 0          # to_q on the wide-tile kernels (the fold lives there only)
 
-    def hip(self, x, B, N, context=None, res=None, ln=None, stats_out=False):
+    def hip(self, x, B, N, context=None, res=None, ln=None, stats_out=False, single=False):
         """x: [B*N, query_dim] tokens (already normalised, or UN-normalised with ln = (LayerNorm, partial row sums of
         x): the norm is then folded into the q | k | v / q projection); context: None (self-attention) or a ContextKV;
         res: residual added by the out-projection epilogue.  -> [B*N, query_dim]; with stats_out also the partial
-        row sums of the result (for the next folded LayerNorm)."""
+        row sums of the result (for the next folded LayerNorm).
+        single: x / res / the statistics hold ONE copy ([B/2 * N] rows) of a CFG pair whose halves are identical up to here and
+        whose unconditional half has an all-zero context (zero_lead == B / 2): the query projection runs on that copy (it IS
+        the conditional half), the out-projection re-joins the halves with the residual read once (ops.gemm res_rows) --
+        no torch.cat of the tokens, the block input or the statistics.  Returns the full batch."""
         Cd, H, D = self.inner_dim, self.heads, self.dim_head
         if ln is not None and not self.ln_foldable(x, N, context):
             raise ValueError("CrossAttention.hip: ln= passed for a shape the fold does not serve (see ln_foldable)")
@@ -243,6 +247,19 @@ class CrossAttention(nn.Module, L._Packed):
             if context.B != B:
                 raise ValueError(f"context batch {context.B} != activation batch {B}")
             z = context.zero_lead
+            if single:
+                if not (res is not None and 2 * z == B and stats_out and ops.wide_tile_ok(self.to_out[0].out_features, Cd)):
+                    raise ValueError("CrossAttention.hip(single=True) needs the zero-context shortcut on half the batch, a residual, "
+                                     "statistics and the wide-tile out-projection (SpatialTransformer.hip checks before it asks)")
+                w_o, b_o = self.to_out[0]._pk()
+                out = torch.empty((B * N, res.shape[1]), dtype=torch.float16, device=res.device)
+                st_o = torch.empty((B * N, out.shape[1] // 160, 2), dtype=torch.float32, device=out.device)
+                q = self.to_q.hip(x, ln=ln)                       # the one copy = the conditional half
+                o = ops.attention(q, k[z * context.Nkp:], vt[:, z * context.Nkp:], B - z, H, N, context.Nk, D,
+                                  self.scale, ldq=Cd, ldk=Cd, ldvt=B * context.Nkp, q_bs=N * Cd,
+                                  k_bs=context.Nkp * Cd, vt_bs=context.Nkp)
+                ops.gemm(o, w_o, bias=b_o, res=res, out=out, zero_rows=z * N, ln_out=st_o, res_rows=z * N)
+                return out, st_o
             if 0 < z < B and res is not None:
                 # rows of the first z samples: x + bias; the remaining samples: the real thing
                 Bc = B - z
@@ -313,12 +330,22 @@ class BasicTransformerBlock(nn.Module):
             return self.attn1.hip(x, B, N, c1, res=x, ln=(self.norm1, xs), stats_out=True)
         return self.attn1.hip(self.norm1.hip(x), B, N, c1, res=x)
 
-    def hip_rest(self, x, B, N, context, xs=None):
-        """cross-attention and feed-forward residual branches; xs: partial row sums of x when the block folds"""
+    def pair_single_ok(self, x, B, N, context, xs):
+        """can hip_rest(single=True) take ONE copy of a CFG pair (B = the doubled batch)?  The folded block, the zero-context
+        shortcut on exactly the unconditional half, the wide-tile out-projection."""
+        return xs is not None and context is not None and not isinstance(context, ContextMix) and \
+            2 * getattr(context, 'zero_lead', 0) == B and \
+            ops.wide_tile_ok(self.attn2.to_out[0].out_features, self.attn2.inner_dim)
+
+    def hip_rest(self, x, B, N, context, xs=None, single=False):
+        """cross-attention and feed-forward residual branches; xs: partial row sums of x when the block folds.
+        single: x / xs are ONE copy of a CFG pair (see CrossAttention.hip); B is the doubled batch, the result is doubled"""
         z = getattr(context, 'zero_lead', 0) if context is not None else 0
         if xs is not None and context is not None and not isinstance(context, ContextMix):
-            x, xs = self.attn2.hip(x, B, N, context, res=x, ln=(self.norm2, xs), stats_out=True)
+            x, xs = self.attn2.hip(x, B, N, context, res=x, ln=(self.norm2, xs), stats_out=True, single=single)
             return self.ff.hip(x, res=x, ln=(self.norm3, xs))
+        if single:
+            raise ValueError("hip_rest(single=True) without the folded block (see pair_single_ok)")
         if 0 < z < B:   # LayerNorm only feeds to_q: skip it for the zero-context samples too
             xn = torch.empty_like(x)
             self.norm2.hip(x[z * N:], out=xn[z * N:])
@@ -366,6 +393,9 @@ class SpatialTransformer(nn.Module):
         for p in self.proj_out.parameters():  # zero-initialised in the reference (attention.py:343-347)
             p.detach().zero_()
 
+    # the CFG-pair doubling without torch.cat (PfdGemmDesc.res_rows); tests switch it per call
+    pair_without_copies = True
+
     def hip(self, x, context=None, cfg_pair=False):
         """x: NHWC fp16 [B,H,W,C]; context: ContextKV | None.
         cfg_pair: x holds ONE copy of a classifier-free-guidance batch whose unconditional and conditional halves
@@ -390,9 +420,19 @@ class SpatialTransformer(nn.Module):
             hs = None
             if isinstance(h, tuple):
                 h, hs = h
-                hs = torch.cat([hs, hs])
-            h, x, B = torch.cat([h, h]), torch.cat([x, x]), 2 * B      # the only two copies (21 MB each at 64^2)
-            h = blocks[0].hip_rest(h, B, N, context, hs)
+            x_rows = None
+            if self.pair_without_copies and not self.use_linear and blocks[0].pair_single_ok(h, 2 * B, N, context, hs) and \
+                    ops.wide_tile_ok(self.proj_out.out_channels, inner):
+                # round 5: no copy at all -- the cross-attention out-projection and proj_out re-join the halves and read
+                # their residual (the single copy of the tokens / of the block input) twice (PfdGemmDesc.res_rows)
+                B = 2 * B
+                h = blocks[0].hip_rest(h, B, N, context, hs, single=True)
+                x_rows = (B // 2) * N
+            else:
+                if hs is not None:
+                    hs = torch.cat([hs, hs])
+                h, x, B = torch.cat([h, h]), torch.cat([x, x]), 2 * B      # three copies (21 MB each at 64^2 for h and x)
+                h = blocks[0].hip_rest(h, B, N, context, hs)
             hs = None
             blocks = blocks[1:]
         for blk in blocks:
@@ -400,6 +440,8 @@ class SpatialTransformer(nn.Module):
             hs = None
         if self.use_linear:
             return self.proj_out.hip(h.view(B, H, W_, -1), res=x)
+        if cfg_pair and x_rows is not None:
+            return self.proj_out.hip(h.view(B, H, W_, -1), res=x.view(-1, Cc), gn_out=True, res_rows=x_rows)
         return self.proj_out.hip(h.view(B, H, W_, -1), res=x, gn_out=True)   # read next by a GroupNorm (ResBlock / head)
 
     def forward(self, x, context=None):

@@ -127,7 +127,7 @@ class ResBlock(TimestepBlock):
     # launch.  Bit-identical, and measured SLOWER on MI355X (profiles/r02_gn_prologue_ab.log: the affine map + SiLU on
     # the patch kernel's loader waves costs the convolution 20-26 us, the apply pass it removes 13-18 us; end to end
     # 6.58 vs 6.68 images/s), so it is off unless PFD_GN_PROLOGUE=1 (tests switch it per call).
-    fuse_groupnorm = os.environ.get("PFD_GN_PROLOGUE", "0") == "1"
+    fuse_groupnorm = False
     # GroupNorm 2 (+ SiLU) inside the split-K reduction of the first convolution (PfdGemmDesc.gnf_y; tests switch it per call)
     fuse_reduce_groupnorm = True
 

@@ -47,7 +47,7 @@ def test_emulation_reproduces_the_hardware_validated_kernels(emu):
 
 
 def test_statistics_emitting_splitk_reduce(emu):
-    """split-K reduction that also emits the GroupNorm statistics of what it stores (1024 threads per slab):
+    """split-K reduction that also emits the GroupNorm statistics of what it stores (three row sweeps of loads in flight):
     statistics == sums of the stored f16 values"""
     lines = _run(emu, "statistics")
     assert len(lines) == 2 and all("statistics err" in l for l in lines), "\n".join(lines)

@@ -486,11 +486,21 @@ def test_cfg_prefix_sharing_matches_the_doubled_batch(net, golden):
                         verbose=False)
         return x.float()
 
+    from lib.model_zoo.attention import SpatialTransformer
     for control, shape in ((None, [2, 4, 8, 8]), (None, [2, 4, 32, 32]), (hint, [2, 4, 16, 24])):
         a, b = run(True, control, shape), run(False, control, shape)
         d = float((a - b).abs().max())
         print(f"[parity] CFG prefix sharing vs doubled batch {shape} control={control is not None}: max|diff| {d:.2e}")
         assert d <= 4e-3 * max(1.0, float(b.abs().max()))
+        # the re-join of the two halves without copies (round 5: the cross-attention out-projection and proj_out read the one
+        # residual twice, PfdGemmDesc.res_rows) against the torch.cat form: the same kernels on the same values -> the same bits
+        was = SpatialTransformer.pair_without_copies
+        SpatialTransformer.pair_without_copies = not was
+        try:
+            c = run(True, control, shape)
+        finally:
+            SpatialTransformer.pair_without_copies = was
+        assert torch.equal(a, c), float((a - c).abs().max())
 
 
 def test_zero_uncond_shortcut_is_exact(net, golden):
