@@ -333,13 +333,17 @@ def main():
                 res["roofline"] = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                    "frac": ach / HBM_PEAK_GBS}
             pmc = os.path.join(REPO, "profiles", "pmc_traffic.json")
-            traffic = None
+            traffic, traffic_from = None, None
             if os.path.exists(pmc):
                 try:
-                    traffic = json.load(open(pmc)).get(top["name"])
+                    tj = json.load(open(pmc))
+                    traffic = tj.get(top["name"])
+                    # (the PMC passes cannot ride in this process: rocprofv3 --pmc over torch crashes here; the tracked file
+                    #  names the commit whose kernels it counted)
+                    traffic_from = {"file": "profiles/pmc_traffic.json", "commit": tj.get("_commit"), "recorded": tj.get("_recorded")}
                 except Exception:
                     traffic = None
-            res["roofline"].update({"traffic": traffic, "kernel": top["name"], "launches": top["launches"],
+            res["roofline"].update({"traffic": traffic, "traffic_from": traffic_from, "kernel": top["name"], "launches": top["launches"],
                                     "avg_launch_ms": top["ms_graph"] / top["launches"],
                                     "avg_launch_ms_eager": top["ms"] / top["launches"], "eager_to_graph": norm,
                                     "eager_gap_us_per_launch": gap_ms * 1e3,
