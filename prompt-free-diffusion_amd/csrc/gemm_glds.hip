@@ -2220,6 +2220,7 @@ int pfd_gemm160_try(const PfdGemmDesc* d, int variant, int splits, hipStream_t s
     if (splits == 0) {
       splits = 1;
       const long tl = tiles(256);
+      // (round 5, end to end: no split below 200 tiles -> below 100: +2.3 % per batch; aiming at 512 blocks instead of 256: +3.7 %)
       if (d->ws && tl < 200) {
         splits = (int)((256 + tl - 1) / tl);
         if (splits > 8) splits = 8;
@@ -2320,6 +2321,11 @@ int pfd_gemm160_try(const PfdGemmDesc* d, int variant, int splits, hipStream_t s
     if (variant == 82 && (p.ksize == 0 || (p.stride == 1 && !p.ups)) && tiles(128) <= 256 && nk_split >= 6) variant = 83;
   }
   const int conv = p.ksize > 0 ? 1 : 0;
+  // round 5: the 64-row tiles run on EIGHT waves (4 x 1 wave layout, wave tile 16 x 160: variants 41 / 43) wherever the rules
+  // above picked the four-wave forms 22 / 23 -- twice the waves issuing LDS-DMA pieces per CU on launches that are chains of
+  // round trips.  Same tile, same split counts, same K order.  End to end -0.2 % (22 -> 41) and -0.3 % (23 -> 43), alternating on
+  // one box (profiles/r05_e2e_ab_candidates.log); round 3 had adopted the eight-wave forms only where the COLD REPLAY showed a gain.
+  if (auto_variant && bn == 160) variant = variant == 22 ? 41 : variant == 23 ? 43 : variant;
   if (variant == 48 || variant == 47) {   // 8 MFMA waves + 4 loader waves (49: ping-pong consumer groups, 47: 3-stage ring)
     const int mode = variant == 47 ? 2 : 0;
     if (bn == 128) return launch160ws<4>(p, 12 + 4 * conv, s, mode) < 0 ? PFD_ELAUNCH : 0;
