@@ -1986,7 +1986,7 @@ inline void launch_splitk_reduce(const G160Params& p, hipStream_t s) {
   } else {
     const long nvec = (long)p.M * (p.N / 8);
     int g = (int)((nvec + 255) / 256);
-    if (g > 2048) g = 2048;
+    if (g > 2048) g = 2048;   // (1024 / 8192: no difference end to end, round 5)
     hipLaunchKernelGGL(splitk_reduce_kernel, dim3(g), dim3(256), 0, s, p);
   }
   // a split-K output that feeds a folded LayerNorm: its row statistics by the stand-alone kernel
