@@ -207,10 +207,15 @@ typedef struct PfdGemmDesc {
 int pfd_gemm_f16(const PfdGemmDesc* d, pfd_stream_t stream);
 /* Same, with the kernel variant forced (tests and tuning only); 0 = the library's heuristic.
  *   tile in {22, 21, 12, 11}: register-staged kernel, (64*TM) x (64*TN) x 64 tile, tile = 10*TM+TN
- *   tile = 1000 + 100*v + s : LDS-DMA wide-tile kernel (needs N % 160 == 0 or N % 128 == 0),
- *          v in {44, 24, 22} = 256 / 128 / 64 rows x (160 | 128) columns block tile (0 = heuristic;
- *          48 = 256 rows with 4 dedicated LDS-DMA loader waves; 99 = the 3x3 patch kernel), split-K factor s in
- *          0..8 (0 = heuristic), e.g. 1000 + 4400 + 2 = 5402. */
+ *   tile = 1000 + 100*v + s : LDS-DMA wide-tile kernel (needs N % 160 == 0 or N % 128 == 0), split-K factor s in 0..8
+ *          (0 = heuristic), e.g. 1000 + 4400 + 2 = 5402.  v (0 = heuristic):
+ *            44 / 24 / 22     256 / 128 / 64 rows x (160 | 128) columns, two operand stages (4 x 2 / 2 x 2 wave layouts)
+ *            82 / 41          the 128- / 64-row tiles on eight waves (160-wide only)
+ *            25 / 83, 23 / 43 the same tiles on 3- / 4-stage operand rings with counted waits (160-wide only)
+ *            84               256 x 320 tile, GEGLU projections only
+ *            48 / 47          256 rows with 4 dedicated LDS-DMA loader waves, two / three operand stages
+ *            99 / 98 / 96     the 3x3 patch kernel: 8-wave form / loader waves with two weight stages / three (the default)
+ *          A variant that does not serve the launch (shape, epilogue, ABI 8 / 9 fields) is PFD_ESHAPE. */
 int pfd_gemm_f16_ex(const PfdGemmDesc* d, int32_t tile, pfd_stream_t stream);
 
 /* GEGLU weight packing the serving kernel expects for a projection of N = 2*dim_out output rows: the
