@@ -2259,7 +2259,8 @@ int pfd_gemm160_try(const PfdGemmDesc* d, int variant, int splits, hipStream_t s
     // short-K linears on >= 8192 rows are epilogue / HBM bound: two co-resident 128-row blocks overlap one
     // block's store pass with the other's K loop (GEGLU 32768x2560x320: 87 -> 79 us, qkv 8192x1920x640: 42 -> 35);
     // mid-K problems with <= 256 tiles of 128 rows take 64-row tiles (8192x640x2560: 54 -> 46 us)
-    if (p.ksize == 0 && variant == 44 && p.M >= 8192 && nk_all <= 20) variant = 24;
+        // (nk_all <= 40 since round 5, end to end -0.25 %; <= 20 came from the cold replay)
+    if (p.ksize == 0 && variant == 44 && p.M >= 8192 && nk_all <= 40) variant = 24;
     // 128-row tiles that fill the chip at most once run the 3-stage ring (one 110 KB block per CU is no loss
     // there): 8192x640x2560 46 -> 38 us, 8192x640x1280 25 -> 24 (profiles/r02_ring_replay.log)
     if (bn == 160 && p.ksize == 0 && variant == 24 && t128 <= 256 && nk_all >= 16) variant = 25;
@@ -2277,8 +2278,8 @@ int pfd_gemm160_try(const PfdGemmDesc* d, int variant, int splits, hipStream_t s
     // 5120 55 -> 48 us, 2048 x 640 x 5760 / s2 52 -> 37, 8192 x 320 x 2880 / s2 38.5 -> 30.7).
     if (bn == 160) {
       // (nk_all >= 5 since round 5 -- the 64^2 GEGLU projection, K = 320, too: -0.3 % end to end; >= 10 came from the cold replay)
-      if (p.act == PFD_ACT_GEGLU && p.ksize == 0 && p.N % 320 == 0 && p.M >= 2048 && nk_all >= 5) variant = 84;
-      else if (p.ksize == 0 && (variant == 24 || variant == 25) && p.M <= 2048 && nk_all >= 64) variant = 43;
+            if (p.act == PFD_ACT_GEGLU && p.ksize == 0 && p.N % 320 == 0 && p.M >= 2048 && nk_all >= 5) variant = 84;
+      else if (p.ksize == 0 && (variant == 24 || variant == 25) && p.M <= 2048 && nk_all >= 32) variant = 43;   // (>= 64 until round 5; >= 32: -0.5 % end to end)
       else if (p.ksize > 0 && p.stride == 2 && p.M <= 8192 && (variant == 24 || variant == 25 || variant == 22)) variant = 43;
       else if (variant == 24) variant = 82;
       else if (variant == 25) variant = 83;
