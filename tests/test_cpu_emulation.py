@@ -53,6 +53,13 @@ def test_statistics_emitting_splitk_reduce(emu):
     assert len(lines) == 2 and all("statistics err" in l for l in lines), "\n".join(lines)
 
 
+def test_residual_stored_once_for_a_doubled_batch(emu):
+    """PfdGemmDesc.res_rows (ABI 9): the store pass, the store pass behind zero rows (the cross-attention re-join of a CFG pair)
+    and the plain split-K reduction read residual row m - res_rows for the second half"""
+    lines = _run(emu, "residual read with one wrap")
+    assert len(lines) == 3, "\n".join(lines)
+
+
 def test_splitk_reduce_with_fused_groupnorm(emu):
     """PfdGemmDesc.gnf_y (ABI 9, round 5): the split-K reduction whose blocks own (sample, group) slabs and normalise them in
     the same launch -- ring kernel, 4-wave ring with residual and raw tensor kept, patch kernel: raw result bit for bit the

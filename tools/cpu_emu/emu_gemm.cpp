@@ -46,6 +46,7 @@ struct Case {
   bool w_tiled = false;    // the weight is handed over K-tile-contiguous (PfdGemmDesc.w_tiled)
   bool gn_stats = false;   // the launch emits GroupNorm statistics (PfdGemmDesc.gn_out): checked against the sums of what it stored
   int gnf = 0;             // 1 / 2: GroupNorm(+SiLU) fused into the split-K reduction (PfdGemmDesc.gnf_y), raw tensor skipped / kept
+  int res_rows = 0;        // > 0: the residual holds that many rows, read with one wrap (PfdGemmDesc.res_rows)
 };
 
 static int run_variant(const Case& c, int variant, const std::vector<h16>& A, const std::vector<h16>& A2, const std::vector<h16>& Wt,
@@ -74,6 +75,7 @@ static int run_variant(const Case& c, int variant, const std::vector<h16>& A, co
   d.B = c.B; d.H = c.H; d.Wd = c.W; d.Cin = c.Cin; d.Ho = Ho; d.Wo = Wo;
   if (c.k_split) { d.k_split = c.k_split; d.A2 = A2.data(); d.lda2 = K - c.k_split; }
   d.zero_rows = c.zero_rows;
+  d.res_rows = c.res_rows;
   d.ws = ws.data(); d.ws_bytes = ws.size() * sizeof(float);
   if (gn) d.gn_out = gn->data();
   if (gnf_y) {
@@ -140,7 +142,7 @@ static int run_case(const Case& c) {
       if (c.rowvec) s += (double)rv[(size_t)(m / rows_per_rv) * N + n];
       if (c.act == PFD_ACT_SILU) s = s / (1.0 + exp(-s));
       else if (c.act == PFD_ACT_RELU) s = s > 0 ? s : 0;
-      if (c.res) s += (double)R[(size_t)m * N + n];
+      if (c.res) s += (double)R[(size_t)(c.res_rows > 0 && m >= c.res_rows ? m - c.res_rows : m) * N + n];
       max_ref = std::max(max_ref, fabs(s));
       max_err = std::max(max_err, fabs(s - (double)C[(size_t)m * N + n]));
     }
@@ -226,6 +228,10 @@ int main(int argc, char** argv) {
   // the hardware-validated LDS-ring kernels (sanity of the emulation itself)
   lin("variant 23 (64x160, 4-stage LDS ring) 200x160x512", 200, 160, 512, 23, 1, true, -1);
   lin("variant 83 (128x160, 8 waves, 3-stage LDS ring) 200x160x320", 200, 160, 320, 83, 1, false, -1);
+  // residual stored once for a doubled batch (PfdGemmDesc.res_rows, round 5): store pass and plain split-K reduction, + zero rows
+  { auto c = lin("residual read with one wrap (res_rows 128), 8-wave 128-row tile", 256, 160, 256, 82, 1, true, -1); c->res_rows = 128; }
+  { auto c = lin("residual read with one wrap + zero rows (the CFG re-join), 64-row ring", 256, 320, 512, 23, 1, true, -1); c->res_rows = 128; c->zero_rows = 128; }
+  { auto c = lin("residual read with one wrap, split-K 2 (plain reduction)", 256, 160, 1024, 23, 2, true, -1); c->res_rows = 128; }
   // split-K reduction that also emits the GroupNorm statistics (three row sweeps in flight)
   { auto c = lin("split-K 4 + GroupNorm statistics (N 320: cpg 10), residual", 128, 320, 1024, 23, 4, true, -1); c->gn_stats = true; }
   { auto c = conv("split-K 2 conv 8x8x128 -> 1280 + statistics (cpg 40), SiLU-free", 1280, 83, 2, 3, 1, 1, 0, 2, 8, 8, 128, true, -1); c->gn_stats = true; }
