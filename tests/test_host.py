@@ -389,3 +389,33 @@ def test_stale_groupnorm_statistics_are_dropped_on_rewrite():
     assert ops.get_gn_stats(ops._written(t, st2)) is st2                   # rewritten with fresh ones
     assert ops.get_gn_stats(t[:32]) is None                                # views do not inherit
     assert ops._written(None) is None
+
+
+def test_unet_next_norm_hints(full_net):
+    """UNetModel2D_Next._next_norms (round 5): which data layers are told the GroupNorm that reads their output ALONE, so that
+    their last convolution's split-K reduction can also write that norm's result (PfdGemmDesc.gnf_y).  A ResBlock followed by a
+    context layer gets SpatialTransformer.norm (eps 1e-6, no SiLU), one followed by a plain ResBlock gets in_layers[0] + SiLU
+    (eps 1e-5); layers whose output enters a skip concat, convolution-only layers and -- with ControlNet residuals, which are
+    added in between (pfd.py:515) -- the middle block's output get none."""
+    from lib.model_zoo.openaimodel import ResBlock
+    unet = full_net.diffuser['image']
+    order = list(unet.i_order) + list(unet.m_order) + list(unet.o_order)
+    hints = unet._next_norms(unet, False)
+    assert len(hints) == 18 and all(order[i] == 'd' for i in hints)
+    n_in, n_mid = len(unet.i_order), len(unet.m_order)
+    d_pos = [i for i, t in enumerate(order) if t == 'd']
+    blocks = dict(zip(d_pos, unet.data_blocks))
+    for i, (norm, silu) in hints.items():
+        assert isinstance(blocks[i][len(blocks[i]) - 1], ResBlock)          # only a trailing ResBlock can use the hint
+        nxt = next(j for j in range(i + 1, len(order)) if order[j] in ('d', 'c', 'load_hidden_feature'))
+        assert order[nxt] != 'load_hidden_feature'                            # never the half of a skip concat
+        if order[nxt] == 'c':
+            assert not silu and norm.eps == 1e-6 and norm.num_channels == blocks[i][len(blocks[i]) - 1].out_channels
+        else:
+            assert silu and norm.eps == 1e-5 and norm is blocks[nxt][0].in_layers[0]
+    # 8 of them are at widths the fused reduction serves (1280 channels: the 16^2 / 8^2 levels)
+    assert sum(1 for norm, _ in hints.values() if norm.num_channels == 1280) == 8
+    with_ctl = unet._next_norms(unet, True)
+    last_mid = n_in + n_mid - 1
+    assert set(hints) - set(with_ctl) == ({last_mid} & set(hints)) and len(with_ctl) >= 17
+    assert unet._next_norms(unet, False) is hints                             # cached
