@@ -28,21 +28,9 @@
 #include <stdlib.h>
 
 #include "pfd_common.h"
+#include "attention_params.h"
 
 namespace {
-
-typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-
-struct AttnParams {
-  const half_t* Q;
-  const half_t* K;
-  const half_t* Vt;
-  half_t* O;
-  long ldq, ldk, ldvt, ldo;
-  long q_bs, k_bs, vt_bs, o_bs;
-  int B, H, Nq, Nk, D;
-  float scale_log2;
-};
 
 // Occupancy: D = 40 needs 136 VGPRs when left alone (3 waves per SIMD); asked for 4 waves per SIMD the
 // allocation fits 128 without scratch and self-attention at N = 4096 gains 4.6 % (452 -> 473 TF), the 148-key
@@ -692,6 +680,16 @@ int launch(const AttnParams& p, hipStream_t s) {
     pfd_prof_begin(8, 4.0 * p.B * p.H * (double)p.Nq * p.Nk * D,
                    2.0 * p.B * p.H * D * (2.0 * p.Nq + 2.0 * p.Nk), s);
   // 8-wave blocks pay when a block has many queries to amortise the staging over and the grid still fills the chip twice
+  if constexpr (D == 40) {
+    // round 6: the software-pipelined 64-queries-per-wave kernel (attention3.hip) for self-attention-sized problems
+    // (PFD_ATTN3=0: the round-5 kernel -- A/B switch of the round, to be removed once decided)
+    static const bool attn3 = !(getenv("PFD_ATTN3") && atoi(getenv("PFD_ATTN3")) == 0);
+    if (attn3 && pfd_attention3_takes(p)) {
+      pfd_attention3_launch(p, s);
+      if (prof) pfd_prof_end(s);
+      return pfd_check_launch("pfd_attention_f16");
+    }
+  }
   const bool big = p.Nq >= 1024 && (long)p.B * p.H * ((p.Nq + 255) / 256) >= 512;
   const bool w8 = D == 40 && (big || attn_force8());
   // (round 5: 64-query blocks of two waves for the grids that fill less than the chip -- d = 160 at 16^2 / 8^2 -- measured

@@ -1,0 +1,295 @@
+// attention3_kernel (round 6): d = 40 self-attention as a SOFTWARE-PIPELINED loop, 64 queries per wave.
+// Replaces attention.py:188-199 of the reference (materialised [B*H, N, N] scores) for the UNet's 64^2 / 96^2 self-attention.
+//
+// Same math as attention2_kernel<40, 8, true, true> (attention.hip): transposed formulation S^T = K Q^T, O^T = V^T P^T, the running
+// maximum folded into the QK^T MFMA through contraction slot 40, PV on v_mfma_f32_16x16x32_f16 with the row sum on the ones row
+// 40 of V^T, deferred rescale at +6 -- a different schedule.  The round-5 kernel ran QK^T -> max -> exp -> PV strictly in sequence
+// inside a wave and relied on 4 waves per SIMD (two barrier-locked pairs) to overlap one wave's VALU with another's MFMAs: 262 us for
+// the B 8 / 64^2 shape with the matrix pipe 0.39 busy, 0.39 of the wave cycles issue-stalled, 0.35 LDS bank-conflict share
+// (profiles/r06_pmc_sq_attn.md).  Here ONE wave's instruction stream carries independent matrix and vector work side by side:
+//   * a wave owns TWO 32-query sub-blocks A and B, half an iteration apart:
+//         seg 1   MFMA  S_B(t)   = K(t) Q_B          |  VALU  P_A(t) = f16(exp2(S_A(t)))  (+ v_permlane16_swap re-layout)
+//         seg 2   MFMA  O_A     += V^T(t) P_A(t)      |  VALU  max over S_B(t)            -> rescale decision for B
+//         seg 3   MFMA  S_A(t+1) = K(t+1) Q_A         |  VALU  P_B(t)
+//         seg 4   MFMA  O_B     += V^T(t) P_B(t)      |  VALU  max over S_A(t+1)          -> rescale decision for A
+//     every MFMA segment has the other sub-block's softmax half next to it, and a rescale (rare) always sits between the
+//     completed PV of a tile and the exponentials of the next one (the guide's T13 order);
+//   * 4 waves = 256 queries share a staged tile, two blocks per CU (2 waves per SIMD, up to 256 registers each);
+//   * K lives in a 3-stage ring (tiles t and t+1 are read in one iteration, t+2 is in flight), V^T in two stages; the global
+//     loads of an iteration are issued at its top and written to LDS at its bottom: one barrier per 64-key tile;
+//   * a V^T fragment is ONE ds_read_b128: the staging writes the keys of a row in the order the P^T operand has them after the
+//     swap (16-byte slot 4 u + kg holds keys 32 u + 16 (kg & 1) + 4 (kg >> 1) + {0..3, 8..11}), slots XOR-swizzled by
+//     (d >> 1) & 7 so that every 16-lane group of the read hits 16 different bank quads; 6 + 6 fragment reads per sub-block
+//     and tile instead of 6 + 24 eight-byte ones.
+// Requires Nk % 64 == 0 and Nk >= 128 (self-attention at every latent size whose token count is a multiple of 64); the
+// dispatcher keeps attention2_kernel for everything else (cross-attention, ragged key counts, small grids).
+// The translation unit is compiled with -fno-honor-nans: without it every fmaxf on an MFMA result is preceded by a
+// canonicalising v_max_f32 x, x (53 instead of 23 instructions for the 32-value maximum of a tile).  No NaN can arise here.
+#pragma once
+#include <stdlib.h>
+
+#include "attention_params.h"
+
+namespace {
+
+__global__ __launch_bounds__(256, 2) void attention3_kernel(const AttnParams p) {
+  constexpr int D = 40, KV = 64, K_LD = 56, VT_LD = 64, DV = 48, NS = 3, NDT = 3;
+  constexpr int K_TILE = KV * K_LD, V_TILE = DV * VT_LD;
+  constexpr int NTHR = 256, QB = 256;
+  __shared__ __attribute__((aligned(16))) half_t lds[3 * K_TILE + 2 * V_TILE];
+  half_t* const Ks = lds;
+  half_t* const Vts = lds + 3 * K_TILE;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l31 = lane & 31, hi = lane >> 5, dl = lane & 15, kg = lane >> 4;
+  const int nqb = (p.Nq + QB - 1) / QB;
+  const int lin = xcd_remap(blockIdx.x, gridDim.x);
+  const int bh = lin / nqb;
+  const int qb = lin - bh * nqb;
+  const int b = bh / p.H, h = bh - b * p.H;
+  const int q0 = qb * QB + wave * 64;
+
+  static_assert((3 * K_TILE + 2 * V_TILE) % 8 == 0, "16-byte clears");
+  for (int i = tid; i < (3 * K_TILE + 2 * V_TILE) / 8; i += NTHR) reinterpret_cast<uint4*>(lds)[i] = make_uint4(0, 0, 0, 0);
+  __syncthreads();
+  for (int i = tid; i < 2 * KV; i += NTHR) Vts[(i / KV) * V_TILE + D * VT_LD + (i % KV)] = (half_t)1.f;   // ones row: sum_kv P
+  for (int i = tid; i < 3 * KV; i += NTHR) Ks[(i / KV) * K_TILE + (i % KV) * K_LD + D] = (half_t)1.f;     // fold column
+
+  half8_t qfA[NS], qfB[NS];
+  auto load_q = [&](int qs, half8_t* qf) __attribute__((always_inline)) {
+    const half_t* qp = p.Q + (long)b * p.q_bs + (long)min(qs + l31, p.Nq - 1) * p.ldq + h * D;
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+      const int d = s * 16 + hi * 8;
+      Pack16 t;
+      t.u = *reinterpret_cast<const uint4*>(qp + min(d, D - 8));   // unconditional; the padding slots are zeroed below
+      if (d >= D) t.u = make_uint4(0, 0, 0, 0);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) qf[s][e] = (half_t)((float)t.h[e] * p.scale_log2);
+    }
+  };
+  load_q(q0, qfA);
+  load_q(q0 + 32, qfB);
+
+  float4_t oA[NDT][2], oB[NDT][2];   // O^T: [d tile][q tile], col = q % 16 = lane & 15, rows 4 (lane >> 4) + r
+#pragma unroll
+  for (int i = 0; i < NDT; ++i)
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      oA[i][q] = (float4_t){0.f, 0.f, 0.f, 0.f};
+      oB[i][q] = (float4_t){0.f, 0.f, 0.f, 0.f};
+    }
+  float mA = 0.f, mB = 0.f;          // the folded maxima (f16-representable), 0 before the first tile
+
+  // ---- staging: 320 16-byte chunks of K (64 rows x 5) and of V^T (40 rows x 8) per tile; thread t moves chunk t of both,
+  //      wave 0 also K chunk 256 + t, wave 1 also V^T chunk 256 + (t - 64) ----
+  const int krow0 = tid / 5, kcc0 = tid - krow0 * 5;
+  const int kx = 256 + lane, krow1 = kx / 5, kcc1 = kx - krow1 * 5;
+  const int vd0 = tid >> 3, vcc0 = tid & 7;
+  const int vd1 = 32 + (lane >> 3), vcc1 = lane & 7;
+  auto v_slot = [&](int d, int cc) __attribute__((always_inline)) {   // halfs; the chunk's second 8 bytes go to (this ^ 16)
+    return d * VT_LD + ((((cc >> 2) << 2) | ((cc >> 1) & 1)) ^ ((d >> 1) & 7)) * 8 + 4 * (cc & 1);
+  };
+  const int k_lds0 = krow0 * K_LD + kcc0 * 8, k_lds1 = krow1 * K_LD + kcc1 * 8;
+  const int v_lds0 = v_slot(vd0, vcc0), v_lds1 = v_slot(vd1, vcc1);
+  const half_t* kbase = p.K + (long)b * p.k_bs + h * D;
+  const half_t* vbase = p.Vt + (long)h * D * p.ldvt + (long)b * p.vt_bs;
+  const half_t* kp0 = kbase + (long)krow0 * p.ldk + kcc0 * 8;
+  const half_t* kp1 = kbase + (long)krow1 * p.ldk + kcc1 * 8;
+  const half_t* vp0 = vbase + (long)vd0 * p.ldvt + vcc0 * 8;
+  const half_t* vp1 = vbase + (long)vd1 * p.ldvt + vcc1 * 8;
+  const long kstep = (long)KV * p.ldk;
+  u32x4 kr0, kr1, vr0, vr1;
+  kr1 = vr1 = (u32x4){0u, 0u, 0u, 0u};
+  auto load_k = [&](int tile) __attribute__((always_inline)) {
+    kr0 = *reinterpret_cast<const u32x4*>(kp0 + tile * kstep);
+    if (wave == 0) kr1 = *reinterpret_cast<const u32x4*>(kp1 + tile * kstep);
+  };
+  auto load_v = [&](int tile) __attribute__((always_inline)) {
+    vr0 = *reinterpret_cast<const u32x4*>(vp0 + tile * KV);
+    if (wave == 1) vr1 = *reinterpret_cast<const u32x4*>(vp1 + tile * KV);
+  };
+  auto store_k = [&](int stage) __attribute__((always_inline)) {
+    half_t* Kd = Ks + stage * K_TILE;
+    *reinterpret_cast<u32x4*>(Kd + k_lds0) = kr0;
+    if (wave == 0) *reinterpret_cast<u32x4*>(Kd + k_lds1) = kr1;
+  };
+  auto store_v = [&](int stage) __attribute__((always_inline)) {
+    half_t* Vd = Vts + stage * V_TILE;
+    *reinterpret_cast<uint2*>(Vd + v_lds0) = make_uint2(vr0[0], vr0[1]);
+    *reinterpret_cast<uint2*>(Vd + (v_lds0 ^ 16)) = make_uint2(vr0[2], vr0[3]);
+    if (wave == 1) {
+      *reinterpret_cast<uint2*>(Vd + v_lds1) = make_uint2(vr1[0], vr1[1]);
+      *reinterpret_cast<uint2*>(Vd + (v_lds1 ^ 16)) = make_uint2(vr1[2], vr1[3]);
+    }
+  };
+
+  // ---- the building blocks of an iteration ----
+  const int k_frag = l31 * K_LD + hi * 8;                               // + u * 32 * K_LD + s * 16
+  const int v_frag0 = dl * VT_LD + ((0 + kg) ^ ((dl >> 1) & 7)) * 8;    // u = 0; + i * 16 * VT_LD (row 16 i + dl: same swizzle)
+  const int v_frag1 = dl * VT_LD + ((4 + kg) ^ ((dl >> 1) & 7)) * 8;    // u = 1
+  auto qk = [&](const half_t* Kt, const half8_t* qf, float16_t* st) __attribute__((always_inline)) {
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) st[u][r] = 0.f;
+#pragma unroll
+      for (int s = 0; s < NS; ++s) {
+        const half8_t kf = *reinterpret_cast<const half8_t*>(Kt + k_frag + u * 32 * K_LD + s * 16);
+        st[u] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[s], st[u], 0, 0, 0);
+      }
+    }
+  };
+  union H8 {
+    half8_t h;
+    unsigned w[4];
+  };
+  // P^T of one sub-block and tile: pb[u][q tile] = the B operand of the 16x16x32 MFMA (rows (q 0-15 | 16-31, hi, bb) after the swap)
+  auto softmax_p = [&](const float16_t* st, half8_t (*pb)[2]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      H8 a, bq, r0, r1;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        a.h[j] = (half_t)__builtin_amdgcn_exp2f(st[u][j]);
+        bq.h[j] = (half_t)__builtin_amdgcn_exp2f(st[u][8 + j]);
+      }
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const auto sw = __builtin_amdgcn_permlane16_swap(a.w[k], bq.w[k], false, false);
+        r0.w[k] = sw[0];
+        r1.w[k] = sw[1];
+      }
+      pb[u][0] = r0.h;
+      pb[u][1] = r1.h;
+    }
+  };
+  auto pv = [&](const half_t* Vt, const half8_t (*pb)[2], float4_t (*o)[2]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < NDT; ++i)
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const half8_t vf = *reinterpret_cast<const half8_t*>(Vt + i * 16 * VT_LD + (u ? v_frag1 : v_frag0));
+        o[i][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf, pb[u][0], o[i][0], 0, 0, 0);
+        o[i][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf, pb[u][1], o[i][1], 0, 0, 0);
+      }
+  };
+  auto tile_max = [&](const float16_t* st) __attribute__((always_inline)) {   // max over the 64 keys of the lane's query
+    float m0 = fmaxf(st[0][0], st[0][1]), m1 = fmaxf(st[1][0], st[1][1]);     // (two chains of v_max3_f32)
+#pragma unroll
+    for (int r = 2; r < 16; r += 2) {
+      m0 = fmaxf(fmaxf(m0, st[0][r]), st[0][r + 1]);
+      m1 = fmaxf(fmaxf(m1, st[1][r]), st[1][r + 1]);
+    }
+    m0 = fmaxf(m0, m1);
+    const auto sw = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, m0), __builtin_bit_cast(unsigned, m0), false, false);
+    return fmaxf(__builtin_bit_cast(float, (unsigned)sw[0]), __builtin_bit_cast(float, (unsigned)sw[1]));              // lanes l and l ^ 32 hold the two key halves
+  };
+  // st holds s' - m (log2 units).  The folded maximum is raised when some row's tile maximum is more than 6 above it (P <= 64
+  // in f16) or on the first tile; O and the pending scores move to the new maximum, nothing else is live at the old one.
+  auto decide = [&](float16_t* st, float4_t (*o)[2], half8_t* qf, float& m_run, bool force) __attribute__((always_inline)) {
+    const float mx = tile_max(st);
+    if (force || __any(mx > 6.0f)) {
+      const bool up = force || mx > 0.f;
+      const float m_new = up ? (float)(half_t)(m_run + mx) : m_run;
+      const float delta = m_new - m_run;                     // exact: both are f16 values
+      const float alpha = __builtin_amdgcn_exp2f(-delta);    // (accumulators are 0 on the first tile)
+      const float a0 = __shfl(alpha, dl, 64), a1 = __shfl(alpha, dl + 16, 64);   // accumulator columns: q = dl + 16 qt
+#pragma unroll
+      for (int i = 0; i < NDT; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          o[i][0][r] *= a0;
+          o[i][1][r] *= a1;
+        }
+#pragma unroll
+      for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) st[u][r] -= delta;
+      m_run = m_new;
+      if (hi) qf[NS - 1][0] = (half_t)(-m_new);              // contraction slot 40: k block 2, upper lane half, element 0
+    }
+  };
+
+  const int nt = p.Nk / KV;
+  float16_t stA[2], stB[2];
+  half8_t pbuf[2][2];
+  // prologue: K(0), V(0), K(1) staged; S_A(0) and its (forced) decision
+  load_k(0);
+  load_v(0);
+  store_k(0);
+  store_v(0);
+  load_k(1);
+  store_k(1);
+  __syncthreads();
+  qk(Ks, qfA, stA);
+  decide(stA, oA, qfA, mA, true);
+
+  int ks0 = 0, ks1 = 1, ks2 = 2;   // ring stages of K(t), K(t + 1), K(t + 2)
+  // one iteration = tile t for both sub-blocks; MORE: tile t + 1 exists (its S_A is started here).  MORE / FIRST are literal
+  // constants at the call sites, so each half of the steady-state iteration is ONE basic block (MFMA and VALU interleave).
+  auto iteration = [&](int t, const bool FIRST, const bool MORE) __attribute__((always_inline)) {
+    load_k(min(t + 2, nt - 1));    // (clamped: the last two iterations restage a tile nobody reads again)
+    load_v(min(t + 1, nt - 1));
+    __builtin_amdgcn_sched_barrier(0);
+    const half_t* Vt = Vts + (t & 1) * V_TILE;
+    qk(Ks + ks0 * K_TILE, qfB, stB);             // seg 1
+    softmax_p(stA, pbuf);
+    pv(Vt, pbuf, oA);                            // seg 2
+    decide(stB, oB, qfB, mB, FIRST);
+    if (MORE) qk(Ks + ks1 * K_TILE, qfA, stA);   // seg 3
+    softmax_p(stB, pbuf);
+    pv(Vt, pbuf, oB);                            // seg 4
+    if (MORE) decide(stA, oA, qfA, mA, false);
+    store_k(ks2);
+    store_v((t & 1) ^ 1);
+    __syncthreads();
+    const int k_ = ks0;
+    ks0 = ks1;
+    ks1 = ks2;
+    ks2 = k_;
+  };
+  iteration(0, true, true);        // nt >= 2
+  for (int t = 1; t + 1 < nt; ++t) iteration(t, false, true);
+  iteration(nt - 1, false, false);
+
+  // ---- epilogue: O[q, d] = O^T[d, q] / l; l = row 40 of O^T (d tile 2, local row 8 = lane row 2, register 0) ----
+  auto store_o = [&](float4_t (*o)[2], int qs) __attribute__((always_inline)) {
+    const float l0 = __shfl(o[2][0][0], 32 + dl, 64), l1 = __shfl(o[2][1][0], 32 + dl, 64);
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt) {
+      const int q = qs + qt * 16 + dl;
+      const float inv = 1.0f / (qt ? l1 : l0);
+      if (q < p.Nq) {
+        half_t* op = p.O + (long)b * p.o_bs + (long)q * p.ldo + h * D;
+#pragma unroll
+        for (int i = 0; i < NDT; ++i) {
+          const int d0 = i * 16 + 4 * kg;
+          if (d0 < D) {
+            half4_t ov;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) ov[e] = (half_t)(o[i][qt][e] * inv);
+            *reinterpret_cast<half4_t*>(op + d0) = ov;
+          }
+        }
+      }
+    }
+  };
+  store_o(oA, q0);
+  store_o(oB, q0 + 32);
+}
+
+}  // namespace
+
+bool pfd_attention3_takes(const AttnParams& p) {
+  // whole 64-key tiles, at least two of them; enough 256-query blocks to give every CU one
+  // (PFD_ATTN3_FORCE=1: test hook -- selftest --attn, tools/cpu_emu -- that takes small grids too)
+  static const bool force = getenv("PFD_ATTN3_FORCE") && atoi(getenv("PFD_ATTN3_FORCE")) != 0;
+  if (p.D != 40 || p.Nk % 64 != 0 || p.Nk < 128) return false;
+  return force || (p.Nq >= 256 && (long)p.B * p.H * ((p.Nq + 255) / 256) >= 256);
+}
+
+void pfd_attention3_launch(const AttnParams& p, hipStream_t s) {
+  dim3 grid(((p.Nq + 255) / 256) * p.H * p.B);
+  hipLaunchKernelGGL(attention3_kernel, grid, dim3(256), 0, s, p);
+}

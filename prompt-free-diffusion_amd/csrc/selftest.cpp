@@ -1638,6 +1638,9 @@ int main(int argc, char** argv) {
     run_attn_case(1, 2, 520, 1000, 40, false, 700);   // maximum jumps at key 700 (tile 10 of 16)
     run_attn_case(2, 2, 512, 256, 40, true, 130);
     run_attn_case(1, 2, 300, 148, 40, false, 140);    // ... inside the ragged tile
+    run_attn_case(1, 2, 512, 1024, 40, true, 700);    // round 6: whole 64-key tiles (attention3_kernel when PFD_ATTN3_FORCE=1 or the grid is big)
+    run_attn_case(1, 1, 700, 640, 40, false, 333);    // ragged last query block
+    run_attn_case(8, 8, 1024, 1024, 40, true, 500);   // 256 blocks: attention3_kernel by the dispatcher's own rule
     printf("SELFTEST %d/%d passed, %d failed\n", g_total - g_fail, g_total, g_fail);
     return g_fail;
   }
@@ -1654,6 +1657,8 @@ int main(int argc, char** argv) {
   }
   if (argc > 1 && !strcmp(argv[1], "--bench-attn")) {
     bench_attn("self-attn 64^2 d40", 8, 8, 4096, 4096, 40);
+    bench_attn("self-attn 64^2 d40 (CFG prefix)", 4, 8, 4096, 4096, 40);
+    bench_attn("self-attn 96^2 d40 (C5)", 4, 8, 9216, 9216, 40);
     bench_attn("self-attn 32^2 d80", 8, 8, 1024, 1024, 80);
     bench_attn("self-attn 16^2 d160", 8, 8, 256, 256, 160);
     bench_attn("cross-attn 64^2 d40", 4, 8, 4096, 148, 40);

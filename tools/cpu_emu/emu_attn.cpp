@@ -16,6 +16,7 @@ int pfd_check_launch(const char*) { return 0; }
 void pfd_set_error(const char*) {}
 
 #include "attention_emu.inc"
+#include "attention3_kernel.h"   // round 6: the software-pipelined d = 40 kernel (no inline asm: included as it is)
 
 typedef _Float16 h16;
 static std::mt19937 rng(11);
@@ -27,10 +28,13 @@ static std::vector<h16> rand_h(size_t n, float scale) {
 }
 static int g_fail = 0, g_total = 0;
 
-static void run_case(int B, int H, int Nq, int Nk, int D) {
+static void run_case(int B, int H, int Nq, int Nk, int D, int spike = 0) {
   const int C = H * D;
   const long nkp = (Nk + 7) / 8 * 8;
   auto Q = rand_h((size_t)B * Nq * C, 1.5f), K = rand_h((size_t)B * Nk * C, 1.5f), V = rand_h((size_t)B * Nk * C, 1.f);
+  if (spike > 0 && spike < Nk)   // key `spike` = 4 x query (spike % Nq): the row maximum jumps in the middle of the stream
+    for (int b = 0; b < B; ++b)
+      for (int c = 0; c < C; ++c) K[((size_t)b * Nk + spike) * C + c] = (h16)(4.0f * (float)Q[((size_t)b * Nq + spike % Nq) * C + c]);
   std::vector<h16> Vt((size_t)C * B * nkp, (h16)0.f), O((size_t)B * Nq * C, (h16)-9.f);
   for (int b = 0; b < B; ++b)
     for (int j = 0; j < Nk; ++j)
@@ -78,6 +82,16 @@ static void run_case(int B, int H, int Nq, int Nk, int D) {
 int main(int argc, char** argv) {
   bool quick = false, force8 = true;
   for (int i = 1; i < argc; ++i) {
+    if (!strcmp(argv[i], "--a3")) {       // attention3_kernel: whole 64-key tiles; one block / ragged queries / three heads
+      setenv("PFD_ATTN3_FORCE", "1", 1);
+      run_case(1, 1, 256, 192, 40);
+      run_case(1, 2, 300, 128, 40);
+      run_case(2, 1, 256, 320, 40);
+      run_case(1, 1, 256, 320, 40, 200);   // deferred rescale taken in tile 3 (sub-block A or B by the query's position)
+      run_case(1, 1, 256, 256, 40, 100);   // ... in tile 1, query 100 = sub-block B of wave 1
+      printf("%d cases, %d failed\n", g_total, g_fail);
+      return g_fail;
+    }
     quick = quick || !strcmp(argv[i], "--quick");
     if (!strcmp(argv[i], "--w4")) force8 = false;   // the 4-wave d = 40 form (what small launches take)
   }

@@ -238,3 +238,19 @@ static inline emu_u2 emu_permlane16_swap(unsigned a, unsigned b) {
   return r;
 }
 #define __builtin_amdgcn_permlane16_swap(a, b, fi, bc) emu_permlane16_swap(a, b)
+// v_permlane32_swap: the upper 32 lanes of the first operand trade places with the lower 32 lanes of the second
+// ({a', b'}: a' = a.lo b.lo, b' = a.hi b.hi)
+static inline emu_u2 emu_permlane32_swap(unsigned a, unsigned b) {
+  emu::Wave& w = emu::wave();
+  const int l = emu::lane();
+  w.slot[l] = ((uint64_t)b << 32) | a;
+  emu::wave_sync();
+  auto A = [&](int lane) { return (unsigned)(w.slot[lane] & 0xffffffffu); };
+  auto B = [&](int lane) { return (unsigned)(w.slot[lane] >> 32); };
+  emu_u2 r;
+  r.v[0] = l < 32 ? A(l) : B(l - 32);
+  r.v[1] = l < 32 ? A(l + 32) : B(l);
+  emu::wave_sync();
+  return r;
+}
+#define __builtin_amdgcn_permlane32_swap(a, b, fi, bc) emu_permlane32_swap(a, b)
