@@ -1,0 +1,121 @@
+// Micro-benchmark (round 6): how much vector work hides beside matrix work on ONE gfx950 SIMD, by who issues it.
+//   body = NM MFMAs on independent accumulators + NV vector instructions on independent registers, interleaved by the compiler
+//   under sched_group_barrier (1 MFMA, NV / NM VALU); 1 or 2 waves per SIMD (256- / 512-thread blocks, one block per CU);
+//   SPLIT: the first four waves of a 512-thread block issue only the MFMAs, the other four only the vector instructions.
+// Prints cycles per body per wave (clock64) and the wall time.   build: hipcc --offload-arch=gfx950 -O3 mfma_valu.hip -o mfma_valu
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <vector>
+
+typedef _Float16 half8_t __attribute__((ext_vector_type(8)));
+typedef float float4_t __attribute__((ext_vector_type(4)));
+typedef float float16_t __attribute__((ext_vector_type(16)));
+
+template <int NM, int NV, int VK, bool BIG, bool SPLIT>
+__global__ void k(const float* in, float* out, long long* cyc, int iters) {
+  const int tid = threadIdx.x, wave = tid >> 6;
+  half8_t a, b;
+  for (int e = 0; e < 8; ++e) { a[e] = (_Float16)in[(tid + e) & 255]; b[e] = (_Float16)in[(tid + 8 + e) & 255]; }
+  float4_t acc[8];
+  float16_t big[4];
+  for (int i = 0; i < 8; ++i) acc[i] = (float4_t){0.f, 0.f, 0.f, 0.f};
+  for (int i = 0; i < 4; ++i) for (int r = 0; r < 16; ++r) big[i][r] = 0.f;
+  float v[32];
+  for (int i = 0; i < 32; ++i) v[i] = in[(tid + i) & 255] * 1e-3f;
+  const bool do_m = !SPLIT || wave < 4, do_v = !SPLIT || wave >= 4;
+  __syncthreads();
+  const long long t0 = clock64();
+  for (int it = 0; it < iters; ++it) {
+    if (do_m) {
+#pragma unroll
+      for (int i = 0; i < NM; ++i) {
+        if (BIG) big[i & 3] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, big[i & 3], 0, 0, 0);
+        else acc[i & 7] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, acc[i & 7], 0, 0, 0);
+      }
+    }
+    if (do_v) {
+#pragma unroll
+      for (int i = 0; i < NV; ++i) {
+        float& x = v[i & 31];
+        if (VK == 0) x = __builtin_amdgcn_exp2f(x);
+        else if (VK == 1) x = __builtin_fmaf(x, 1.0001f, 1e-6f);
+        else if (VK == 2) x = __builtin_fmaxf(__builtin_fmaxf(x, v[(i + 1) & 31]), v[(i + 2) & 31]);
+      }
+    }
+    if constexpr (!SPLIT && NM > 0 && NV > 0) {
+      constexpr int PER = (NV + (NM > 0 ? NM : 1) - 1) / (NM > 0 ? NM : 1);
+#pragma unroll
+      for (int i = 0; i < NM; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x8, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x2, PER, 0);
+      }
+    }
+  }
+  const long long t1 = clock64();
+  float s = 0.f;
+  for (int i = 0; i < 8; ++i) s += acc[i][0] + acc[i][3];
+  for (int i = 0; i < 4; ++i) s += big[i][0] + big[i][15];
+  for (int i = 0; i < 32; ++i) s += v[i];
+  out[blockIdx.x * blockDim.x + tid] = s;
+  if ((tid & 63) == 0) cyc[blockIdx.x * (blockDim.x >> 6) + wave] = t1 - t0;
+}
+
+template <int NM, int NV, int VK, bool BIG, bool SPLIT>
+static void run(const char* label, int threads, const float* din, float* dout, long long* dcyc) {
+  const int iters = 20000, blocks = 256;
+  hipEvent_t e0, e1;
+  hipEventCreate(&e0); hipEventCreate(&e1);
+  hipLaunchKernelGGL((k<NM, NV, VK, BIG, SPLIT>), dim3(blocks), dim3(threads), 0, 0, din, dout, dcyc, 100);
+  hipDeviceSynchronize();
+  hipEventRecord(e0, 0);
+  hipLaunchKernelGGL((k<NM, NV, VK, BIG, SPLIT>), dim3(blocks), dim3(threads), 0, 0, din, dout, dcyc, iters);
+  hipEventRecord(e1, 0);
+  hipEventSynchronize(e1);
+  float ms = 0;
+  hipEventElapsedTime(&ms, e0, e1);
+  const int nw = blocks * threads / 64;
+  std::vector<long long> c(nw);
+  hipMemcpy(c.data(), dcyc, nw * sizeof(long long), hipMemcpyDeviceToHost);
+  double mean = 0;
+  for (auto x : c) mean += (double)x;
+  mean /= nw;
+  // clock64 = s_memtime (constant 100 MHz on gfx9) -- report wall ns per body too
+  printf("%-58s waves/SIMD %d  %8.3f ms  %8.2f ns/body  memtime ticks/body %7.2f\n", label, threads / 256, ms, ms * 1e6 / iters, mean / iters);
+  fflush(stdout);
+}
+
+int main() {
+  float *din, *dout;
+  long long* dcyc;
+  hipMalloc(&din, 256 * 4); hipMalloc(&dout, 256 * 512 * 4); hipMalloc(&dcyc, 256 * 8 * 8);
+  std::vector<float> h(256);
+  for (int i = 0; i < 256; ++i) h[i] = (float)(i % 17) * 0.01f;
+  hipMemcpy(din, h.data(), 1024, hipMemcpyHostToDevice);
+#define RUN(NM, NV, VK, BIG, SPLIT, T, L) run<NM, NV, VK, BIG, SPLIT>(L, T, din, dout, dcyc)
+  for (int T = 256; T <= 512; T += 256) {
+    RUN(8, 0, 0, false, false, T, "8 mfma16x16x32");
+    RUN(8, 0, 0, true, false, T, "8 mfma32x32x16");
+    RUN(0, 16, 0, false, false, T, "16 v_exp");
+    RUN(0, 16, 1, false, false, T, "16 v_fma");
+    RUN(0, 16, 2, false, false, T, "16 v_max3");
+    RUN(8, 8, 0, false, false, T, "8 mfma16 + 8 v_exp (one stream)");
+    RUN(8, 16, 0, false, false, T, "8 mfma16 + 16 v_exp (one stream)");
+    RUN(8, 32, 0, false, false, T, "8 mfma16 + 32 v_exp (one stream)");
+    RUN(8, 16, 1, false, false, T, "8 mfma16 + 16 v_fma (one stream)");
+    RUN(8, 32, 1, false, false, T, "8 mfma16 + 32 v_fma (one stream)");
+    RUN(8, 16, 0, true, false, T, "8 mfma32 + 16 v_exp (one stream)");
+    RUN(8, 32, 0, true, false, T, "8 mfma32 + 32 v_exp (one stream)");
+    RUN(8, 64, 0, true, false, T, "8 mfma32 + 64 v_exp (one stream)");
+    RUN(8, 32, 1, true, false, T, "8 mfma32 + 32 v_fma (one stream)");
+    RUN(8, 64, 1, true, false, T, "8 mfma32 + 64 v_fma (one stream)");
+  }
+  RUN(8, 16, 0, false, true, 512, "SPLIT: waves 0-3 8 mfma16 | waves 4-7 16 v_exp");
+  RUN(8, 32, 0, false, true, 512, "SPLIT: waves 0-3 8 mfma16 | waves 4-7 32 v_exp");
+  RUN(8, 32, 1, false, true, 512, "SPLIT: waves 0-3 8 mfma16 | waves 4-7 32 v_fma");
+  RUN(8, 64, 1, false, true, 512, "SPLIT: waves 0-3 8 mfma16 | waves 4-7 64 v_fma");
+  RUN(8, 32, 0, true, true, 512, "SPLIT: waves 0-3 8 mfma32 | waves 4-7 32 v_exp");
+  RUN(8, 64, 0, true, true, 512, "SPLIT: waves 0-3 8 mfma32 | waves 4-7 64 v_exp");
+  RUN(8, 128, 1, true, true, 512, "SPLIT: waves 0-3 8 mfma32 | waves 4-7 128 v_fma");
+  return 0;
+}
