@@ -32,7 +32,6 @@
 
 namespace {
 
-template <int ABL>   // ABL: timing ablations (round-6 experiment, results are garbage when != 0)
 __global__ __launch_bounds__(256, 2) void attention3_kernel(const AttnParams p) {
   constexpr int D = 40, KV = 64, K_LD = 56, VT_LD = 64, DV = 48, NS = 3, NDT = 3;
   constexpr int K_TILE = KV * K_LD, V_TILE = DV * VT_LD;
@@ -137,11 +136,6 @@ __global__ __launch_bounds__(256, 2) void attention3_kernel(const AttnParams p) 
 #pragma unroll
       for (int s = 0; s < NS; ++s) {
         const half8_t kf = *reinterpret_cast<const half8_t*>(Kt + k_frag + u * 32 * K_LD + s * 16);
-        if (ABL & 8) {
-#pragma unroll
-          for (int r = 0; r < 16; ++r) st[u][r] += (float)kf[r & 7] * (float)qf[s][r & 7];
-          continue;
-        }
         st[u] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[s], st[u], 0, 0, 0);
       }
     }
@@ -152,22 +146,13 @@ __global__ __launch_bounds__(256, 2) void attention3_kernel(const AttnParams p) 
   };
   // P^T of one sub-block and tile: pb[u][q tile] = the B operand of the 16x16x32 MFMA (rows (q 0-15 | 16-31, hi, bb) after the swap)
   auto softmax_p = [&](const float16_t* st, half8_t (*pb)[2]) __attribute__((always_inline)) {
-    if (ABL & 32) {
-#pragma unroll
-      for (int u = 0; u < 2; ++u)
-#pragma unroll
-        for (int q = 0; q < 2; ++q)
-#pragma unroll
-          for (int e = 0; e < 8; ++e) pb[u][q][e] = (half_t)st[u][0];
-      return;
-    }
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
       H8 a, bq, r0, r1;
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
-        a.h[j] = (half_t)((ABL & 1) ? st[u][j] : __builtin_amdgcn_exp2f(st[u][j]));
-        bq.h[j] = (half_t)((ABL & 1) ? st[u][8 + j] : __builtin_amdgcn_exp2f(st[u][8 + j]));
+        a.h[j] = (half_t)__builtin_amdgcn_exp2f(st[u][j]);
+        bq.h[j] = (half_t)__builtin_amdgcn_exp2f(st[u][8 + j]);
       }
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
@@ -185,11 +170,6 @@ __global__ __launch_bounds__(256, 2) void attention3_kernel(const AttnParams p) 
 #pragma unroll
       for (int u = 0; u < 2; ++u) {
         const half8_t vf = *reinterpret_cast<const half8_t*>(Vt + i * 16 * VT_LD + (u ? v_frag1 : v_frag0));
-        if (ABL & 4) {
-          o[i][0][0] += (float)vf[0] * (float)pb[u][0][0];
-          o[i][1][0] += (float)vf[1] * (float)pb[u][1][0];
-          continue;
-        }
         o[i][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf, pb[u][0], o[i][0], 0, 0, 0);
         o[i][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf, pb[u][1], o[i][1], 0, 0, 0);
       }
@@ -207,8 +187,7 @@ __global__ __launch_bounds__(256, 2) void attention3_kernel(const AttnParams p) 
   };
   // st holds s' - m (log2 units).  The folded maximum is raised when some row's tile maximum is more than 6 above it (P <= 64
   // in f16) or on the first tile; O and the pending scores move to the new maximum, nothing else is live at the old one.
-  auto decide = [&](float16_t* st, float4_t (*o)[2], half8_t* qf, float& m_run, bool force) __attribute__((always_inline)) {
-    const float mx = (ABL & 2) ? 0.f : tile_max(st);
+  auto decide = [&](float16_t* st, float4_t (*o)[2], half8_t* qf, float& m_run, float mx, bool force) __attribute__((always_inline)) {
     if (force || __any(mx > 6.0f)) {
       const bool up = force || mx > 0.f;
       const float m_new = up ? (float)(half_t)(m_run + mx) : m_run;
@@ -243,31 +222,27 @@ __global__ __launch_bounds__(256, 2) void attention3_kernel(const AttnParams p) 
   store_k(1);
   __syncthreads();
   qk(Ks, qfA, stA);
-  decide(stA, oA, qfA, mA, true);
+  decide(stA, oA, qfA, mA, tile_max(stA), true);
 
   int ks0 = 0, ks1 = 1, ks2 = 2;   // ring stages of K(t), K(t + 1), K(t + 2)
   // one iteration = tile t for both sub-blocks; MORE: tile t + 1 exists (its S_A is started here).  MORE / FIRST are literal
   // constants at the call sites, so each half of the steady-state iteration is ONE basic block (MFMA and VALU interleave).
   auto iteration = [&](int t, const bool FIRST, const bool MORE) __attribute__((always_inline)) {
-    if (!(ABL & 16)) {
-      load_k(min(t + 2, nt - 1));    // (clamped: the last two iterations restage a tile nobody reads again)
-      load_v(min(t + 1, nt - 1));
-    }
+    load_k(min(t + 2, nt - 1));    // (clamped: the last two iterations restage a tile nobody reads again)
+    load_v(min(t + 1, nt - 1));
     __builtin_amdgcn_sched_barrier(0);
     const half_t* Vt = Vts + (t & 1) * V_TILE;
     qk(Ks + ks0 * K_TILE, qfB, stB);             // seg 1
     softmax_p(stA, pbuf);
     pv(Vt, pbuf, oA);                            // seg 2
-    decide(stB, oB, qfB, mB, FIRST);
+    decide(stB, oB, qfB, mB, tile_max(stB), FIRST);
     if (MORE) qk(Ks + ks1 * K_TILE, qfA, stA);   // seg 3
     softmax_p(stB, pbuf);
     pv(Vt, pbuf, oB);                            // seg 4
-    if (MORE) decide(stA, oA, qfA, mA, false);
-    if (!(ABL & 16)) {
-      store_k(ks2);
-      store_v((t & 1) ^ 1);
-      __syncthreads();
-    }
+    if (MORE) decide(stA, oA, qfA, mA, tile_max(stA), false);
+    store_k(ks2);
+    store_v((t & 1) ^ 1);
+    __syncthreads();
     const int k_ = ks0;
     ks0 = ks1;
     ks1 = ks2;
@@ -315,18 +290,5 @@ bool pfd_attention3_takes(const AttnParams& p) {
 
 void pfd_attention3_launch(const AttnParams& p, hipStream_t s) {
   dim3 grid(((p.Nq + 255) / 256) * p.H * p.B);
-  static const int abl = getenv("PFD_ATTN3_ABL") ? atoi(getenv("PFD_ATTN3_ABL")) : 0;
-  switch (abl) {
-    case 1: hipLaunchKernelGGL(attention3_kernel<1>, grid, dim3(256), 0, s, p); break;
-    case 2: hipLaunchKernelGGL(attention3_kernel<2>, grid, dim3(256), 0, s, p); break;
-    case 3: hipLaunchKernelGGL(attention3_kernel<3>, grid, dim3(256), 0, s, p); break;
-    case 4: hipLaunchKernelGGL(attention3_kernel<4>, grid, dim3(256), 0, s, p); break;
-    case 8: hipLaunchKernelGGL(attention3_kernel<8>, grid, dim3(256), 0, s, p); break;
-    case 12: hipLaunchKernelGGL(attention3_kernel<12>, grid, dim3(256), 0, s, p); break;
-    case 16: hipLaunchKernelGGL(attention3_kernel<16>, grid, dim3(256), 0, s, p); break;
-    case 34: hipLaunchKernelGGL(attention3_kernel<34>, grid, dim3(256), 0, s, p); break;
-    case 50: hipLaunchKernelGGL(attention3_kernel<50>, grid, dim3(256), 0, s, p); break;
-    case 28: hipLaunchKernelGGL(attention3_kernel<28>, grid, dim3(256), 0, s, p); break;
-    default: hipLaunchKernelGGL(attention3_kernel<0>, grid, dim3(256), 0, s, p); break;
-  }
+  hipLaunchKernelGGL(attention3_kernel, grid, dim3(256), 0, s, p);
 }

@@ -1453,7 +1453,8 @@ static int replay(const char* path, bool timed = false, int force_tile = 0) {
       if (q[19] > 0) { d.k_split = (int)q[19]; d.A2 = dA.p + (size_t)d.M * d.k_split; d.lda = d.k_split; d.lda2 = d.K - d.k_split; }
       d.zero_rows = (int)q[20];
       if (q[21]) d.gn_out = dGnO.p;
-      if (timed) {
+      static const bool replay_warm = getenv("PFD_REPLAY_WARM") && atoi(getenv("PFD_REPLAY_WARM")) != 0;   // weights of every launch from ONE buffer (cache-warm): the bound of any weight prefetch
+      if (timed && !replay_warm) {
         const size_t wn = ((size_t)d.N * d.K + 4095) & ~(size_t)4095;
         if (pool_off + wn > pool_elems) pool_off = 0;
         d.W = dPool.p + pool_off;
