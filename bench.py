@@ -194,8 +194,12 @@ def main():
             raise SystemExit(f"bench.py: {world} ranks for {torch.cuda.device_count()} visible GPU(s): one process per GPU")
         torch.cuda.set_device(local)
     dev = f'cuda:{local}' if on_gpu else 'cpu'
-    if world > 1:
+    # PFD_FORCE_COLLECTIVE=1: a process group (and the path's collectives) at world size 1 too -- the one-GPU RCCL smoke
+    forced = os.environ.get("PFD_FORCE_COLLECTIVE") == "1"
+    if world > 1 or forced:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if forced and world == 1:
+            os.environ.setdefault("MASTER_PORT", "29531")
         try:
             dist.init_process_group(args.backend, rank=rank, world_size=world,   # "nccl" == RCCL on ROCm
                                     timeout=datetime.timedelta(seconds=args.pg_timeout))
@@ -247,7 +251,7 @@ def main():
         step(i)
 
     def barrier():
-        if world > 1:
+        if world > 1 or forced:
             if on_gpu:
                 dist.barrier(device_ids=[local])   # (explicit device: no guess from the rank, no warning, no wrong-GPU context)
             else:
@@ -299,8 +303,9 @@ def main():
                                    f"{args.ddim_steps}-step DDIM ({ddim_real} real steps), CFG {args.scale}, fp16, "
                                    f"batch={args.batch}/GPU, {args.batch if args.per_sample_image else 1} SeeCoder encode(s) + VAE decode per batch",
                        "global_batch": n_global, "parallelism": f"dp{world}",
-                       "world_size_reported_by_backend": dist.get_world_size() if world > 1 else 1,
-                       "backend": (args.backend + (" (RCCL)" if args.backend == "nccl" else "")) if world > 1 else None},
+                       "world_size_reported_by_backend": dist.get_world_size() if (world > 1 or forced) else 1,
+                       "backend": (args.backend + (" (RCCL)" if args.backend == "nccl" else "")) if (world > 1 or forced) else None,
+                       "collectives_forced_at_world_1": bool(forced and world == 1)},
         }
         if args.stub:
             res["data"] = "stub (CPU stand-ins for the GPU compute: launcher / collective test only, not a measurement)"
@@ -367,7 +372,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(net, args.height, args.width, ddim_real, args.scale)
         print(json.dumps(res))
-    if world > 1:
+    if world > 1 or forced:
         dist.destroy_process_group()
 
 

@@ -311,6 +311,127 @@ int launch(const GemmParams& p0, hipStream_t s) {
   return pfd_check_launch("pfd_gemm_f16");
 }
 
+// ------------------------------------------------------------------------------------------------
+// conv3x3_narrow_kernel (round 6): 3x3 / stride 1 / pad 1 convolution with N <= 16 output channels -- the UNet head
+// (GroupNorm -> SiLU -> conv 320 -> 4, openaimodel.py:2732-2737 of the reference), the VAE's conv_out (128 -> 3).  The 64 x 64
+// tile of gemm_conv_kernel spent 60 of its 64 columns on padding (32768 x 4 x 2880: 52 us, 14 TFLOP/s).  Here:
+//   * a block = 64 consecutive output pixels of one image row (16 per wave); per 64-channel block of the input it stages the
+//     3 x 66-pixel patch once (global -> registers -> LDS, next block's loads in flight under the MFMAs, one barrier per
+//     channel block; pixels outside the image are zeros) and all nine taps read shifted pixels of it;
+//   * v_mfma_f32_16x16x32_f16 with the WEIGHTS as the A operand (row n = lane & 15, rows >= N alias row 0 and are never
+//     stored) and the activations as B (column = pixel): the accumulator holds, per lane, output channels 4 (lane >> 4) + r
+//     of ONE pixel -- the lanes of row group 0 store 8 contiguous bytes per pixel for N = 4;
+//   * weights come straight from global memory (N x K x 2 bytes <= 92 KB for the whole launch: L1 / L2 resident), the 18
+//     fragments of a channel block requested before its barrier;
+//   * 144-byte pixel pitch in LDS (9 x 16 bytes: every 16-lane group of a ds_read_b128 hits 16 different bank quads).
+// Algorithmic work: 2 M N K flops; bytes = input image once + weights + output.
+constexpr int NRW_PX = 64, NRW_PW = NRW_PX + 2, NRW_PATCH = 3 * NRW_PW, NRW_PITCH = BK + 8;
+constexpr int NRW_CHUNKS = NRW_PATCH * (BK / 8), NRW_PT = (NRW_CHUNKS + 255) / 256;
+
+__global__ __launch_bounds__(256) void conv3x3_narrow_kernel(const GemmParams p) {
+  __shared__ __attribute__((aligned(16))) half_t lds[2][NRW_PATCH * NRW_PITCH];
+  typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, kg = lane >> 4;
+  const int segs = (p.Wd + NRW_PX - 1) / NRW_PX;
+  const int seg = blockIdx.x % segs, y = (blockIdx.x / segs) % p.H, b = blockIdx.x / (segs * p.H);
+  const int x0 = seg * NRW_PX;
+  const int ncb = p.Cin / BK;
+
+  // staging: chunk c = tid + 256 j: patch pixel c >> 3 (row (c >> 3) / 66, column (c >> 3) % 66), 16-byte channel chunk c & 7
+  const half_t* src[NRW_PT];
+  int dst[NRW_PT];
+  bool live[NRW_PT], inside[NRW_PT];
+#pragma unroll
+  for (int j = 0; j < NRW_PT; ++j) {
+    const int c = tid + 256 * j;
+    live[j] = c < NRW_CHUNKS;
+    const int pp = min(c, NRW_CHUNKS - 1) >> 3, cc = c & 7;
+    const int pr = pp / NRW_PW, px = pp - pr * NRW_PW;
+    const int yy = y + pr - 1, xx = x0 + px - 1;
+    inside[j] = yy >= 0 && yy < p.H && xx >= 0 && xx < p.Wd;
+    const int yc = min(max(yy, 0), p.H - 1), xc = min(max(xx, 0), p.Wd - 1);   // unconditional loads from a valid pixel, masked below
+    src[j] = p.A + (((long)b * p.H + yc) * p.Wd + xc) * p.lda + cc * 8;
+    dst[j] = pp * NRW_PITCH + cc * 8;
+  }
+  u32x4 reg[NRW_PT];
+  auto load_patch = [&](int cb) __attribute__((always_inline)) {
+#pragma unroll
+    for (int j = 0; j < NRW_PT; ++j) reg[j] = *reinterpret_cast<const u32x4*>(src[j] + cb * BK);
+  };
+  auto store_patch = [&](int stage) __attribute__((always_inline)) {
+#pragma unroll
+    for (int j = 0; j < NRW_PT; ++j) {
+      const u32x4 v = inside[j] ? reg[j] : (u32x4){0u, 0u, 0u, 0u};
+      if (live[j]) *reinterpret_cast<u32x4*>(&lds[stage][dst[j]]) = v;
+    }
+  };
+  // weight fragment of (tap, k half): row (l15 < N ? l15 : 0), 8 halfs at tap * Cin + cb * 64 + ks * 32 + kg * 8
+  const half_t* wrow = p.W + (long)(l15 < p.N ? l15 : 0) * p.ldw + kg * 8;
+  const int xfrag = (wave * 16 + l15) * NRW_PITCH + kg * 8;   // + (ky * 66 + kx) * PITCH + ks * 32
+
+  float4_t acc = {0.f, 0.f, 0.f, 0.f};
+  load_patch(0);
+  store_patch(0);
+  for (int cb = 0; cb < ncb; ++cb) {
+    if (cb + 1 < ncb) load_patch(cb + 1);
+    half8_t wf[9][2];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) wf[t][ks] = *reinterpret_cast<const half8_t*>(wrow + (long)t * p.Cin + cb * BK + ks * 32);
+    __syncthreads();
+    const half_t* L = lds[cb & 1];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+      const int ky = t / 3, kx = t - ky * 3;
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        const half8_t xf = *reinterpret_cast<const half8_t*>(L + xfrag + (ky * NRW_PW + kx) * NRW_PITCH + ks * 32);
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[t][ks], xf, acc, 0, 0, 0);
+      }
+    }
+    if (cb + 1 < ncb) store_patch((cb + 1) & 1);
+  }
+  // epilogue: lane (pixel l15, row group kg) holds channels 4 kg + r
+  const int x = x0 + wave * 16 + l15, n0 = 4 * kg;
+  if (x < p.Wd && n0 < p.N) {
+    const long m = ((long)b * p.H + y) * p.Wd + x;
+    half_t o[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int n = min(n0 + r, p.N - 1);
+      o[r] = (half_t)(acc[r] + (p.bias ? (float)p.bias[n] : 0.f));
+    }
+    half_t* cp = p.C + m * p.ldc + n0;
+    if (n0 + 4 <= p.N && (p.ldc & 3) == 0 && (reinterpret_cast<uintptr_t>(p.C) & 7) == 0) {
+      Pack8 q;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) q.e[r] = o[r];
+      *reinterpret_cast<uint2*>(cp) = q.u;
+    } else {
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        if (n0 + r < p.N) cp[r] = o[r];
+    }
+  }
+}
+
+// the narrow-output 3x3 convolution: shapes conv3x3_narrow_kernel serves
+static bool narrow_conv_takes(const GemmParams& p) {
+  return p.ksize == 3 && p.stride == 1 && p.pad == 1 && !p.ups && p.Ho == p.H && p.Wo == p.Wd && p.N <= 16 && p.Cin % BK == 0 &&
+         !p.rowvec && !p.R && p.act == PFD_ACT_NONE && !p.bias_per_row;
+}
+
+static int launch_narrow_conv(const GemmParams& p, hipStream_t s) {
+  const bool prof = pfd_prof_on();
+  if (prof)
+    pfd_prof_begin(20, 2.0 * p.M * p.N * p.K, 2.0 * p.B * p.H * p.Wd * p.Cin + 2.0 * p.N * p.K + 2.0 * p.M * p.N, s);
+  const int segs = (p.Wd + NRW_PX - 1) / NRW_PX;
+  hipLaunchKernelGGL(conv3x3_narrow_kernel, dim3(segs * p.H * p.B), dim3(256), 0, s, p);
+  if (prof) pfd_prof_end(s);
+  return pfd_check_launch("pfd_gemm_f16(conv3x3 narrow)");
+}
+
 }  // namespace
 
 int pfd_gemm160_try(const PfdGemmDesc* d, int variant, int splits, hipStream_t s);  // gemm_glds.hip
@@ -388,6 +509,7 @@ extern "C" int pfd_gemm_f16_ex(const PfdGemmDesc* d, int32_t tile, pfd_stream_t 
   }
   if (p.act < PFD_ACT_NONE || p.act > PFD_ACT_GEGLU) return PFD_EINVAL;
   hipStream_t s = (hipStream_t)stream;
+  if (tile == 0 && narrow_conv_takes(p)) return launch_narrow_conv(p, s);
   if (p.act == PFD_ACT_GEGLU) {
     // N % 160 == 0 is packed in pairs for the wide-tile kernel (pfd_gemm_geglu_group): if that kernel declined
     // the call (unaligned C / ldc, forced tile), running the 32-block-interleave kernel here would pair the

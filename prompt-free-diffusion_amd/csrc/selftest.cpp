@@ -303,6 +303,16 @@ static void run_gemm_case(const GemmCase& c) {
 }
 
 // K-tile-contiguous weights (PfdGemmDesc.w_tiled): every wide-tile kernel family, both tile widths, conv K walks, split-K
+// conv3x3_narrow_kernel (round 6): 3x3 convolutions with N <= 16 output channels
+static void run_narrow_conv_cases() {
+  run_gemm_case({0, 4, 0, 0, true, false, false, false, 0, 0, 3, 1, 1, 0, 2, 16, 64, 320});    // the UNet head: 320 -> 4 on a 64-wide image
+  run_gemm_case({0, 3, 0, 0, true, false, false, false, 0, 0, 3, 1, 1, 0, 1, 12, 40, 128});    // N = 3 (VAE conv_out), one ragged segment
+  run_gemm_case({0, 4, 0, 0, false, false, false, false, 0, 8, 3, 1, 1, 0, 1, 9, 96, 64});     // no bias, ld + 8, 64 + 32 pixel segments
+  run_gemm_case({0, 8, 0, 0, true, false, false, false, 0, 0, 3, 1, 1, 0, 1, 8, 16, 512});     // N = 8: two row groups store
+  run_gemm_case({0, 13, 0, 0, true, false, false, false, 0, 0, 3, 1, 1, 0, 1, 5, 130, 64});    // N = 13: element stores, three segments
+  run_gemm_case({0, 4, 0, PFD_ACT_SILU, true, false, false, false, 0, 0, 3, 1, 1, 0, 1, 8, 64, 64});   // an activation: the general kernel
+}
+
 static void run_tiled_weight_cases() {
   for (int v : {0, 3200, 3300, 3400, 3500, 5400, 5800, 5100, 5300, 9200, 9300}) {
     GemmCase a{700, 320, 1024, 0, true, true, true, false, v}; a.w_tiled = 1; run_gemm_case(a);
@@ -1618,6 +1628,16 @@ int main(int argc, char** argv) {
     printf("SELFTEST %d/%d passed, %d failed\n", g_total - g_fail, g_total, g_fail);
     return g_fail;
   }
+  if (argc > 1 && !strcmp(argv[1], "--narrow")) {   // conv3x3_narrow_kernel: cases + the two shapes of the pipeline
+    run_narrow_conv_cases();
+    bench_gemm("unet head conv 320->4 @64^2 B8", 8 * 4096, 4, 2880, 3, 8, 64, 320, 0);
+    bench_gemm("unet head conv 320->4 @96^2 B4", 4 * 9216, 4, 2880, 3, 4, 96, 320, 0);
+    bench_gemm("vae conv_out 128->3 @512^2 B4", 4 * 262144, 3, 1152, 3, 4, 512, 128, 0);
+    bench_gemm("unet head conv, round-5 kernel", 8 * 4096, 4, 2880, 3, 8, 64, 320, 11);
+    bench_gemm("vae conv_out, round-5 kernel", 4 * 262144, 3, 1152, 3, 4, 512, 128, 21);
+    printf("SELFTEST %d/%d passed, %d failed\n", g_total - g_fail, g_total, g_fail);
+    return g_fail;
+  }
   if (argc > 1 && !strcmp(argv[1], "--ln")) {
     run_ln_fold_suite();
     printf("SELFTEST %d/%d passed, %d failed\n", g_total - g_fail, g_total, g_fail);
@@ -1788,6 +1808,7 @@ int main(int argc, char** argv) {
     run_gemm_case({0, 160, 0, 0, true, true, false, false, 3402, 0, 3, 1, 1, 1, 1, 5, 6, 128});           // upsample + split
     run_gemm_case({0, 320, 0, 0, true, false, false, false, 0, 8, 3, 2, 0, 0, 1, 9, 9, 64});               // pad 0, ld+8
     run_gemm_case({0, 160, 0, 0, true, false, false, false, 0, 0, 1, 1, 0, 0, 2, 6, 6, 128});              // 1x1 as conv
+    run_narrow_conv_cases();
 
     run_gemm_case({0, 160, 0, PFD_ACT_SILU, true, true, true, false, 0, 0, 3, 1, 1, 0, 1, 16, 48, 128});   // patch kernel, 2-D tiles
     run_gemm_case({0, 320, 0, 0, true, true, true, false, 0, 0, 3, 1, 1, 0, 2, 8, 96, 64});

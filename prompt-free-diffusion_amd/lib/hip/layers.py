@@ -88,7 +88,7 @@ def fold_layernorm(w, b, gamma, beta):
     g32, be32 = gamma.detach().float(), beta.detach().float()
     wg = (w32 * g32[None, :]).to(torch.float16).contiguous()
     cs = wg.float().sum(1).contiguous()
-    bp = w32 @ be32
+    bp = (w32 * be32[None, :]).sum(1)     # (elementwise + row sum, not `w32 @ be32`: no rocBLAS gemv inside lib/)
     if b is not None:
         bp = bp + b.float()
     return wg, cs, bp.to(torch.float16).contiguous()

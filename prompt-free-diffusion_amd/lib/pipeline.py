@@ -12,6 +12,8 @@ samples [r*n/P, (r+1)*n/P) of the global batch.  x_T is drawn ONCE for the globa
 CPU generator and sliced, so results do not depend on P.  The only collective is one RCCL
 all-gather of the decoded images after the loop (`gather=True`).
 """
+import os
+
 import torch
 
 from .hip import ops
@@ -55,9 +57,19 @@ def shard_xT(n_global, height, width, seed, rank, world_size):
     return torch.randn([n_global, 4, height // 8, width // 8], generator=g)[rank * n:(rank + 1) * n]
 
 
+def force_collective():
+    """PFD_FORCE_COLLECTIVE=1 with an initialised process group: the collectives run even at world size 1 -- the
+    one-GPU RCCL smoke (tests/test_hip_parity.py::test_rccl_one_rank_collectives, `bench.py --gpus 1` under that
+    environment): communicator creation, all_gather and all_reduce on an MI355X without a multi-GPU node"""
+    if os.environ.get("PFD_FORCE_COLLECTIVE") != "1":
+        return False
+    import torch.distributed as dist
+    return dist.is_available() and dist.is_initialized()
+
+
 def all_gather_batch(local, world_size):
     """the one collective of the path: concatenate every rank's shard in rank order"""
-    if world_size == 1:
+    if world_size == 1 and not force_collective():
         return local
     import torch.distributed as dist
     out = [torch.empty_like(local) for _ in range(world_size)]
@@ -139,7 +151,7 @@ class _Marks:
 
 def max_over_ranks(seconds, world_size, device='cpu'):
     """the timing reduction of bench.py: a step is as slow as its slowest rank"""
-    if world_size == 1:
+    if world_size == 1 and not force_collective():
         return float(seconds)
     import torch.distributed as dist
     t = torch.tensor([float(seconds)], device=device, dtype=torch.float64)

@@ -155,3 +155,19 @@ def test_bench_launcher_fails_loudly_instead_of_hanging():
     # a world size that contradicts --gpus is an error message, not a hang
     r = _bench("--gpus", "2", env={"WORLD_SIZE": "1"})
     assert r.returncode != 0 and "WORLD_SIZE=1" in (r.stderr + r.stdout)
+
+
+def test_forced_collectives_at_world_size_one():
+    """PFD_FORCE_COLLECTIVE=1: `bench.py --gpus 1` creates a 1-rank process group and the pipeline's all_gather /
+    barrier / max-over-ranks all_reduce run through it (gloo + stub here; the same switch drives the one-GPU RCCL
+    smoke, tests/test_hip_parity.py::test_rccl_one_rank_collectives)"""
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, PFD_FORCE_COLLECTIVE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), RANK="0",
+               LOCAL_RANK="0", WORLD_SIZE="1")
+    r = subprocess.run([sys.executable, os.path.join(repo, "bench.py"), "--gpus", "1", "--steps", "1", "--warmup", "1",
+                        "--stub", "--backend", "gloo"], env=env, capture_output=True, text=True, timeout=300)
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert r.returncode == 0 and len(lines) == 1, r.stdout[-1500:] + r.stderr[-1500:]
+    d = json.loads(lines[0])
+    assert d["config"]["backend"] == "gloo" and d["config"]["collectives_forced_at_world_1"] is True
+    assert d["config"]["world_size_reported_by_backend"] == 1 and d["n_gpus"] == 1

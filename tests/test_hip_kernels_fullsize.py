@@ -383,3 +383,18 @@ def test_wide_512x768_unet_and_vae_vs_oracle(net, param_shapes):
     img = net.vae_decode(z.cuda().half(), 'image')
     assert img.shape == (1, 3, 512, 768)
     check("VAE decode 512x768", img, O.vae_decode(seeded_sd(param_shapes, "vae.image."), "vae.image.", z))
+
+
+def test_1024x768_unet_eps_vs_oracle(net, param_shapes):
+    """One numeric check above 768^2: apply_model at a 128 x 96 latent (1024 x 768 image; 12 288 tokens,
+    192 whole 64-key tiles: the software-pipelined d = 40 attention kernel of round 6, patch tiles on 96-wide rows) against the
+    oracle on the conditional sample -- test_tall_and_wide_resolutions checks shape / range / finiteness only"""
+    import pfd_oracle as O
+    _threads()
+    g = torch.Generator().manual_seed(22)
+    x = torch.randn((1, 4, 128, 96), generator=g)
+    cond = torch.randn((1, 148, 768), generator=g)
+    xx, t, c = torch.cat([x, x]), torch.full((2,), 601, dtype=torch.long), torch.cat([torch.zeros_like(cond), cond])
+    eps = net.apply_model({'type': 'image', 'x': xx.cuda().half()}, t.cuda(), {'type': 'image', 'c': c.cuda().half()})
+    ref = O.unet_apply(seeded_sd(param_shapes, "diffuser.image."), "diffuser.image.", xx[1:], t[1:], c[1:])
+    check("UNet eps at a 128x96 latent (1024x768 image)", eps[1:], ref)

@@ -590,3 +590,32 @@ def test_groupnorm_statistics_from_the_producers(net, monkeypatch):
     # determinism of the producer sums
     y_again, _ = chain()
     assert torch.equal(y_ps, y_again)
+
+
+def test_rccl_one_rank_collectives():
+    """The multi-GPU path's collectives on the one GPU there is: `bench.py --gpus 1` under
+    PFD_FORCE_COLLECTIVE=1 creates a 1-rank "nccl" (= RCCL) process group and runs the REAL pipeline through it --
+    PromptFreePipeline.generate(gather=True) -> all_gather_batch -> dist.all_gather, bench.py's barrier(device_ids) and
+    max_over_ranks -> dist.all_reduce(MAX).  No scaling claim: communicator creation and the three collectives executing on
+    an MI355X is what is checked (the world-size-2 logic is covered on gloo, tests/test_distributed_cpu.py)."""
+    import os
+    import socket
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, PFD_FORCE_COLLECTIVE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0",
+               LOCAL_RANK="0", WORLD_SIZE="1", HSA_ENABLE_IPC_MODE_LEGACY="0", NCCL_DEBUG="VERSION")
+    r = subprocess.run([sys.executable, os.path.join(repo, "bench.py"), "--gpus", "1", "--steps", "1", "--warmup", "1",
+                        "--batch", "2", "--height", "256", "--width", "256", "--ddim-steps", "4", "--no-cpu-baseline",
+                        "--no-prof", "--backend", "nccl", "--pg-timeout", "120"],
+                       env=env, capture_output=True, text=True, timeout=600)
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert r.returncode == 0 and lines, r.stdout[-2000:] + r.stderr[-3000:]
+    d = json.loads(lines[-1])
+    print(f"[rccl] 1-rank nccl process group: {d['config']}; value {d['value']:.3f} images/s")
+    assert d["config"]["backend"] == "nccl (RCCL)" and d["config"]["collectives_forced_at_world_1"] is True
+    assert d["config"]["world_size_reported_by_backend"] == 1 and d["n_gpus"] == 1 and d["value"] > 0
