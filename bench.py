@@ -311,7 +311,8 @@ def main():
             res["data"] = "stub (CPU stand-ins for the GPU compute: launcher / collective test only, not a measurement)"
         if prof:
             top = max(prof, key=lambda b: b["ms"])
-            mfma = top["name"].startswith(("gemm", "conv3x3", "attention", "swin"))
+            mfma = top["name"].startswith(("gemm", "conv3x3", "attention", "swin")) and \
+                (top["bytes"] <= 0 or top["flops"] / top["bytes"] >= MFMA_PEAK_TFLOPS * 1e12 / (HBM_PEAK_GBS * 1e9))
             tot = sum(b["ms"] for b in prof)
             # Event pairs around EAGER launches also contain the idle time between the previous kernel's end and this
             # kernel's start (the host enqueues ~23 k launches per batch through ctypes; the hipGraph the timed region
@@ -355,10 +356,17 @@ def main():
                                     "measured_on": prof_where + " (eager event pairs minus the per-launch enqueue gap)",
                                     "alg_flops_per_launch": top["flops"] / top["launches"],
                                     "alg_bytes_per_launch": top["bytes"] / top["launches"]})
-            hbm_bound = lambda b: not b["name"].startswith(("gemm", "conv3x3", "attention", "swin"))  # noqa: E731
+            # A bucket's binding roofline is HBM when its algorithmic intensity (flops per byte, summed over its launches) is
+            # below the machine balance 2500 TFLOP/s / 8 TB/s = 312: GroupNorm / LayerNorm / glue / the split-K reductions
+            # (no flops), and -- round 6 -- the short-K linears of the 64-row / 128-row tiles.  Those
+            # MFMA-kernel buckets are reported BOTH ways: TFLOP/s in kernel_tflops, GB/s here.
+            balance = MFMA_PEAK_TFLOPS * 1e12 / (HBM_PEAK_GBS * 1e9)
+            mfma_named = lambda b: b["name"].startswith(("gemm", "conv3x3", "attention", "swin"))  # noqa: E731
+            hbm_bound = lambda b: (not mfma_named(b)) or (b["bytes"] > 0 and b["flops"] / b["bytes"] < balance)  # noqa: E731
             res["kernel_time_ms_per_step"] = {b["name"]: round(b["ms_graph"] / prof_steps, 3) for b in prof}
             res["kernel_tflops"] = {b["name"]: round(b["flops"] / (b["ms_graph"] / 1e3) / 1e12, 1) for b in prof
-                                    if b["flops"] > 0 and b["ms_graph"] > 0 and not hbm_bound(b)}
+                                    if b["flops"] > 0 and b["ms_graph"] > 0 and mfma_named(b)}
+            res["kernel_flops_per_byte"] = {b["name"]: round(b["flops"] / b["bytes"], 1) for b in prof if b["bytes"] > 0 and b["flops"] > 0}
             # HBM-bound families (GroupNorm, LayerNorm, elementwise / glue, softmax): algorithmic bytes per second and
             # the fraction of the 8 TB/s peak
             res["kernel_gbps"] = {b["name"]: round(b["bytes"] / (b["ms_graph"] / 1e3) / 1e9, 1) for b in prof

@@ -15,8 +15,8 @@
 //     every MFMA segment has the other sub-block's softmax half next to it, and a rescale (rare) always sits between the
 //     completed PV of a tile and the exponentials of the next one (the guide's T13 order);
 //   * 4 waves = 256 queries share a staged tile, two blocks per CU (2 waves per SIMD, up to 256 registers each);
-//   * K lives in a 3-stage ring (tiles t and t+1 are read in one iteration, t+2 is in flight), V^T in two stages; the global
-//     loads of an iteration are issued at its top and written to LDS at its bottom: one barrier per 64-key tile;
+//   * K lives in a 5-stage ring (tiles t .. t+2 are read in one barrier interval, t+3 and t+4 are in flight), V^T in four stages;
+//     the global loads of an interval are issued at its top and written to LDS at its bottom: one barrier per TWO 64-key tiles;
 //   * a V^T fragment is ONE ds_read_b128: the staging writes the keys of a row in the order the P^T operand has them after the
 //     swap (16-byte slot 4 u + kg holds keys 32 u + 16 (kg & 1) + 4 (kg >> 1) + {0..3, 8..11}), slots XOR-swizzled by
 //     (d >> 1) & 7 so that every 16-lane group of the read hits 16 different bank quads; 6 + 6 fragment reads per sub-block
@@ -36,9 +36,10 @@ __global__ __launch_bounds__(256, 2) void attention3_kernel(const AttnParams p) 
   constexpr int D = 40, KV = 64, K_LD = 56, VT_LD = 64, DV = 48, NS = 3, NDT = 3;
   constexpr int K_TILE = KV * K_LD, V_TILE = DV * VT_LD;
   constexpr int NTHR = 256, QB = 256;
-  __shared__ __attribute__((aligned(16))) half_t lds[3 * K_TILE + 2 * V_TILE];
+  constexpr int KR = 5, VR = 4;   // ring stages: K(t .. t+2) are read while K(t+3), K(t+4) land; V^T(t), V^T(t+1) while V^T(t+2), V^T(t+3) land
+  __shared__ __attribute__((aligned(16))) half_t lds[KR * K_TILE + VR * V_TILE];
   half_t* const Ks = lds;
-  half_t* const Vts = lds + 3 * K_TILE;
+  half_t* const Vts = lds + KR * K_TILE;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l31 = lane & 31, hi = lane >> 5, dl = lane & 15, kg = lane >> 4;
@@ -49,11 +50,11 @@ __global__ __launch_bounds__(256, 2) void attention3_kernel(const AttnParams p) 
   const int b = bh / p.H, h = bh - b * p.H;
   const int q0 = qb * QB + wave * 64;
 
-  static_assert((3 * K_TILE + 2 * V_TILE) % 8 == 0, "16-byte clears");
-  for (int i = tid; i < (3 * K_TILE + 2 * V_TILE) / 8; i += NTHR) reinterpret_cast<uint4*>(lds)[i] = make_uint4(0, 0, 0, 0);
+  static_assert((KR * K_TILE + VR * V_TILE) % 8 == 0, "16-byte clears");
+  for (int i = tid; i < (KR * K_TILE + VR * V_TILE) / 8; i += NTHR) reinterpret_cast<uint4*>(lds)[i] = make_uint4(0, 0, 0, 0);
   __syncthreads();
-  for (int i = tid; i < 2 * KV; i += NTHR) Vts[(i / KV) * V_TILE + D * VT_LD + (i % KV)] = (half_t)1.f;   // ones row: sum_kv P
-  for (int i = tid; i < 3 * KV; i += NTHR) Ks[(i / KV) * K_TILE + (i % KV) * K_LD + D] = (half_t)1.f;     // fold column
+  for (int i = tid; i < VR * KV; i += NTHR) Vts[(i / KV) * V_TILE + D * VT_LD + (i % KV)] = (half_t)1.f;   // ones row: sum_kv P
+  for (int i = tid; i < KR * KV; i += NTHR) Ks[(i / KV) * K_TILE + (i % KV) * K_LD + D] = (half_t)1.f;     // fold column
 
   half8_t qfA[NS], qfB[NS];
   auto load_q = [&](int qs, half8_t* qf) __attribute__((always_inline)) {
@@ -99,28 +100,28 @@ __global__ __launch_bounds__(256, 2) void attention3_kernel(const AttnParams p) 
   const half_t* vp0 = vbase + (long)vd0 * p.ldvt + vcc0 * 8;
   const half_t* vp1 = vbase + (long)vd1 * p.ldvt + vcc1 * 8;
   const long kstep = (long)KV * p.ldk;
-  u32x4 kr0, kr1, vr0, vr1;
-  kr1 = vr1 = (u32x4){0u, 0u, 0u, 0u};
-  auto load_k = [&](int tile) __attribute__((always_inline)) {
-    kr0 = *reinterpret_cast<const u32x4*>(kp0 + tile * kstep);
-    if (wave == 0) kr1 = *reinterpret_cast<const u32x4*>(kp1 + tile * kstep);
+  u32x4 kr0[2], kr1[2], vr0[2], vr1[2];   // two tiles of each operand in flight per barrier interval
+  kr1[0] = kr1[1] = vr1[0] = vr1[1] = (u32x4){0u, 0u, 0u, 0u};
+  auto load_k = [&](const int i, int tile) __attribute__((always_inline)) {
+    kr0[i] = *reinterpret_cast<const u32x4*>(kp0 + tile * kstep);
+    if (wave == 0) kr1[i] = *reinterpret_cast<const u32x4*>(kp1 + tile * kstep);
   };
-  auto load_v = [&](int tile) __attribute__((always_inline)) {
-    vr0 = *reinterpret_cast<const u32x4*>(vp0 + tile * KV);
-    if (wave == 1) vr1 = *reinterpret_cast<const u32x4*>(vp1 + tile * KV);
+  auto load_v = [&](const int i, int tile) __attribute__((always_inline)) {
+    vr0[i] = *reinterpret_cast<const u32x4*>(vp0 + tile * KV);
+    if (wave == 1) vr1[i] = *reinterpret_cast<const u32x4*>(vp1 + tile * KV);
   };
-  auto store_k = [&](int stage) __attribute__((always_inline)) {
+  auto store_k = [&](const int i, int stage) __attribute__((always_inline)) {
     half_t* Kd = Ks + stage * K_TILE;
-    *reinterpret_cast<u32x4*>(Kd + k_lds0) = kr0;
-    if (wave == 0) *reinterpret_cast<u32x4*>(Kd + k_lds1) = kr1;
+    *reinterpret_cast<u32x4*>(Kd + k_lds0) = kr0[i];
+    if (wave == 0) *reinterpret_cast<u32x4*>(Kd + k_lds1) = kr1[i];
   };
-  auto store_v = [&](int stage) __attribute__((always_inline)) {
+  auto store_v = [&](const int i, int stage) __attribute__((always_inline)) {
     half_t* Vd = Vts + stage * V_TILE;
-    *reinterpret_cast<uint2*>(Vd + v_lds0) = make_uint2(vr0[0], vr0[1]);
-    *reinterpret_cast<uint2*>(Vd + (v_lds0 ^ 16)) = make_uint2(vr0[2], vr0[3]);
+    *reinterpret_cast<uint2*>(Vd + v_lds0) = make_uint2(vr0[i][0], vr0[i][1]);
+    *reinterpret_cast<uint2*>(Vd + (v_lds0 ^ 16)) = make_uint2(vr0[i][2], vr0[i][3]);
     if (wave == 1) {
-      *reinterpret_cast<uint2*>(Vd + v_lds1) = make_uint2(vr1[0], vr1[1]);
-      *reinterpret_cast<uint2*>(Vd + (v_lds1 ^ 16)) = make_uint2(vr1[2], vr1[3]);
+      *reinterpret_cast<uint2*>(Vd + v_lds1) = make_uint2(vr1[i][0], vr1[i][1]);
+      *reinterpret_cast<uint2*>(Vd + (v_lds1 ^ 16)) = make_uint2(vr1[i][2], vr1[i][3]);
     }
   };
 
@@ -213,44 +214,72 @@ __global__ __launch_bounds__(256, 2) void attention3_kernel(const AttnParams p) 
   const int nt = p.Nk / KV;
   float16_t stA[2], stB[2];
   half8_t pbuf[2][2];
-  // prologue: K(0), V(0), K(1) staged; S_A(0) and its (forced) decision
-  load_k(0);
-  load_v(0);
-  store_k(0);
-  store_v(0);
-  load_k(1);
-  store_k(1);
+  auto wrapk = [](int x) __attribute__((always_inline)) { return x >= KR ? x - KR : x; };
+  auto wrapv = [](int x) __attribute__((always_inline)) { return x >= VR ? x - VR : x; };
+  auto last = [&](int t) __attribute__((always_inline)) { return min(t, nt - 1); };   // clamped: a tile nobody reads is restaged
+  // prologue: K(0), K(1), K(2), V(0), V(1) staged; S_A(0) and its (forced) decision
+  load_k(0, 0);
+  load_k(1, 1);
+  load_v(0, 0);
+  load_v(1, 1);
+  store_k(0, 0);
+  store_k(1, 1);
+  store_v(0, 0);
+  store_v(1, 1);
+  load_k(0, last(2));
+  store_k(0, 2);
   __syncthreads();
   qk(Ks, qfA, stA);
   decide(stA, oA, qfA, mA, tile_max(stA), true);
 
-  int ks0 = 0, ks1 = 1, ks2 = 2;   // ring stages of K(t), K(t + 1), K(t + 2)
-  // one iteration = tile t for both sub-blocks; MORE: tile t + 1 exists (its S_A is started here).  MORE / FIRST are literal
-  // constants at the call sites, so each half of the steady-state iteration is ONE basic block (MFMA and VALU interleave).
-  auto iteration = [&](int t, const bool FIRST, const bool MORE) __attribute__((always_inline)) {
-    load_k(min(t + 2, nt - 1));    // (clamped: the last two iterations restage a tile nobody reads again)
-    load_v(min(t + 1, nt - 1));
-    __builtin_amdgcn_sched_barrier(0);
-    const half_t* Vt = Vts + (t & 1) * V_TILE;
-    qk(Ks + ks0 * K_TILE, qfB, stB);             // seg 1
+  // one tile for both sub-blocks: K(t) at ring stage k0, K(t + 1) at k1, V^T(t) at v0.  MORE: tile t + 1 exists (its S_A is started
+  // here); a literal at the call sites, so each half of a tile is ONE basic block (MFMA and VALU interleave)
+  auto tile_step = [&](int k0, int k1, int v0, bool first, const bool MORE) __attribute__((always_inline)) {
+    const half_t* Vt = Vts + v0 * V_TILE;
+    qk(Ks + k0 * K_TILE, qfB, stB);              // seg 1
     softmax_p(stA, pbuf);
     pv(Vt, pbuf, oA);                            // seg 2
-    decide(stB, oB, qfB, mB, tile_max(stB), FIRST);
-    if (MORE) qk(Ks + ks1 * K_TILE, qfA, stA);   // seg 3
+    decide(stB, oB, qfB, mB, tile_max(stB), first);
+    if (MORE) qk(Ks + k1 * K_TILE, qfA, stA);    // seg 3
     softmax_p(stB, pbuf);
     pv(Vt, pbuf, oB);                            // seg 4
     if (MORE) decide(stA, oA, qfA, mA, tile_max(stA), false);
-    store_k(ks2);
-    store_v((t & 1) ^ 1);
-    __syncthreads();
-    const int k_ = ks0;
-    ks0 = ks1;
-    ks1 = ks2;
-    ks2 = k_;
   };
-  iteration(0, true, true);        // nt >= 2
-  for (int t = 1; t + 1 < nt; ++t) iteration(t, false, true);
-  iteration(nt - 1, false, false);
+  // Round 6b: TWO tiles per barrier.  With one barrier per 64-key tile the loads + ds_writes + barrier of an iteration cost 52 of
+  // the kernel's 272 us (timing ablation, profiles/r06_attn3_ablation.log) -- mostly the four waves of a block waiting for each
+  // other 64 times per block; a pair of tiles halves the rendezvous.  Invariant at the top of an interval that starts at tile t:
+  // K(t), K(t+1), K(t+2), V^T(t), V^T(t+1) are staged and visible; a pair restages K(t+3), K(t+4), V^T(t+2), V^T(t+3).
+  int t = 0, kq = 0, vq = 0;       // kq / vq: ring stages of K(t) / V^T(t)
+  if (nt & 1) {                    // odd tile count: one single-tile interval first (restages K(3), V^T(2))
+    load_k(0, last(3));
+    load_v(0, last(2));
+    __builtin_amdgcn_sched_barrier(0);
+    tile_step(0, 1, 0, true, true);              // (nt >= 3 here)
+    store_k(0, 3);
+    store_v(0, 2);
+    __syncthreads();
+    t = 1; kq = 1; vq = 1;
+  }
+  auto pair = [&](const bool LAST) __attribute__((always_inline)) {
+    load_k(0, last(t + 3));
+    load_k(1, last(t + 4));
+    load_v(0, last(t + 2));
+    load_v(1, last(t + 3));
+    __builtin_amdgcn_sched_barrier(0);
+    const int k1 = wrapk(kq + 1), k2 = wrapk(kq + 2), v1 = wrapv(vq + 1);
+    tile_step(kq, k1, vq, t == 0, true);
+    tile_step(k1, k2, v1, false, !LAST);
+    store_k(0, wrapk(kq + 3));
+    store_k(1, wrapk(kq + 4));
+    store_v(0, wrapv(vq + 2));
+    store_v(1, wrapv(vq + 3));
+    __syncthreads();
+    t += 2;
+    kq = k2;
+    vq = wrapv(vq + 2);
+  };
+  while (t + 2 < nt) pair(false);
+  pair(true);
 
   // ---- epilogue: O[q, d] = O^T[d, q] / l; l = row 40 of O^T (d tile 2, local row 8 = lane row 2, register 0) ----
   auto store_o = [&](float4_t (*o)[2], int qs) __attribute__((always_inline)) {

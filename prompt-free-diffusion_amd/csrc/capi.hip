@@ -33,7 +33,7 @@ extern "C" const char* pfd_last_error(void) { return g_err; }
 #include <vector>
 
 namespace {
-constexpr int kProfBuckets = 21;
+constexpr int kProfBuckets = 22;
 constexpr int kProfRing = 16384;
 struct ProfSlot {
   hipEvent_t a = nullptr, b = nullptr;
@@ -58,7 +58,8 @@ const char* kBucketNames[kProfBuckets] = {
     "swin_attn_kernel",            "groupnorm(stats+finalize+apply)", "layernorm_kernel",
     "gemm160_kernel<4,4>(256x160)", "gemm160_kernel<2,4>(128x160)", "gemm160_kernel<2,2>(64x160)",
     "elementwise / glue",          "gemm160_kernel<4,4,conv>(256x160)", "gemm160_kernel<2,4,conv>(128x160)",
-    "gemm160_kernel<2,2,conv>(64x160)", "conv3x3_patch_kernel(256x160)", "conv3x3_narrow_kernel(N<=16)"};
+    "gemm160_kernel<2,2,conv>(64x160)", "conv3x3_patch_kernel(256x160)", "conv3x3_narrow_kernel(N<=16)",
+    "splitk_reduce(+epilogue / GroupNorm)"};
 
 void harvest(ProfSlot& s) {
   if (s.bucket < 0) return;

@@ -396,12 +396,14 @@ __global__ __launch_bounds__(256) void conv3x3_narrow_kernel(const GemmParams p)
   const int x = x0 + wave * 16 + l15, n0 = 4 * kg;
   if (x < p.Wd && n0 < p.N) {
     const long m = ((long)b * p.H + y) * p.Wd + x;
-    half_t o[4];
+    // bias: four unconditional loads issued together (an absent bias reads the zero page; `p.bias ? load : 0` is a branch +
+    // load + vmcnt(0) per element -- tools/isa_audit.py)
+    const half_t* bsrc = p.bias ? p.bias : pfd_zero_halves();
+    half_t bv[4], o[4];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int n = min(n0 + r, p.N - 1);
-      o[r] = (half_t)(acc[r] + (p.bias ? (float)p.bias[n] : 0.f));
-    }
+    for (int r = 0; r < 4; ++r) bv[r] = bsrc[p.bias ? min(n0 + r, p.N - 1) : r];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) o[r] = (half_t)(acc[r] + (float)bv[r]);
     half_t* cp = p.C + m * p.ldc + n0;
     if (n0 + 4 <= p.N && (p.ldc & 3) == 0 && (reinterpret_cast<uintptr_t>(p.C) & 7) == 0) {
       Pack8 q;

@@ -1976,6 +1976,14 @@ thread_local GnFuse t_gnf = {nullptr, nullptr, nullptr, 0, 0.f, 0, 0, 0};
 
 // launches the reduction of a split-K launch (plain, or the statistics-emitting form) and the LayerNorm fallback statistics
 inline void launch_splitk_reduce(const G160Params& p, hipStream_t s) {
+  // Round 6: the reduction is timed as its own bucket (it is HBM-bound glue, not part of the GEMM's MFMA time): the caller's
+  // event pair is closed here and a new one covers the reduction launch(es); the caller's pfd_prof_end then closes this one.
+  // Algorithmic bytes: the fp32 slabs once + the f16 result (+ residual, + the normalised copy of the fused GroupNorm form).
+  if (pfd_prof_on()) {
+    pfd_prof_end(s);
+    const double mn = (double)p.M * p.N;
+    pfd_prof_begin(21, 0.0, 4.0 * p.splits * mn + 2.0 * mn * (1 + (p.R ? 1 : 0) + (t_gnf.y ? 1 : 0)), s);
+  }
   if (t_gnf.y) {   // (host: no gn_out / ln_out with it)
     const GnFuse f = t_gnf;
     hipLaunchKernelGGL(splitk_reduce_gnorm_kernel, dim3(32 * (p.M / f.rows)), dim3(GNF_T), 0, s, p, f);
@@ -2190,7 +2198,7 @@ int pfd_gemm160_try(const PfdGemmDesc* d, int variant, int splits, hipStream_t s
   }
   if (p.gn_table) {   // GroupNorm prologue: patch kernel or nothing (validated here, PFD_ESHAPE by the caller otherwise)
     if (bn != 160 || (variant != 0 && variant != 98)) return 1;
-    variant = 98;   // loader waves without the ping-pong groups (the prologue path is not built for them)
+    variant = 98;   // loader waves with two weight stages (the form the prologue instances are built on)
     if (p.gn_c1 <= 0 || p.gn_c1 > p.Cin || (p.gn_c1 % BK) || (p.gn_c1 < p.Cin && !p.A2)) return 1;
     if ((p.lda2 & 7) || (reinterpret_cast<uintptr_t>(p.A2) & 15) || (reinterpret_cast<uintptr_t>(p.gn_table) & 15))
       return 1;
@@ -2328,7 +2336,7 @@ int pfd_gemm160_try(const PfdGemmDesc* d, int variant, int splits, hipStream_t s
   // round trips.  Same tile, same split counts, same K order.  End to end -0.2 % (22 -> 41) and -0.3 % (23 -> 43), alternating on
   // one box (profiles/r05_e2e_ab_candidates.log); round 3 had adopted the eight-wave forms only where the COLD REPLAY showed a gain.
   if (auto_variant && bn == 160) variant = variant == 22 ? 41 : variant == 23 ? 43 : variant;
-  if (variant == 48 || variant == 47) {   // 8 MFMA waves + 4 loader waves (49: ping-pong consumer groups, 47: 3-stage ring)
+  if (variant == 48 || variant == 47) {   // 8 MFMA waves + 4 loader waves (48: two operand stages, 47: 3-stage ring)
     const int mode = variant == 47 ? 2 : 0;
     if (bn == 128) return launch160ws<4>(p, 12 + 4 * conv, s, mode) < 0 ? PFD_ELAUNCH : 0;
     return launch160ws<5>(p, 12 + 4 * conv, s, mode) < 0 ? PFD_ELAUNCH : 0;

@@ -1402,14 +1402,15 @@ __global__ void count_mismatch_kernel(const unsigned short* a, const unsigned sh
 static int replay(const char* path, bool timed = false, int force_tile = 0) {
   FILE* f = fopen(path, "r");
   if (!f) { printf("cannot open %s\n", path); return 1; }
-  // one launch per line: 19 fields (rounds 1-3) or 22 (+ k_split, zero_rows, gn_out != NULL)
-  std::vector<std::array<long, 22>> rows;
+  // one launch per line: 19 fields (rounds 1-3), 22 (+ k_split, zero_rows, gn_out != NULL) or 24 (+ gnf = 0 | 1 | 2 = fused
+  // GroupNorm in the split-K reduction keeping / skipping the raw result, res_rows); shorter lines are padded with zeros
+  std::vector<std::array<long, 24>> rows;
   char line[512];
   while (fgets(line, sizeof(line), f)) {
-    std::array<long, 22> r{};
+    std::array<long, 24> r{};
     int n = 0, off = 0, adv = 0;
-    while (n < 22 && sscanf(line + off, "%ld%n", &r[n], &adv) == 1) { ++n; off += adv; }
-    if (n != 19 && n != 22) break;
+    while (n < 24 && sscanf(line + off, "%ld%n", &r[n], &adv) == 1) { ++n; off += adv; }
+    if (n != 19 && n != 22 && n != 24) break;
     rows.push_back(r);
   }
   fclose(f);
@@ -1420,7 +1421,7 @@ static int replay(const char* path, bool timed = false, int force_tile = 0) {
     maxA = std::max(maxA, a); maxW = std::max(maxW, (size_t)N * K); maxC = std::max(maxC, (size_t)M * N);
     maxV = std::max(maxV, (size_t)std::max(M, N) * 4);
   }
-  Dev<h16> dA(rand_h(maxA)), dW(rand_h(maxW, 0.05f)), dB(rand_h(maxV)), dRV(rand_h(maxC)), dR(rand_h(maxC)), dC(maxC);
+  Dev<h16> dA(rand_h(maxA)), dW(rand_h(maxW, 0.05f)), dB(rand_h(maxV)), dRV(rand_h(maxC)), dR(rand_h(maxC)), dC(maxC), dY(maxC);
   Dev<float> dWS((size_t)24 << 20);
   size_t maxM = 1;
   for (auto& q : rows) maxM = std::max(maxM, (size_t)q[0]);
@@ -1463,6 +1464,12 @@ static int replay(const char* path, bool timed = false, int force_tile = 0) {
       if (q[19] > 0) { d.k_split = (int)q[19]; d.A2 = dA.p + (size_t)d.M * d.k_split; d.lda = d.k_split; d.lda2 = d.K - d.k_split; }
       d.zero_rows = (int)q[20];
       if (q[21]) d.gn_out = dGnO.p;
+      if (q[22]) {   // GroupNorm(+SiLU) of the output inside the split-K reduction (PfdGemmDesc.gnf_y); the residual then wraps never
+        d.gnf_gamma = dB.p; d.gnf_beta = dB.p + d.N; d.gnf_y = dY.p; d.gnf_ldy = nout; d.gnf_eps = 1e-5f; d.gnf_act = PFD_ACT_SILU;
+        d.gnf_rows = d.ksize > 0 ? d.Ho * d.Wo : (int)std::min<long>(q[18], d.M);
+        d.gnf_skip_raw = q[22] == 2;
+      }
+      if (q[23] > 0 && d.R && !q[22]) d.res_rows = (int)q[23];
       static const bool replay_warm = getenv("PFD_REPLAY_WARM") && atoi(getenv("PFD_REPLAY_WARM")) != 0;   // weights of every launch from ONE buffer (cache-warm): the bound of any weight prefetch
       if (timed && !replay_warm) {
         const size_t wn = ((size_t)d.N * d.K + 4095) & ~(size_t)4095;
@@ -1483,7 +1490,14 @@ static int replay(const char* path, bool timed = false, int force_tile = 0) {
       }
       static const bool replay_tiled = getenv("PFD_REPLAY_TILED") && atoi(getenv("PFD_REPLAY_TILED")) != 0;
       if (replay_tiled && (d.N % 160 == 0 || d.N % 128 == 0) && d.K % 64 == 0 && !d.bias_per_row) d.w_tiled = 1;
-      if (force_tile == 0 || pfd_gemm_f16_ex(&d, force_tile, nullptr) != 0) bad += pfd_gemm_f16(&d, nullptr) != 0;
+      if (force_tile == 0 || pfd_gemm_f16_ex(&d, force_tile, nullptr) != 0) {
+        int rc = pfd_gemm_f16(&d, nullptr);
+        if (rc == PFD_ESHAPE && d.gnf_y) {   // declined (this build does not split the shape): the two-call form's first call
+          d.gnf_y = nullptr;
+          rc = pfd_gemm_f16(&d, nullptr);
+        }
+        bad += rc != 0;
+      }
       // PFD_REPLAY_DET=1: every launch twice on the same operands into two buffers; the results must be the same bits
       static const bool replay_det = getenv("PFD_REPLAY_DET") && atoi(getenv("PFD_REPLAY_DET")) != 0;
       if (replay_det && rep == 0) {
@@ -1517,7 +1531,7 @@ static int replay(const char* path, bool timed = false, int force_tile = 0) {
   HIP_OK(hipDeviceSynchronize());
   printf("replayed %zu launches x%d, %d errors\n", rows.size(), reps, bad);
   if (timed) {
-    struct Agg { std::array<long, 22> q; int n; double ms; };
+    struct Agg { std::array<long, 24> q; int n; double ms; };
     std::vector<Agg> aggs;
     for (size_t i = 0; i < rows.size(); ++i) {
       bool found = false;

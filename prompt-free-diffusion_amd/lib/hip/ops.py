@@ -61,17 +61,19 @@ def _workspace(device):
 
 
 _TRACE = os.environ.get("PFD_TRACE_GEMM")
+_TRACE_GN = os.environ.get("PFD_TRACE_GN")
 # False: every LayerNorm is its own launch again (tests flip it per call; the round-3 A/B: -52 ms per batch for the fold)
 LN_FOLD = True
 
 
 # One record per GEMM / conv launch: THE field list of profiles/unet_c2_gemm_shapes.txt.  The writer below, the readers in
-# tests/test_hip_kernels_fullsize.py (parse_launch_records) and csrc/selftest.cpp (--replay: 19 or 22 integers per line) follow
+# tests/test_hip_kernels_fullsize.py (parse_launch_records) and csrc/selftest.cpp (--replay: 19, 22 or 24 integers per line) follow
 # it; tests/test_host.py parses the tracked file with it on CPU, so a regenerated file cannot break a GPU-only test unseen.
 TRACE_FIELDS = ("M", "N", "K", "act", "has_bias", "has_rowvec", "has_res", "bias_per_row",
                 "ksize", "stride", "pad", "ups", "B", "H", "W", "Cin", "Ho", "Wo", "rows_per_rv",
-                "k_split", "zero_rows", "gn_out")
+                "k_split", "zero_rows", "gn_out", "gnf", "res_rows")
 TRACE_FIELDS_ABI7 = 19      # rounds 1-3 wrote the first 19 (k_split = zero_rows = gn_out = 0)
+TRACE_FIELDS_ABI8 = 22      # rounds 4-5 the first 22 (ABI 9's gnf = 0 | 1 keeps the raw result | 2 skips it, res_rows = 0: ADVICE r05)
 
 
 def trace_record(d):
@@ -79,7 +81,7 @@ def trace_record(d):
     return tuple(int(v) for v in (
         d.M, d.N, d.K, d.act, d.bias is not None, d.rowvec is not None, d.R is not None, d.bias_per_row,
         d.ksize, d.stride, d.pad, d.ups, d.B, d.H, d.Wd, d.Cin, d.Ho, d.Wo, d.rows_per_rv,
-        d.k_split, d.zero_rows, bool(d.gn_out)))
+        d.k_split, d.zero_rows, bool(d.gn_out), (2 if d.gnf_skip_raw else 1) if d.gnf_y else 0, d.res_rows))
 
 
 def parse_launch_records(path, distinct=True):
@@ -91,8 +93,8 @@ def parse_launch_records(path, distinct=True):
         v = tuple(int(t) for t in line.split())
         if not v:
             continue
-        if len(v) == TRACE_FIELDS_ABI7:
-            v = v + (0,) * (len(TRACE_FIELDS) - TRACE_FIELDS_ABI7)
+        if len(v) in (TRACE_FIELDS_ABI7, TRACE_FIELDS_ABI8):
+            v = v + (0,) * (len(TRACE_FIELDS) - len(v))
         if len(v) != len(TRACE_FIELDS):
             raise ValueError(f"{path}:{ln}: {len(v)} fields, expected {len(TRACE_FIELDS)} ({' '.join(TRACE_FIELDS)})")
         if distinct and v in seen:
@@ -176,22 +178,27 @@ def _new_gn_stats(M, N, device):
 
 def set_gn_stats(t, stats):
     """attach the producer's statistics to the tensor OBJECT that holds its output (views / copies do not inherit them)"""
-    t._pfd_gn = (stats, t.data_ptr(), tuple(t.shape))
+    t._pfd_gn = (stats, t.data_ptr(), tuple(t.shape), t._version)
     return t
 
 
 def get_gn_stats(t):
     """the statistics the producer of `t` emitted, or None (also when the object was re-pointed since)"""
     ent = getattr(t, "_pfd_gn", None)
-    if ent is None or ent[1] != t.data_ptr() or ent[2] != tuple(t.shape):
-        return None
+    if ent is None or ent[1] != t.data_ptr() or ent[2] != tuple(t.shape) or ent[3] != t._version:
+        return None       # (the version counter also moves on torch in-place ops and writes through a view of this tensor)
     return ent[0]
 
 
 def _written(out, stats=None):
     """every op that writes into a caller-provided `out` goes through here: the tensor object carries the statistics of
-    THIS write or none (stale producer statistics would be normalised with silently).  Writing through a VIEW of a
-    statistics-carrying tensor is not tracked: the object that holds the statistics must be the one written."""
+    THIS write or none (stale producer statistics would be normalised with silently).  A write through a VIEW of a
+    statistics-carrying tensor invalidates them through the shared version counter (get_gn_stats / get_normed compare it)."""
+    if out is not None:
+        # the library wrote through a raw pointer: tell torch (the version counter is shared by every view of the storage), so
+        # that statistics / normalised copies riding on ANOTHER object over these bytes -- ControlNet's `add(h[b:b+1], g,
+        # out=h[b:b+1])` writes through a view of h -- stop matching (ADVICE r05)
+        torch._C._increment_version(out)
     if stats is not None:
         set_gn_stats(out, stats)
     elif out is not None and getattr(out, "_pfd_gn", None) is not None:
@@ -204,14 +211,14 @@ def _written(out, stats=None):
 def set_normed(t, key, y):
     """attach the GroupNorm of `t` that its producer already computed (conv(gn_fuse=...)): key = (id of the norm module's
     gamma storage, eps, silu).  Rides on the tensor OBJECT like the statistics; any rewrite of the object drops it."""
-    t._pfd_normed = (key, t.data_ptr(), tuple(t.shape), y)
+    t._pfd_normed = (key, t.data_ptr(), tuple(t.shape), y, t._version)
     return t
 
 
 def get_normed(t, key):
     ent = getattr(t, "_pfd_normed", None)
-    if ent is None or ent[0] != key or ent[1] != t.data_ptr() or ent[2] != tuple(t.shape):
-        return None
+    if ent is None or ent[0] != key or ent[1] != t.data_ptr() or ent[2] != tuple(t.shape) or ent[4] != t._version:
+        return None       # (ADVICE r05: a torch in-place op or a write through a view bumps the version -> recompute)
     return ent[3]
 
 
@@ -412,9 +419,11 @@ def conv(x, w, ksize, *, stride=1, pad=None, ups=False, bias=None, rowvec=None, 
         if gn is not None or gn_out:
             raise ValueError("conv: gn_fuse cannot be combined with gn= / gn_out=")
         g_gamma, g_beta, g_eps, g_silu, g_keep = gn_fuse
+        # (everything the library's decision can depend on -- residual present, leading dimensions, device --
+        #  and only for heuristic calls: a decline under a forced tile says nothing about the heuristic's choice)
         key = (B, H, W_, Cin, N, ksize, stride, pad, bool(ups), Ho, Wo, act, rowvec is not None,
-               None if rowvec is None else d.rows_per_rv)
-        if key in _GNF_DECLINED:
+               None if rowvec is None else d.rows_per_rv, res is not None, int(d.lda), int(d.ldc), int(d.ldr), str(x.device))
+        if tile == 0 and key in _GNF_DECLINED:
             return None
         _chk16(g_gamma, "conv gn_fuse gamma")
         _chk16(g_beta, "conv gn_fuse beta")
@@ -426,7 +435,8 @@ def conv(x, w, ksize, *, stride=1, pad=None, ups=False, bias=None, rowvec=None, 
         lib = _lib()
         rc = lib.pfd_gemm_f16_ex(_byref(d), tile, _stream()) if tile else lib.pfd_gemm_f16(_byref(d), _stream())
         if rc == _b.PFD_ESHAPE:      # nothing was launched (include/pfd_hip.h)
-            _GNF_DECLINED.add(key)
+            if tile == 0:
+                _GNF_DECLINED.add(key)
             return None
         _b.check(rc, f"pfd_gemm_f16(conv, fused GroupNorm) M{M} N{N} K{K}")
         if _TRACE:
@@ -516,6 +526,10 @@ def groupnorm(x, gamma, beta, groups, eps, *, x2=None, silu=False, out=None):
     lib = _lib()
     st1 = get_gn_stats(x) if GN_PSTATS else None
     st2 = get_gn_stats(x2) if (GN_PSTATS and x2 is not None) else None
+    if _TRACE_GN:   # PFD_TRACE_GN=<file>: which norms find their producers' statistics (tools/gn_paths.py)
+        with open(_TRACE_GN, "a") as f:
+            f.write(f"{B} {HW} {C1} {C2} {int(st1 is not None)} {int(x2 is None or st2 is not None)} "
+                    f"{int(bool(lib.pfd_groupnorm_takes_pstats(B, C1, C2, HW, groups)))}\n")
     if st1 is not None and (x2 is None or st2 is not None) and groups == 32 and \
             lib.pfd_groupnorm_takes_pstats(B, C1, C2, HW, groups):
         rc = lib.pfd_groupnorm_pstats_f16(x.data_ptr(), C1, x.stride(-2), st1.data_ptr(), _ptr(x2), C2,

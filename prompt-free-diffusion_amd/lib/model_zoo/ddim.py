@@ -130,7 +130,8 @@ class DDIMSampler(object):
         time_range = np.flip(timesteps)
         total_steps = timesteps.shape[0]
         # all step timestamps at once on the device: [total_steps, 1] int64 (repeated over the nb * n samples of a step)
-        t_col = torch.as_tensor(np.ascontiguousarray(time_range), device=device).long()[:, None]
+        # (.copy(): a flipped ONE-element array counts as contiguous and keeps its negative stride -- a one-step schedule raised here)
+        t_col = torch.as_tensor(np.array(time_range).copy(), device=device).long()[:, None]
         x_type, c_type = x_info['type'], c_info['type']
         stochastic = bool(np.any(np.asarray(self.ddim_sigmas) != 0.))
 

@@ -466,10 +466,15 @@ class UNetModel2D_Next(nn.Module, L._Packed):
         output ALONE: the next layer is a context layer (SpatialTransformer.norm) or a data layer that starts with a ResBlock
         and takes no skip concat (in_layers[0] + SiLU).  With ControlNet residuals the middle block's output is modified
         before its consumer reads it: no hint there.  Cached per (context net, control) on the module."""
+        # (ADVICE r05) keyed by a WEAK reference to the context net plus what the table depends on (block counts, orders): a
+        # replaced / freed context net cannot alias an old entry through a reused id, and its modules are not kept alive here
+        import weakref
         cache = self.__dict__.setdefault("_nn_cache", {})
-        key = (id(cnet), bool(with_control))
-        if key in cache:
-            return cache[key]
+        key = (bool(with_control), len(cnet.context_blocks), len(self.data_blocks), tuple(self.i_order), tuple(self.m_order),
+               tuple(self.o_order))
+        ent = cache.get(key)
+        if ent is not None and ent[0]() is cnet:
+            return ent[1]
         order = list(self.i_order) + list(self.m_order) + list(self.o_order)
         d_list, c_list = list(self.data_blocks), list(cnet.context_blocks)
         di = ci = 0
@@ -498,7 +503,7 @@ class UNetModel2D_Next(nn.Module, L._Packed):
             fn = seq[j][1].first_norm()
             if fn is not None:
                 out[i] = fn
-        cache[key] = out
+        cache[key] = (weakref.ref(cnet), out)
         return out
 
     def forward(self, x, timesteps, context):

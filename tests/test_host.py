@@ -339,7 +339,7 @@ def test_tracked_launch_list_parses_under_the_gpu_tests_reader():
     recs = FS._records()
     assert len(recs) >= 55 and all(len(r) == len(ops.TRACE_FIELDS) for r in recs)
     raw_widths = {len(line.split()) for line in open(FS.SHAPES) if line.strip()}
-    assert raw_widths <= {ops.TRACE_FIELDS_ABI7, len(ops.TRACE_FIELDS)}, raw_widths
+    assert raw_widths <= {ops.TRACE_FIELDS_ABI7, ops.TRACE_FIELDS_ABI8, len(ops.TRACE_FIELDS)}, raw_widths
     src = open(os.path.join(REPO, "prompt-free-diffusion_amd", "csrc", "selftest.cpp")).read()
     assert f"std::array<long, {len(ops.TRACE_FIELDS)}>" in src and f"n != {len(ops.TRACE_FIELDS)}" in src, \
         "selftest --replay reads a different number of fields than ops.TRACE_FIELDS"

@@ -89,6 +89,8 @@ int main(int argc, char** argv) {
       run_case(2, 1, 256, 320, 40);
       run_case(1, 1, 256, 320, 40, 200);   // deferred rescale taken in tile 3 (sub-block A or B by the query's position)
       run_case(1, 1, 256, 256, 40, 100);   // ... in tile 1, query 100 = sub-block B of wave 1
+      run_case(1, 1, 256, 704, 40, 500);   // 11 tiles: both rings wrap twice (odd count: single-tile interval + five pairs)
+      run_case(1, 1, 256, 768, 40);        // 12 tiles: pairs only
       printf("%d cases, %d failed\n", g_total, g_fail);
       return g_fail;
     }
