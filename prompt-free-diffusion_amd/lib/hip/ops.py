@@ -198,7 +198,7 @@ def _written(out, stats=None):
         # the library wrote through a raw pointer: tell torch (the version counter is shared by every view of the storage), so
         # that statistics / normalised copies riding on ANOTHER object over these bytes -- ControlNet's `add(h[b:b+1], g,
         # out=h[b:b+1])` writes through a view of h -- stop matching
-        torch._C._increment_version(out)
+        torch._C._increment_version((out,))     # (an iterable of tensors: a bare tensor is iterated row by row)
     if stats is not None:
         set_gn_stats(out, stats)
     elif out is not None and getattr(out, "_pfd_gn", None) is not None:

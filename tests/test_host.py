@@ -389,6 +389,23 @@ def test_stale_groupnorm_statistics_are_dropped_on_rewrite():
     assert ops.get_gn_stats(ops._written(t, st2)) is st2                   # rewritten with fresh ones
     assert ops.get_gn_stats(t[:32]) is None                                # views do not inherit
     assert ops._written(None) is None
+    # round 6: a write through a VIEW of the carrying tensor (ControlNet: add(h[b:b+1], g, out=h[b:b+1])) or a torch
+    # in-place op invalidates statistics and a producer-computed normalised copy alike -- the shared version counter
+    h = torch.zeros(128, 320, dtype=torch.float16)
+    ops.set_gn_stats(h, st)
+    ops.set_normed(h, ("k", 1e-5, True), torch.ones(128, 320))
+    assert ops.get_gn_stats(h) is st and ops.get_normed(h, ("k", 1e-5, True)) is not None
+    ops._written(h[0:64])                                                  # the library wrote through a view
+    assert ops.get_gn_stats(h) is None and ops.get_normed(h, ("k", 1e-5, True)) is None
+    ops.set_gn_stats(h, st)
+    h.add_(1)                                                              # torch wrote in place
+    assert ops.get_gn_stats(h) is None
+    import time
+    big = torch.zeros(32768, 320, dtype=torch.float16)
+    t0 = time.perf_counter()
+    for _ in range(100):
+        ops._written(big)
+    assert time.perf_counter() - t0 < 0.05, "ops._written must not touch the tensor's elements (it once iterated its rows)"
 
 
 def test_unet_next_norm_hints(full_net):

@@ -39,8 +39,10 @@ def bucket(name):
         return f"gemm_conv_kernel<{m.group(1)},{m.group(2)},{m.group(3)}>"
     if "conv3x3_patch" in name:
         return "conv3x3_patch_kernel(256x160)"
-    if "splitk_reduce_kernel" in name:
-        return "splitk_reduce_kernel"
+    if "conv3x3_narrow" in name:
+        return "conv3x3_narrow_kernel(N<=16)"
+    if "splitk_reduce" in name:       # plain, statistics-emitting and fused-GroupNorm forms: one bench.py bucket since round 6
+        return "splitk_reduce(+epilogue / GroupNorm)"
     return None
 
 

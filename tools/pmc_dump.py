@@ -39,7 +39,7 @@ def main(db, out=None, flt=None):
     txt = "\n".join(lines)
     print(txt)
     if out:
-        open(out, "w").write(txt + "\n")
+        open(out, "w").write(txt + "\n")   # ("" = print only)
 
 
 if __name__ == "__main__":
