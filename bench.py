@@ -362,7 +362,9 @@ def main():
             # MFMA-kernel buckets are reported BOTH ways: TFLOP/s in kernel_tflops, GB/s here.
             balance = MFMA_PEAK_TFLOPS * 1e12 / (HBM_PEAK_GBS * 1e9)
             mfma_named = lambda b: b["name"].startswith(("gemm", "conv3x3", "attention", "swin"))  # noqa: E731
-            hbm_bound = lambda b: (not mfma_named(b)) or (b["bytes"] > 0 and b["flops"] / b["bytes"] < balance)  # noqa: E731
+            # (1.5 x the balance: the 64-row linears sit at 325 flops per byte -- weight- / activation-streaming launches of the
+            #  16^2 / 8^2 levels that neither roof describes alone; they are listed against both)
+            hbm_bound = lambda b: (not mfma_named(b)) or (b["bytes"] > 0 and b["flops"] / b["bytes"] < 1.5 * balance)  # noqa: E731
             res["kernel_time_ms_per_step"] = {b["name"]: round(b["ms_graph"] / prof_steps, 3) for b in prof}
             res["kernel_tflops"] = {b["name"]: round(b["flops"] / (b["ms_graph"] / 1e3) / 1e12, 1) for b in prof
                                     if b["flops"] > 0 and b["ms_graph"] > 0 and mfma_named(b)}
