@@ -681,10 +681,9 @@ int launch(const AttnParams& p, hipStream_t s) {
                    2.0 * p.B * p.H * D * (2.0 * p.Nq + 2.0 * p.Nk), s);
   // 8-wave blocks pay when a block has many queries to amortise the staging over and the grid still fills the chip twice
   if constexpr (D == 40) {
-    // round 6: the software-pipelined 64-queries-per-wave kernel (attention3.hip) for self-attention-sized problems
-    // (PFD_ATTN3=0: the round-5 kernel -- A/B switch of the round, to be removed once decided)
-    static const bool attn3 = !(getenv("PFD_ATTN3") && atoi(getenv("PFD_ATTN3")) == 0);
-    if (attn3 && pfd_attention3_takes(p)) {
+    // round 6: the software-pipelined 64-queries-per-wave kernel (attention3.hip) for self-attention-sized problems (decided on
+    // hardware against the kernel below: 260 vs 284 us at B 8 / 64^2, profiles/r06_bench_attn_*.log; the A/B switch is gone)
+    if (pfd_attention3_takes(p)) {
       pfd_attention3_launch(p, s);
       if (prof) pfd_prof_end(s);
       return pfd_check_launch("pfd_attention_f16");
