@@ -1698,6 +1698,14 @@ int main(int argc, char** argv) {
     bench_attn("self-attn 16^2 d160", 8, 8, 256, 256, 160);
     bench_attn("cross-attn 64^2 d40", 4, 8, 4096, 148, 40);
     bench_attn("seecoder cross d96", 1, 8, 144, 4096, 96);
+    // fixed cost of the short launches: the same problems with fewer keys
+    bench_attn("cross-attn 64^2 d40, 64 keys", 4, 8, 4096, 64, 40);
+    bench_attn("cross-attn 64^2 d40, 8 keys", 4, 8, 4096, 8, 40);
+    bench_attn("cross-attn 32^2 d80", 4, 8, 1024, 148, 80);
+    bench_attn("cross-attn 32^2 d80, 8 keys", 4, 8, 1024, 8, 80);
+    bench_attn("cross-attn 16^2 d160", 4, 8, 256, 148, 160);
+    bench_attn("cross-attn 16^2 d160, 8 keys", 4, 8, 256, 8, 160);
+    bench_attn("self-attn 16^2 d160, 64 keys", 8, 8, 256, 64, 160);
     return 0;
   }
   if (argc > 1 && !strcmp(argv[1], "--bench-gn")) {
