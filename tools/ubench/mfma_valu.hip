@@ -2,7 +2,8 @@
 //   body = NM MFMAs on independent accumulators + NV vector instructions on independent registers, interleaved by the compiler
 //   under sched_group_barrier (1 MFMA, NV / NM VALU); 1 or 2 waves per SIMD (256- / 512-thread blocks, one block per CU);
 //   SPLIT: the first four waves of a 512-thread block issue only the MFMAs, the other four only the vector instructions.
-// Prints cycles per body per wave (clock64) and the wall time.   build: hipcc --offload-arch=gfx950 -O3 mfma_valu.hip -o mfma_valu
+// Prints cycles per body per wave (clock64) and the wall time.   build: hipcc --offload-arch=gfx950 -O3 -w mfma_valu.hip -o mfma_valu
+// (the binary is git-ignored; it travels to the GPU box with the snapshot like the built library)
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 #include <stdlib.h>
