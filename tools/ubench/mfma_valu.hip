@@ -81,6 +81,8 @@ __global__ __launch_bounds__(512) void k(const float* in, float* out, long long*
         if (VK == 0) x = __builtin_amdgcn_exp2f(x);
         else if (VK == 1) x = __builtin_fmaf(x, 1.0001f, 1e-6f);
         else if (VK == 2) x = __builtin_fmaxf(__builtin_fmaxf(x, v[(i + 1) & 31]), v[(i + 2) & 31]);
+        else if (VK == 3) { _Float16 h = (_Float16)x; asm volatile("v_exp_f16 %0, %1" : "=v"(h) : "v"(h)); x = (float)h; }   // (+ 2 conversions)
+        else if (VK == 4) { unsigned u = __builtin_bit_cast(unsigned, x); asm volatile("v_exp_f16 %0, %0" : "+v"(u)); x = __builtin_bit_cast(float, u); }   // bare v_exp_f16
       }
     }
     if constexpr (!SPLIT && NM > 0 && NV > 0) {
@@ -164,6 +166,7 @@ int main() {
     RUN(0, 16, 0, false, false, T, "16 v_exp");
     RUN(0, 16, 1, false, false, T, "16 v_fma");
     RUN(0, 16, 2, false, false, T, "16 v_max3");
+    RUN(0, 16, 4, false, false, T, "16 v_exp_f16 (bare)");
     RUN(8, 8, 0, false, false, T, "8 mfma16 + 8 v_exp (one stream)");
     RUN(8, 16, 0, false, false, T, "8 mfma16 + 16 v_exp (one stream)");
     RUN(8, 32, 0, false, false, T, "8 mfma16 + 32 v_exp (one stream)");
