@@ -152,7 +152,7 @@ def test_multicontext_sampling(golden, param_shapes):
 
 
 @pytest.mark.parametrize("case", ["c2", "c3", "c5"])
-def test_trajectory_fixture_first_and_last_step(case):
+def test_trajectory_fixture_first_and_last_step(case, monkeypatch):
     """tests/golden/trajectories.npz (the oracle trajectories the GPU suite compares whole DDIM runs with at the BASELINE
     shapes, oracle/make_trajectory_golden.py) is what THIS oracle computes: the first DDIM step of every case -- context
     encode (SeeCoder / SeeCoder-PA at 512x512 / 768x768), one CFG UNet evaluation (64x64 / 96x96 latent; with the
@@ -168,6 +168,22 @@ def test_trajectory_fixture_first_and_last_step(case):
         f"tests/golden/trajectories.npz was written from other oracle sources ({meta.get('oracle_sources')}): re-run oracle/make_trajectory_golden.py"
     want_steps = {"c2": 50, "c3": 10, "c5": 31}[case]
     assert meta["cases"][case]["steps"] == want_steps
+    # the two pin runs share their synthetic weights and their context encode (same seeds, same image): computed once
+    import pfd_oracle as O
+    sd_memo, enc_memo, make_sd, encode = {}, {}, OW._sd, O.seecoder_encode
+
+    def sd_once(shapes, prefix):
+        if prefix not in sd_memo:
+            sd_memo[prefix] = make_sd(shapes, prefix)
+        return dict(sd_memo[prefix])
+
+    def encode_once(sd, prefix, img):
+        key = (prefix, tuple(img.shape), float(img.double().sum()), len(sd))
+        if key not in enc_memo:
+            enc_memo[key] = encode(sd, prefix, img)
+        return enc_memo[key].clone()
+    monkeypatch.setattr(OW, "_sd", sd_once)
+    monkeypatch.setattr(O, "seecoder_encode", encode_once)
     with torch.no_grad():
         got = OW.CASES[case](OW._param_shapes(), stop_after=1)
         last = OW.CASES[case](OW._param_shapes(), last_from=T(fx[f"{case}.penultimate"]))
