@@ -7,6 +7,8 @@
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 #include <stdlib.h>
+#include <cstring>
+#include <cstdlib>
 #include <vector>
 
 typedef _Float16 half8_t __attribute__((ext_vector_type(8)));
@@ -152,13 +154,42 @@ static void run_rnd(const char* label, int threads, const float* din, float* dou
   fflush(stdout);
 }
 
-int main() {
+// `mfma_valu sustain16 | sustain32 [seconds]`: the random-operand MFMA stream launched back to back for seconds (default 4), TFLOP/s of
+// every half second -- long enough for tools/clock_trace.py to see the clock and board power the chip settles at under a pure matrix load
+template <bool BIG>
+static void sustain(double seconds, const float* din, float* dout, long long* dcyc) {
+  const int iters = 20000, blocks = 256, threads = 512, nw = blocks * threads / 64;
+  const double flops = 2.0 * (BIG ? 32.0 * 32 * 16 : 16.0 * 16 * 32) * 8 * (double)iters * nw;
+  hipEvent_t e0, e1;
+  hipEventCreate(&e0); hipEventCreate(&e1);
+  double total = 0;
+  while (total < seconds * 1e3) {
+    int n = 0;
+    float ms = 0;
+    hipEventRecord(e0, 0);
+    for (; n < 150; ++n) hipLaunchKernelGGL((k_rnd<8, BIG>), dim3(blocks), dim3(threads), 0, 0, din, dout, dcyc, iters);
+    hipEventRecord(e1, 0);
+    hipEventSynchronize(e1);
+    hipEventElapsedTime(&ms, e0, e1);
+    total += ms;
+    printf("%s sustained: %6.0f ms  %7.1f TFLOP/s\n", BIG ? "mfma32x32x16" : "mfma16x16x32", total, flops * n / (ms * 1e-3) / 1e12);
+    fflush(stdout);
+  }
+}
+
+int main(int argc, char** argv) {
   float *din, *dout;
   long long* dcyc;
   hipMalloc(&din, 256 * 4); hipMalloc(&dout, 256 * 512 * 4); hipMalloc(&dcyc, 256 * 8 * 8);
   std::vector<float> h(256);
   for (int i = 0; i < 256; ++i) h[i] = (float)(i % 17) * 0.01f;
   hipMemcpy(din, h.data(), 1024, hipMemcpyHostToDevice);
+  if (argc > 1 && !strncmp(argv[1], "sustain", 7)) {
+    const double sec = argc > 2 ? atof(argv[2]) : 4.0;
+    if (!strcmp(argv[1], "sustain32")) sustain<true>(sec, din, dout, dcyc);
+    else sustain<false>(sec, din, dout, dcyc);
+    return 0;
+  }
 #define RUN(NM, NV, VK, BIG, SPLIT, T, L) run<NM, NV, VK, BIG, SPLIT>(L, T, din, dout, dcyc)
   for (int T = 256; T <= 512; T += 256) {
     RUN(8, 0, 0, false, false, T, "8 mfma16x16x32");
