@@ -78,8 +78,9 @@ def all_gather_batch(local, world_size):
 
 
 class _GraphedStage:
-    """One stage (context encode, VAE decode) replayed as a hipGraph: ~1500 / ~150 launches per call whose
-    issue cost is otherwise paid by the host every batch (SeeCoder: 8 ms eager vs ~3 ms of GPU work).  One
+    """One stage (context encode, VAE decode) replayed as a hipGraph: ~920 / ~105 kernel launches per call at C2
+    (426 / 75 of them the library's, tools/stage_launches.py) whose issue cost is otherwise paid by the host every
+    batch (SeeCoder: 5.8 ms of device time in launches of 4-16 us).  One
     graph per (input shape, dtype, weights identity+version of the sub-model); static input buffer owned here;
     the same kernels as the eager path.  A capture that fails RAISES (like DDIMSampler._capture): a stage
     that silently fell back to eager launches would hide exactly the kind of capture-illegal call (host sync,
