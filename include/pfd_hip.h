@@ -95,8 +95,12 @@ typedef struct PfdGemmDesc {
   int32_t ksize, stride, pad, ups;
   int32_t B, H, Wd, Cin; /* input image (before the optional upsample) */
   int32_t Ho, Wo;        /* output image; M must equal B*Ho*Wo          */
-  /* optional fp32 scratch for split-K (small M*N, huge K: the 8x8 / 16x16 UNet levels); the
-   * library never allocates.  NULL / 0 = never split.  Must not be shared by concurrent streams. */
+  /* optional scratch for split-K (small M*N, huge K: the 8x8 / 16x16 UNet levels); the
+   * library never allocates.  NULL / 0 = never split.  Must not be shared by concurrent streams.
+   * A problem is split only when splits * M * N * 4 <= ws_bytes (the rule of every ABI-9 build).  What the library
+   * keeps in it is private: since round 6 the K-range partial sums are stored rounded to f16 and summed in fp32, in
+   * slab order, by the reduction launch (deterministic; the same freedom the reference's default
+   * torch.backends.cuda.matmul.allow_fp16_reduced_precision_reduction = True gives its own split-K GEMMs). */
   void* ws;
   size_t ws_bytes;
   /* optional transposed tail (ABI 3): with Ct != NULL the output columns n >= n_split are not
@@ -175,7 +179,7 @@ typedef struct PfdGemmDesc {
   void* gn_out;
   /* GroupNorm(32 groups)(+SiLU) of the OUTPUT inside the split-K reduction (ABI 9).  At the 8^2 / 16^2 UNet levels every
    * 3x3 convolution splits its contraction (M <= 2048 rows cannot fill 256 CUs otherwise) and a reduction launch sums the
-   * fp32 slabs, applies the epilogue and stores the f16 result -- which a single-launch GroupNorm then reads once more to
+   * partial-sum slabs, applies the epilogue and stores the f16 result -- which a single-launch GroupNorm then reads once more to
    * normalise it (`h = in_layers(x) + emb_out; h = out_layers(h)`: GroupNorm32 -> SiLU -> conv, openaimodel.py:254-272;
    * eps 1e-5).  With gnf_y != NULL the reduction is done by blocks that own one (sample, group) slab of the output
    * (gnf_rows rows x N / 32 channels): they form the epilogue's f16 values, their statistics and

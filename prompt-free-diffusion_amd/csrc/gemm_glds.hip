@@ -49,7 +49,8 @@ struct G160Params {
   const half_t* rowvec;
   const half_t* R;
   half_t* C;
-  float* ws;  // split-K slabs [splits][M][N] fp32
+  float* ws;  // split-K slabs [splits][M][N]: f16 partial sums (round 6; fp32 through round 5), summed in fp32 in slab order by the reduction kernels.
+              // The host still sizes / requires 4 bytes per element (PfdGemmDesc.ws_bytes: the contract of ABI 9 is unchanged)
   half_t* Ct;  // transposed tail: columns >= n_split -> Ct[(n - n_split) * ldct + m]
   long ldct;
   int n_split;
@@ -270,14 +271,19 @@ __device__ __forceinline__ bool epilogue_stage(float4_t (&acc)[WMB][NT], const G
     }
   }
 
-  if (!GEGLU_ONLY && p.splits > 1) {  // split-K: raw fp32 partials, [split][M][N]
+  if (!GEGLU_ONLY && p.splits > 1) {  // split-K: raw partials, [split][M][N], rounded to f16 (see G160Params.ws)
+    half_t* const wsh = reinterpret_cast<half_t*>(p.ws);
 #pragma unroll
     for (int i = 0; i < WMB; ++i) {
       const int m = mrow(lr0 + i * 16);
       if (m >= p.M) continue;
 #pragma unroll
-      for (int j = 0; j < NT; ++j)
-        gst<float4_t>(p.ws + ((long)split * p.M + m) * p.N + nw + j * 16, acc[i][j]);
+      for (int j = 0; j < NT; ++j) {
+        Pack8 h;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) h.e[r] = (half_t)acc[i][j][r];
+        gst<uint2>(wsh + ((long)split * p.M + m) * p.N + nw + j * 16, h.u);
+      }
     }
     return false;
   }
@@ -1655,21 +1661,16 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const G160Params p) 
     rr.u = *reinterpret_cast<const uint4*>(p.R ? p.R + res_row(p, m) * p.ldr + n : g_zero_page);
     float v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     for (int s0 = 0; s0 < p.splits; s0 += 4) {
-      float4_t a[4], b[4];
+      Pack16 a[4];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const float* src = p.ws + ((long)min(s0 + u, p.splits - 1) * p.M + m) * p.N + n;
-        a[u] = *reinterpret_cast<const float4_t*>(src);
-        b[u] = *reinterpret_cast<const float4_t*>(src + 4);
-      }
+      for (int u = 0; u < 4; ++u)
+        a[u].u = *reinterpret_cast<const uint4*>(reinterpret_cast<const half_t*>(p.ws) +
+                                                 ((long)min(s0 + u, p.splits - 1) * p.M + m) * p.N + n);
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
         const float w = s0 + u < p.splits ? 1.f : 0.f;   // the clamped duplicates add nothing
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          v[e] += a[u][e] * w;
-          v[4 + e] += b[u][e] * w;
-        }
+        for (int e = 0; e < 8; ++e) v[e] += (float)a[u].e[e] * w;
       }
     }
     if (p.ln_in) {   // LayerNorm folded into this GEMM: the affine map of epilogue_stage, on the reduced accumulator
@@ -1749,25 +1750,20 @@ __global__ __launch_bounds__(RGN_T) void splitk_reduce_gn_kernel(const G160Param
       for (int e = 0; e < 8; ++e) v[u][e] = 0.f;
     }
     for (int s0 = 0; s0 < p.splits; s0 += 4) {   // same order of the slabs as splitk_reduce_kernel
-      float4_t a[U][4], b[U][4];
+      Pack16 a[U][4];
 #pragma unroll
       for (int u = 0; u < U; ++u)
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          const float* src = p.ws + ((long)min(s0 + k, p.splits - 1) * p.M + m[u]) * p.N + n;
-          a[u][k] = *reinterpret_cast<const float4_t*>(src);
-          b[u][k] = *reinterpret_cast<const float4_t*>(src + 4);
-        }
+        for (int k = 0; k < 4; ++k)
+          a[u][k].u = *reinterpret_cast<const uint4*>(reinterpret_cast<const half_t*>(p.ws) +
+                                                      ((long)min(s0 + k, p.splits - 1) * p.M + m[u]) * p.N + n);
 #pragma unroll
       for (int u = 0; u < U; ++u)
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
           const float wgt = s0 + k < p.splits ? 1.f : 0.f;
 #pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            v[u][e] += a[u][k][e] * wgt;
-            v[u][4 + e] += b[u][k][e] * wgt;
-          }
+          for (int e = 0; e < 8; ++e) v[u][e] += (float)a[u][k].e[e] * wgt;
         }
     }
 #pragma unroll
@@ -1877,20 +1873,20 @@ __global__ __launch_bounds__(GNF_T) void splitk_reduce_gnorm_kernel(const G160Pa
 #pragma unroll
       for (int e = 0; e < 4; ++e) acc[u][e] = 0.f;
     for (int s0 = 0; s0 < p.splits; s0 += 4) {   // the slab order of splitk_reduce_kernel
-      float4_t a[GNF_U][4];
+      Pack8 a[GNF_U][4];
 #pragma unroll
       for (int u = 0; u < GNF_U; ++u)
 #pragma unroll
         for (int q = 0; q < 4; ++q)
-          a[u][q] = *reinterpret_cast<const float4_t*>(p.ws + ((long)min(s0 + q, p.splits - 1) * p.M + m_b + ru[u]) * p.N +
-                                                       n_g + cu[u] * 4);
+          a[u][q].u = *reinterpret_cast<const uint2*>(reinterpret_cast<const half_t*>(p.ws) +
+                                                      ((long)min(s0 + q, p.splits - 1) * p.M + m_b + ru[u]) * p.N + n_g + cu[u] * 4);
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         const float w = s0 + q < p.splits ? 1.f : 0.f;   // the clamped duplicates add nothing
 #pragma unroll
         for (int u = 0; u < GNF_U; ++u)
 #pragma unroll
-          for (int e = 0; e < 4; ++e) acc[u][e] += a[u][q][e] * w;
+          for (int e = 0; e < 4; ++e) acc[u][e] += (float)a[u][q].e[e] * w;
       }
     }
 #pragma unroll
@@ -1982,7 +1978,7 @@ inline void launch_splitk_reduce(const G160Params& p, hipStream_t s) {
   if (pfd_prof_on()) {
     pfd_prof_end(s);
     const double mn = (double)p.M * p.N;
-    pfd_prof_begin(21, 0.0, 4.0 * p.splits * mn + 2.0 * mn * (1 + (p.R ? 1 : 0) + (t_gnf.y ? 1 : 0)), s);
+    pfd_prof_begin(21, 0.0, 2.0 * p.splits * mn + 2.0 * mn * (1 + (p.R ? 1 : 0) + (t_gnf.y ? 1 : 0)), s);
   }
   if (t_gnf.y) {   // (host: no gn_out / ln_out with it)
     const GnFuse f = t_gnf;
