@@ -271,24 +271,12 @@ __device__ __forceinline__ bool epilogue_stage(float4_t (&acc)[WMB][NT], const G
     }
   }
 
-  if (!GEGLU_ONLY && p.splits > 1) {  // split-K: raw partials, [split][M][N], rounded to f16 (see G160Params.ws)
-    half_t* const wsh = reinterpret_cast<half_t*>(p.ws);
-#pragma unroll
-    for (int i = 0; i < WMB; ++i) {
-      const int m = mrow(lr0 + i * 16);
-      if (m >= p.M) continue;
-#pragma unroll
-      for (int j = 0; j < NT; ++j) {
-        Pack8 h;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) h.e[r] = (half_t)acc[i][j][r];
-        gst<uint2>(wsh + ((long)split * p.M + m) * p.N + nw + j * 16, h.u);
-      }
-    }
-    return false;
-  }
+  // split-K: this block's partial sums go to its slab [split][M][N] rounded to f16 (see G160Params.ws) -- through the SAME staging
+  // image and store pass as a finished tile (whole 16-byte chunks of contiguous row segments; the 8-byte stores straight from the
+  // accumulators are the 2.3 TB/s form described below), only without bias / row vector / activation, which the reduction applies
+  const bool slab = !GEGLU_ONLY && p.splits > 1;
 
-  if (!GEGLU_ONLY && p.Ct && n0 >= p.n_split) {  // transposed tail (tile-uniform): Ct[(n - n_split) * ldct + m] (+ bias)
+  if (!GEGLU_ONLY && !slab && p.Ct && n0 >= p.n_split) {  // transposed tail (tile-uniform): Ct[(n - n_split) * ldct + m] (+ bias)
     float bv[NT][4];
     const half_t* bp = p.bias ? p.bias + nw : g_zero_page;   // unconditional 8-byte loads (see pass 1 below)
     const int bstep = p.bias ? 16 : 0;
@@ -324,8 +312,9 @@ __device__ __forceinline__ bool epilogue_stage(float4_t (&acc)[WMB][NT], const G
   // as branch + load + s_waitcnt vmcnt(0), so the NT bias loads and WMB x NT row-vector loads went out one L2 round
   // trip at a time (up to 25 per tile, on tiles whose whole K loop is 5 steps).  An absent bias reads the zero page
   // with stride 0; a row past M reads row M - 1 (its result is never stored).
-  const half_t* bp = p.bias ? p.bias + nw : g_zero_page;
-  const int bstep = p.bias ? 16 : 0;
+  const bool has_bias = p.bias && !slab;
+  const half_t* bp = has_bias ? p.bias + nw : g_zero_page;
+  const int bstep = has_bias ? 16 : 0;
   Pack8 bq[NT];
 #pragma unroll
   for (int j = 0; j < NT; ++j) bq[j].u = gld<uint2>(bp + j * bstep);
@@ -384,7 +373,7 @@ __device__ __forceinline__ bool epilogue_stage(float4_t (&acc)[WMB][NT], const G
     auto run = [&](auto act) __attribute__((always_inline)) {
       Pack8 cur[NT];
       const int first = mrow(wm * WMB * 16), last = mrow(wm * WMB * 16 + WMB * 16 - 1);   // this wave's first / last output row
-      if (!p.rowvec) {
+      if (!p.rowvec || slab) {
 #pragma unroll
         for (int j = 0; j < NT; ++j) cur[j].u = make_uint2(0, 0);
         for_rows([&](auto it) __attribute__((always_inline)) { put_row(act, it, cur); });
@@ -408,7 +397,7 @@ __device__ __forceinline__ bool epilogue_stage(float4_t (&acc)[WMB][NT], const G
         });
       }
     };
-    switch (p.act) {
+    switch (slab ? PFD_ACT_NONE : p.act) {
       case PFD_ACT_GELU: run(std::integral_constant<int, PFD_ACT_GELU>{}); break;
       case PFD_ACT_RELU: run(std::integral_constant<int, PFD_ACT_RELU>{}); break;
       case PFD_ACT_SILU: run(std::integral_constant<int, PFD_ACT_SILU>{}); break;
@@ -537,16 +526,19 @@ template <int BM, int NT, int NTHREADS, bool LNOUT = false, bool PT = false>
 __device__ __forceinline__ void epilogue_store(const G160Params& p, int m0, int n0, char* smem, int tid, int slab0 = 0) {
   constexpr int BN = 32 * NT;
   constexpr bool GEGLU_ONLY = NT == 10;
-  if (!GEGLU_ONLY && (p.splits > 1 || (p.Ct && n0 >= p.n_split))) return;   // written directly by pass 1 (tile-uniform)
-  const bool geglu = GEGLU_ONLY || p.act == PFD_ACT_GEGLU;
+  const bool slab = !GEGLU_ONLY && p.splits > 1;   // split-K: the staged partial sums go to this block's slab, nothing else happens here
+  if (!GEGLU_ONLY && !slab && p.Ct && n0 >= p.n_split) return;   // written directly by pass 1 (tile-uniform)
+  const bool geglu = GEGLU_ONLY || (!slab && p.act == PFD_ACT_GEGLU);
+  half_t* const Cb = slab ? reinterpret_cast<half_t*>(p.ws) + (long)blockIdx.z * p.M * p.N : p.C;
+  const long ldc = slab ? (long)p.N : p.ldc;
   if constexpr (NT == 5) {
-    if (p.gn_out) {   // the store pass that also forms the GroupNorm statistics of what it stores (host: act != GEGLU, no Ct)
+    if (p.gn_out && !slab) {   // the store pass that also forms the GroupNorm statistics of what it stores (host: act != GEGLU, no Ct)
       epilogue_store_gn<BM, NTHREADS, PT>(p, m0, n0, slab0, smem, tid);
       return;
     }
   }
   if constexpr (LNOUT && !GEGLU_ONLY && (BN / 8) % 4 == 0) {
-    if (p.ln_out) {
+    if (p.ln_out && !slab) {
       // This launch's output feeds a LayerNorm that is folded into ITS consumer GEMM: emit the partial row sums
       // (sum, sum of squares of the f16 values stored, i.e. exactly what a LayerNorm kernel would read) of the BN
       // columns this tile holds.  Four lanes per row, lane k takes chunks k, k + 4, ...: every store instruction still
@@ -599,7 +591,7 @@ __device__ __forceinline__ void epilogue_store(const G160Params& p, int m0, int 
     constexpr int TOTAL = BM * CPR;
     constexpr int ITERS = (TOTAL + NTHREADS - 1) / NTHREADS;
     constexpr int U = ITERS < 5 ? ITERS : 5;   // chunks per thread whose residual loads are in flight together
-    const bool has_r = p.R != nullptr;
+    const bool has_r = p.R != nullptr && !slab;
     for (int it0 = 0; it0 < ITERS; it0 += U) {
       Pack16 r[U];
       // the residual chunks of this group first, unconditional (clamped chunk / row): one load inside `if (p.R)` per
@@ -624,7 +616,7 @@ __device__ __forceinline__ void epilogue_store(const G160Params& p, int m0, int 
 #pragma unroll
           for (int e = 0; e < 8; ++e) v.e[e] = (half_t)((float)v.e[e] + (float)r[u].e[e]);
         }
-        gst<uint4>(p.C + (long)m * p.ldc + nc0 + cc * 8, v.u);
+        gst<uint4>(Cb + (long)m * ldc + nc0 + cc * 8, v.u);
       }
     }
   };
