@@ -100,7 +100,8 @@ typedef struct PfdGemmDesc {
    * A problem is split only when splits * M * N * 4 <= ws_bytes (the rule of every ABI-9 build).  What the library
    * keeps in it is private: since round 6 the K-range partial sums are stored rounded to f16 and summed in fp32, in
    * slab order, by the reduction launch (deterministic; the same freedom the reference's default
-   * torch.backends.cuda.matmul.allow_fp16_reduced_precision_reduction = True gives its own split-K GEMMs). */
+   * torch.backends.cuda.matmul.allow_fp16_reduced_precision_reduction = True gives its own split-K GEMMs); a
+   * partial sum beyond +-65504 becomes +-inf exactly as an f16 result of that magnitude would. */
   void* ws;
   size_t ws_bytes;
   /* optional transposed tail (ABI 3): with Ct != NULL the output columns n >= n_split are not
