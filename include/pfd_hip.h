@@ -187,10 +187,11 @@ typedef struct PfdGemmDesc {
    *     gnf_y[m, n] = act((out[m, n] - mean) * rstd * gnf_gamma[n] + gnf_beta[n])      (act = NONE | SILU)
    * in one launch; the raw result is ALSO stored to C unless gnf_skip_raw != 0 (a tensor only its GroupNorm reads: the
    * first convolution of a ResBlock).  Same arithmetic, in the same order, as the plain reduction followed by
-   * pfd_groupnorm_f16 on its output: the same bits.  Served only where the library splits K (it decides; M small) and --
-   * the conditions under which pfd_groupnorm_f16 takes its single-launch form, so that the two-call fallback stays
-   * bit-identical -- N % 160 == 0, (N / 32) % 4 == 0, 32 <= N / 32 <= 256 (N >= 1024: N = 640 is refused although its
-   * groups are whole multiples of 4 channels), gnf_rows > 0, M % gnf_rows == 0, gnf_rows * (N / 128) <= 8192, at least four
+   * pfd_groupnorm_f16 on its output: the same bits wherever pfd_groupnorm_f16 takes its single-launch form (N >= 1024);
+   * at N = 640 (20 channels per group: the 32x32 UNet level, served since round 6) the raw result is still bitwise the
+   * two-call form's and the normalised one agrees with it up to the summation order of the statistics (last-bit
+   * roundings in < 0.1 % of the elements).  Served only where the library splits K (it decides; M small) and
+   * N % 160 == 0, (N / 32) % 4 == 0, 20 <= N / 32 <= 256, gnf_rows > 0, M % gnf_rows == 0, gnf_rows * (N / 128) <= 8192, at least four
    * samples ((M / gnf_rows) * 32 >= 128 slabs), ws != NULL, gnf_ldy % 4 == 0, gnf_y 8-byte aligned, gnf_act in {NONE, SILU},
    * rowvec == NULL or one row vector per sample (rows_per_rv % gnf_rows == 0 or rows_per_rv >= M), act != GEGLU, no Ct /
    * ln_stats / ln_out / gn_out / bias_per_row / res_rows; anything else -- including a problem the library would not split

@@ -2139,7 +2139,7 @@ int pfd_gemm160_try(const PfdGemmDesc* d, int variant, int splits, hipStream_t s
   const bool gnf = d->gnf_y != nullptr;
   if (gnf) {
     const int cpg = d->N / 32;
-    if (bn != 160 || (d->N % 32) || (cpg % 4) || cpg < 32 || cpg > 256 || d->gnf_rows <= 0 || (d->M % d->gnf_rows) ||
+    if (bn != 160 || (d->N % 32) || (cpg % 4) || cpg < 20 || cpg > 256 || d->gnf_rows <= 0 || (d->M % d->gnf_rows) ||
         (long)d->gnf_rows * (cpg / 4) > (long)GNF_T * GNF_MAX || (long)(d->M / d->gnf_rows) * 32 < 128 || !d->gnf_gamma || !d->gnf_beta ||
         (d->gnf_ldy & 3) || (reinterpret_cast<uintptr_t>(d->gnf_y) & 7) || d->act == PFD_ACT_GEGLU || d->Ct || d->ln_stats ||
         d->ln_out || d->gn_out || d->bias_per_row || !d->ws ||

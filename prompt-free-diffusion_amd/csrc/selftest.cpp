@@ -748,12 +748,16 @@ static void run_gnf_case(int B, int H, int W, int Cin, int N, int act_gn, float 
     const unsigned short one = 0x3C3C;
     nraw_written += memcmp(&c[i], &one, sizeof(h16)) != 0;
   }
-  const bool ok = rc2 == 0 && rc3 == 0 && ny == 0 && (keep_raw ? nc == 0 : nraw_written == 0);
+  // 20 channels per group (N = 640, round 6): pfd_groupnorm_f16 takes its two-launch form there, whose statistics are summed in another
+  // order -- the normalised tensors then agree except for last-bit roundings (< 0.1 % of the elements); the raw tensor stays bitwise
+  const bool bitwise = N / 32 >= 32;
+  const bool ok = rc2 == 0 && rc3 == 0 && (bitwise ? ny == 0 : ny * 1000 < y.size()) && (keep_raw ? nc == 0 : nraw_written == 0);
   if (!ok) {
     ++g_fail;
     printf("FAIL %-58s rc %d %d: normalised %zu of %zu elements differ, raw %zu differ, raw written %zu\n", name, rc2, rc3, ny, y.size(), nc, nraw_written);
   } else {
-    printf("ok   %-58s == conv + groupnorm (bitwise)%s\n", name, keep_raw ? ", raw too" : ", raw tensor not written");
+    printf("ok   %-58s == conv + groupnorm (%s)%s\n", name, bitwise ? "bitwise" : "last-bit roundings of the statistics order only",
+           keep_raw ? ", raw too (bitwise)" : ", raw tensor not written");
   }
   // and the two-call form itself against fp64 (so that "the same bits" is not the same wrong bits): GroupNorm of the stored raw tensor
   std::vector<double> ref(y2.size());
@@ -1608,7 +1612,11 @@ int main(int argc, char** argv) {
     run_gnf_case(8, 16, 16, 1280, 1280, PFD_ACT_SILU, 1e-5f, false, true, false, 10802);   // forced patch kernel, split 2
     run_gnf_case(8, 8, 8, 1280, 1280, PFD_ACT_SILU, 1e-5f, false, true, false, 3308);        // forced 4-stage ring, split 8
     run_gnf_decline_case(8, 64, 64, 320, 320);                                          // 64^2: not split, cpg 10
-    run_gnf_decline_case(8, 32, 32, 640, 640);                                          // cpg 20: the fused form is not built for it
+    // round 6: the 640-channel norms of the 32^2 level (20 channels per group, 1024 x 5 chunks per slab)
+    run_gnf_case(8, 32, 32, 640, 640, PFD_ACT_SILU, 1e-5f, false, true, false);         // ResBlock conv1 @32^2 (patch kernel, split 2)
+    run_gnf_case(8, 32, 32, 640, 640, PFD_ACT_SILU, 1e-5f, true, false, true);          // conv2: + residual, raw kept for the skip
+    run_gnf_case(8, 32, 32, 1280, 640, PFD_ACT_SILU, 1e-5f, false, true, false);        // over a skip concat width
+    run_gnf_case(4, 32, 32, 320, 640, PFD_ACT_SILU, 1e-5f, false, true, false);         // first ResBlock of the level, UNet batch 4
     // residual stored once for a doubled batch (PfdGemmDesc.res_rows): every store pass and both plain reductions
     for (int v : {0, 9200, 9300, 3200, 3300, 5400, 5800}) {
       { GemmCase c{1024, 320, 256, 0, true, true, true, false, v}; c.res_rows = 512; run_gemm_case(c); }                      // plain store pass

@@ -194,6 +194,36 @@ def test_conv_with_groupnorm_in_its_splitk_reduction(B, hw, cin, silu, res):
     assert c64.hip_gn(_dev(2, 64, 64, 320), g64) is None
 
 
+@pytest.mark.parametrize("B,cin,res", [(8, 640, False), (8, 1280, True), (4, 320, False)])
+def test_conv_with_groupnorm_in_its_splitk_reduction_at_20_channels_per_group(B, cin, res):
+    """the same fusion for the 640-channel norms of the 32x32 level (round 6): served; the raw tensor (when kept) is bitwise the
+    two-call form's; the normalised tensor agrees with it except for last-bit roundings (the two-call GroupNorm of this
+    shape sums its statistics in another order) and with torch fp32 within fp16 noise"""
+    from lib.hip import layers as L
+    torch.manual_seed(12)
+    cout, hw = 640, 32
+    conv = L.Conv2d(cin, cout, 3, padding=1).half().cuda()
+    gn = L.GroupNorm(32, cout, eps=1e-5).half().cuda()
+    with torch.no_grad():
+        gn.weight.normal_(1.0, 0.2)
+        gn.bias.normal_(0.0, 0.2)
+    x = _dev(B, hw, hw, cin, scale=1.0)
+    e = _dev(B, cout, seed=7)
+    r = _dev(B, hw, hw, cout, seed=6) if res else None
+    fused = conv.hip_gn(x, gn, silu=True, keep_raw=res, rowvec=e, res=r)
+    assert fused is not None, "the 32^2 convolutions split K: the fused reduction must serve them"
+    raw, y = fused
+    h = conv.hip(x, rowvec=e, res=r)
+    two = gn.hip(h, silu=True)
+    assert float((y != two).float().mean()) < 1e-3 and float((y.float() - two.float()).abs().max()) < 1e-2
+    assert (raw is None) == (not res) and (raw is None or torch.equal(raw, h))
+    ref = F.conv2d(x.float().permute(0, 3, 1, 2), conv.weight.float(), conv.bias.float(), padding=1) + e.float()[:, :, None, None]
+    if res:
+        ref = ref + r.float().permute(0, 3, 1, 2)
+    ref = F.silu(F.group_norm(ref, 32, gn.weight.float(), gn.bias.float(), 1e-5)).permute(0, 2, 3, 1)
+    close(y.float(), ref)
+
+
 def test_groupnorm_concat_and_layernorm():
     from lib.hip import ops
     x1, x2 = _dev(2, 6, 5, 320), _dev(2, 6, 5, 640, seed=3)
